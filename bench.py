@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the BBMM hot path (contract: see task statement / DESIGN.md "Measurement").
+
+One "step" = one ExactGP marginal-log-likelihood evaluation on synthetic data of
+BASELINE.json configs[1] (n = 100 000, d = 3, RBF, 64 probe vectors + the y column, no
+preconditioner, reference-default cg_tolerance = 1 => 21 mBCG iterations): probe draw, fused
+K*V (MFMA) x iterations, device-resident CG vector updates, SLQ log-det, inverse quadratic form.
+Inputs are resident in HBM before the timed region.
+
+  value      = algorithmic K*V flops of the step (2 n^2 (t+1) x CG iterations, summed over ranks)
+               / max-over-ranks wall time                                   [TFLOP/s]
+  roofline   = the dominant kernel (kv_mfma) timed live with HIP events on its launch stream:
+               2 n^2 (t+1) flop per launch / mean launch duration vs 157.3 TF fp32 MFMA peak
+  cpu_baseline = the oracle's matrix-free K*V (the reference's chunked path,
+               lazy_evaluated_kernel_tensor.py:245-275, restated in torch) timed on the host cores
+               on a bounded row-sample of the same K*V
+
+N > 1: one process per GPU; each rank owns 64 probes of a 64*N global probe set (weak scaling);
+the only data-path collective is the 2-float stopping-rule all-reduce per CG iteration and the
+final scalar SLQ all-reduce (RCCL).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+
+
+def synth(n, d, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.rand(n, d, generator=g, dtype=torch.float32)
+    y = torch.sin(2 * math.pi * X[:, 0]) + torch.cos(math.pi * X.sum(-1)) + 0.1 * torch.randn(n, generator=g)
+    return X, y
+
+
+def cpu_baseline(n, d, t, ls, budget_rows=4096):
+    """Oracle (port) K*V throughput on the host: rows [0, budget_rows) of one K*V, all n columns."""
+    from oracle import kernels as OK
+
+    X, _ = synth(n, d)
+    X = X.double()
+    V = torch.randn(n, t, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    rows = min(budget_rows, n)
+    t0 = time.perf_counter()
+    OK.kernel_matmul_chunked("rbf", X[:rows], X, ls, 1.0, V, chunk=1024)
+    dt = time.perf_counter() - t0
+    flops = 2.0 * rows * n * t
+    return {
+        "value": flops / dt / 1e12,
+        "unit": "TFLOP/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"rows 0:{rows} of one n={n} K*V with t={t} (chunked matrix-free path, float64), {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=100_000)
+    ap.add_argument("--d", type=int, default=3)
+    ap.add_argument("--probes", type=int, default=64)
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        group = torch.distributed.group.WORLD
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from gpytorch_amd import backend as B
+    from gpytorch_amd import linear_cg as LCG
+    from gpytorch_amd.bbmm import LOG_2PI, inv_quad_logdet_forward
+
+    n, d, t = args.n, args.d, args.probes
+    ls = {3: 0.25, 10: 0.8, 6: 0.5}.get(d, 0.25)
+    X, y = synth(n, d)
+    Xd, yd = X.to(dev), y.to(dev)
+    lengthscale = torch.tensor([ls], device=dev)
+    outputscale = torch.tensor([1.0], device=dev)
+    noise = torch.tensor([0.1], device=dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    rhs_t = B.to_probe_major(yd.unsqueeze(-1))
+    t_total = t * world
+
+    def step():
+        xp = B.prep_points("rbf", Xd, lengthscale)
+        res = inv_quad_logdet_forward(
+            xp, outputscale, noise, rhs_t, num_probes=t, precond=None, generator=gen, group=group, t_total=t_total
+        )
+        mll = -0.5 * (res.inv_quad.sum() + res.logdet + n * LOG_2PI) / n
+        return mll, res.info.iterations
+
+    def barrier():
+        if group is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    LCG.KV_EVENT_LOG = []
+    barrier()
+    t0 = time.perf_counter()
+    iters_total = 0
+    mll = None
+    for _ in range(args.steps):
+        mll, it = step()
+        iters_total += it
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(et, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(et.item())
+
+    # dominant-kernel timing from the HIP events recorded on the launch stream inside the timed region
+    durs = sorted(e0.elapsed_time(e1) for (e0, e1, _, _, _) in LCG.KV_EVENT_LOG)
+    LCG.KV_EVENT_LOG = None
+    med = durs[len(durs) // 2]
+    live = [x for x in durs if x > 0.2 * med]  # launches issued after convergence are device-side no-ops
+    kv_ms = sum(live) / len(live)
+    cols = t + 1
+    flop_per_launch = 2.0 * n * n * cols
+    achieved = flop_per_launch / (kv_ms * 1e-3) / 1e12
+
+    flops_step_rank = flop_per_launch * (iters_total / args.steps)
+    value = flops_step_rank * world * args.steps / elapsed / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "exactgp_mll_kv_tflops",
+            "value": value,
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"ExactGP MLL forward, RBF, n={n}, d={d}, {t} probes/GPU + y column, no preconditioner, cg_tolerance=1.0",
+                "n": n, "d": d, "probes_per_gpu": t, "rhs_columns": cols, "cg_iterations_per_step": iters_total / args.steps,
+                "parallelism": f"probe-sharded x{world}",
+            },
+            "mll": float(mll),
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": None,
+                "kernel": "kv_mfma_kernel<RBF,DP=4,CT=2,NI=2,EX=1>",
+                "kernel_ms": kv_ms,
+                "launches_timed": len(live),
+                "flop_per_launch": flop_per_launch,
+            },
+        }
+        if not args.skip_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, d, cols, ls)
+        print(json.dumps(out))
+    if group is not None:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

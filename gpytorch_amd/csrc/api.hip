@@ -1,0 +1,430 @@
+// extern "C" entry points of libgpamd.so (see include/gpamd.h for the contract and the reference
+// interfaces each one replaces).  gfx950 only; no torch types, no CPU fallbacks.
+#include "../../include/gpamd.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "cg_kernels.hpp"
+#include "kv_dispatch.hpp"
+#include "kv_valu.hpp"
+#include "misc_kernels.hpp"
+
+using namespace gpamd;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+int num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+float prep_coef(int kind) {
+  switch (kind) {
+    case GPAMD_RBF: return sqrtf(0.5f * 1.4426950408889634f);  // exp(-0.5 s) = exp2(-(0.5 log2 e) s)
+    case GPAMD_MATERN12: return 1.0f;
+    case GPAMD_MATERN32: return sqrtf(3.0f);
+    case GPAMD_MATERN52: return sqrtf(5.0f);
+  }
+  return 0.f;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// column-tile variant for t columns: valu (t <= 8) or mfma CT/EX
+struct KvVariant {
+  bool valu;
+  int tpad;    // valu: 1,2,4,8
+  int ct, ex;  // mfma
+  int bm;      // rows per workgroup
+  int bn;      // j tile
+};
+
+KvVariant pick_variant(int t) {  // t <= 129 handled per launch group
+  KvVariant v{};
+  if (t <= 8) {
+    v.valu = true;
+    v.tpad = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : 8));
+    v.bm = KVV_BM;
+    v.bn = KVV_BN;
+  } else {
+    v.valu = false;
+    if (t % 32 == 1 && t > 1) {
+      v.ct = (t - 1) / 32;
+      v.ex = 1;
+    } else {
+      v.ct = (t + 31) / 32;
+      v.ex = 0;
+    }
+    v.bm = kv_bm_for_ct(v.ct);
+    v.bn = KV_BN;
+  }
+  return v;
+}
+
+constexpr int KV_GROUP = 128;  // columns per launch group (CT = 4); a trailing 129th column rides as EX
+
+// split [0, t) into launch groups of <= 128 (+1) columns
+int group_cols(int t, int g0) {
+  int rem = t - g0;
+  if (rem <= KV_GROUP + 1) return rem;  // includes the 129 = 128 + EX case
+  return KV_GROUP;
+}
+
+void plan_split(int n, int m, int t, int* S, int* jchunk) {
+  // the dominant group decides the grid shape
+  KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t);
+  const int nrb = (n + v.bm - 1) / v.bm;
+  const int slots = num_cus() * 2;  // two resident workgroups per CU (register-limited)
+  const int min_chunk = 4 * v.bn;
+  int smax = m / min_chunk;
+  if (smax < 1) smax = 1;
+  if (smax > 64) smax = 64;
+  int best_s = 1;
+  double best_eff = -1.0;
+  for (int s = 1; s <= smax; ++s) {
+    int jc = ((m + s - 1) / s + v.bn - 1) / v.bn * v.bn;
+    int s_eff = (m + jc - 1) / jc;
+    long units = (long)nrb * s_eff;
+    long rounds = (units + slots - 1) / slots;
+    double eff = (double)units / (double)(rounds * slots);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best_s = s;
+    }
+    if (eff >= 0.92) {
+      best_s = s;
+      break;
+    }
+  }
+  int jc = ((m + best_s - 1) / best_s + v.bn - 1) / v.bn * v.bn;
+  *jchunk = jc;
+  *S = (m + jc - 1) / jc;
+}
+
+int launch_family_mfma(int kind, int dp, int ct, int ex, const KvArgs& a, unsigned grid, hipStream_t st) {
+  switch (kind) {
+    case GPAMD_RBF: return launch_kv_mfma_rbf(dp, ct, ex, a, grid, st);
+    case GPAMD_MATERN12: return launch_kv_mfma_matern12(dp, ct, ex, a, grid, st);
+    case GPAMD_MATERN32: return launch_kv_mfma_matern32(dp, ct, ex, a, grid, st);
+    case GPAMD_MATERN52: return launch_kv_mfma_matern52(dp, ct, ex, a, grid, st);
+  }
+  return -2;
+}
+int launch_family_valu(int kind, int dp, int tpad, const KvArgs& a, unsigned grid, hipStream_t st) {
+  switch (kind) {
+    case GPAMD_RBF: return launch_kv_valu_rbf(dp, tpad, a, grid, st);
+    case GPAMD_MATERN12: return launch_kv_valu_matern12(dp, tpad, a, grid, st);
+    case GPAMD_MATERN32: return launch_kv_valu_matern32(dp, tpad, a, grid, st);
+    case GPAMD_MATERN52: return launch_kv_valu_matern52(dp, tpad, a, grid, st);
+  }
+  return -2;
+}
+
+unsigned col_blocks(int n) {
+  long nb = ((long)n + 1023) / 1024;
+  if (nb < 1) nb = 1;
+  if (nb > CG_MAXNB) nb = CG_MAXNB;
+  return (unsigned)nb;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpamd_abi_version(void) { return GPAMD_ABI_VERSION; }
+const char* gpamd_last_error(void) { return g_err; }
+
+int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, const float* ls, int nls,
+                          const float* shift, float* Xp, int dp, void* stream) {
+  if (kind < 0 || kind > 3) return fail(GPAMD_EINVAL, "prep_points: unknown kind");
+  if (n <= 0 || d <= 0 || dp < d || dp % 4 || (nls != 1 && nls != d)) return fail(GPAMD_EINVAL, "prep_points: bad shape");
+  if (!aligned16(Xp)) return fail(GPAMD_EINVAL, "prep_points: Xp must be 16-byte aligned");
+  long total = (long)n * dp;
+  unsigned grid = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(prep_points_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, n, d, ldx, ls, nls, shift,
+                     prep_coef(kind), Xp, dp);
+  return check_launch("prep_points");
+}
+
+int gpamd_kv_plan(int n, int m, int t, int64_t ldo, int* S_host, int* jchunk_host, int64_t* workspace_floats_host) {
+  if (n <= 0 || m <= 0 || t <= 0) return fail(GPAMD_EINVAL, "kv_plan: bad shape");
+  int S, jc;
+  plan_split(n, m, t, &S, &jc);
+  if (S_host) *S_host = S;
+  if (jchunk_host) *jchunk_host = jc;
+  if (workspace_floats_host) *workspace_floats_host = (int64_t)S * t * ldo;
+  return 0;
+}
+
+int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Vt,
+                          int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, const int* done,
+                          void* stream) {
+  if (kind < 0 || kind > 3) return fail(GPAMD_EINVAL, "kv: unknown kind");
+  if (n <= 0 || m <= 0 || t <= 0 || S <= 0) return fail(GPAMD_EINVAL, "kv: bad shape");
+  if (dp != 4 && dp != 8 && dp != 12 && dp != 16) return fail(GPAMD_EUNSUPPORTED, "kv: padded input dim must be 4, 8, 12 or 16 (d <= 16)");
+  if (ldv % 4 || ldv < m || ldo < n) return fail(GPAMD_EINVAL, "kv: leading dimensions must be >= extent and ldv % 4 == 0");
+  if (!aligned16(Vt) || !aligned16(X1p) || !aligned16(X2p)) return fail(GPAMD_EINVAL, "kv: buffers must be 16-byte aligned");
+  if (jchunk % 4 || (int64_t)jchunk * S < m) return fail(GPAMD_EINVAL, "kv: jchunk*S must cover m and jchunk % 4 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  for (int g0 = 0; g0 < t;) {
+    const int tg = group_cols(t, g0);
+    KvVariant v = pick_variant(tg);
+    KvArgs a;
+    a.X1 = X1p; a.X2 = X2p;
+    a.Vt = Vt + (int64_t)g0 * ldv;
+    a.P = P + (int64_t)g0 * ldo;
+    a.ldv = ldv; a.ldo = ldo; a.pstride = (int64_t)t * ldo;
+    a.n = n; a.m = m; a.t = tg;
+    a.S = S; a.jchunk = jchunk;
+    a.nrb = (n + v.bm - 1) / v.bm;
+    a.done = done;
+    unsigned grid = (unsigned)a.nrb * (unsigned)S;
+    int rc = v.valu ? launch_family_valu(kind, dp, v.tpad, a, grid, st) : launch_family_mfma(kind, dp, v.ct, v.ex, a, grid, st);
+    if (rc) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
+    rc = check_launch("kv_partials");
+    if (rc) return rc;
+    g0 += tg;
+  }
+  return 0;
+}
+
+int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const float* scale, const float* dscale,
+                        const float* Vd, int64_t ldd, float* Out, int64_t ldo, const int* done, void* stream) {
+  if (S <= 0 || t <= 0 || n <= 0) return fail(GPAMD_EINVAL, "kv_reduce: bad shape");
+  if (ldp % 4 || ldo % 4 || (Vd && ldd % 4)) return fail(GPAMD_EINVAL, "kv_reduce: leading dimensions must be multiples of 4");
+  dim3 grid(col_blocks(n), t);
+  hipLaunchKernelGGL((kv_reduce_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, P, S, (int64_t)t * ldp, ldp,
+                     scale, dscale, Vd, ldd, Out, ldo, n, (float*)nullptr, done);
+  return check_launch("kv_reduce");
+}
+
+int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Vt, int64_t ldv,
+                 int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
+                 int64_t ldo, float* workspace, int64_t workspace_floats, void* stream) {
+  int S, jc;
+  if (n <= 0 || m <= 0 || t <= 0) return fail(GPAMD_EINVAL, "kv: bad shape");
+  plan_split(n, m, t, &S, &jc);
+  const int64_t ldp = (n + 3) / 4 * 4;
+  if (workspace_floats < (int64_t)S * t * ldp) return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4))");
+  int rc = gpamd_kv_partials_f32(kind, X1p, n, X2p, m, dp, Vt, ldv, t, workspace, ldp, S, jc, nullptr, stream);
+  if (rc) return rc;
+  return gpamd_kv_reduce_f32(workspace, S, ldp, t, n, scale, dscale, Vd, ldd, Out, ldo, nullptr, stream);
+}
+
+#define KIND_SWITCH(kind, CALL)                     \
+  switch (kind) {                                   \
+    case GPAMD_RBF: { constexpr int KK = KIND_RBF; CALL; } break;       \
+    case GPAMD_MATERN12: { constexpr int KK = KIND_MATERN12; CALL; } break; \
+    case GPAMD_MATERN32: { constexpr int KK = KIND_MATERN32; CALL; } break; \
+    case GPAMD_MATERN52: { constexpr int KK = KIND_MATERN52; CALL; } break; \
+    default: return fail(GPAMD_EINVAL, "unknown kind"); \
+  }
+
+int gpamd_kernel_rows_f32(int kind, const float* X1p, const int64_t* rows, int nrows, const float* X2p, int m, int dp,
+                          const float* scale, float* out, int64_t ldo, void* stream) {
+  if (nrows <= 0 || m <= 0) return fail(GPAMD_EINVAL, "kernel_rows: bad shape");
+  dim3 grid((m + 255) / 256, nrows);
+  KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_rows_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, rows, nrows,
+                                       X2p, m, dp, scale, out, ldo));
+  return check_launch("kernel_rows");
+}
+
+int gpamd_kernel_dense_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* scale,
+                           float* out, int64_t ldo, void* stream) {
+  if (n <= 0 || m <= 0) return fail(GPAMD_EINVAL, "kernel_dense: bad shape");
+  if (n > 65535) return fail(GPAMD_EUNSUPPORTED, "kernel_dense: n > 65535 (materialising K is what this library avoids)");
+  dim3 grid((m + 255) / 256, n);
+  KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_dense_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, n, X2p, m,
+                                       dp, scale, out, ldo));
+  return check_launch("kernel_dense");
+}
+
+int gpamd_kernel_diag_f32(int kind, const float* X1p, const float* X2p, int n, int dp, const float* scale, float* out,
+                          void* stream) {
+  if (n <= 0) return fail(GPAMD_EINVAL, "kernel_diag: bad shape");
+  dim3 grid((n + 255) / 256);
+  KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_diag_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, X2p, n, dp,
+                                       scale, out));
+  return check_launch("kernel_diag");
+}
+
+int gpamd_coldot_f32(const float* A, const float* B, int64_t ld, int n, int t, float* out, float* scratch,
+                     void* stream) {
+  if (n <= 0 || t <= 0 || ld % 4) return fail(GPAMD_EINVAL, "coldot: bad shape");
+  unsigned nb = col_blocks(n);
+  hipLaunchKernelGGL((coldot_kernel<float>), dim3(nb, t), dim3(256), 0, (hipStream_t)stream, A, B, ld, n, scratch,
+                     (const int*)nullptr);
+  hipLaunchKernelGGL((colsum_partials_kernel<float>), dim3(t), dim3(256), 0, (hipStream_t)stream, scratch, (int)nb, out);
+  return check_launch("coldot");
+}
+
+// ------------------------------------------------------------------------------------------- mBCG
+struct gpamd_cg {
+  CgState<float> st;
+};
+
+int64_t gpamd_cg_fscratch_elems(int t, int hist_len) {
+  // bnorm t | rnorm t | rho 2t | stats 4 | alpha_hist h*t | beta_hist h*t | 3 partial arrays t*256
+  return (int64_t)4 * t + 4 + (int64_t)2 * hist_len * t + (int64_t)3 * t * CG_MAXNB;
+}
+int64_t gpamd_cg_iscratch_elems(int t) { return (int64_t)2 * t + 2; }
+
+int gpamd_cg_layout(int t, int hist_len, int64_t* o) {
+  if (!o) return fail(GPAMD_EINVAL, "cg_layout: null output");
+  o[0] = 0;                                   // bnorm
+  o[1] = t;                                   // rnorm
+  o[2] = (int64_t)4 * t + 4;                  // alpha_hist
+  o[3] = (int64_t)4 * t + 4 + (int64_t)hist_len * t;  // beta_hist
+  o[4] = (int64_t)4 * t;                      // stats
+  return 0;
+}
+
+gpamd_cg_t* gpamd_cg_create_f32(int n, int t, int64_t ld, float* X, float* R, float* D, float* Q, float* Z,
+                                float* fscratch, int* iscratch, int hist_len, float eps, float stop_updating_after) {
+  if (n <= 0 || t <= 0 || ld % 4 || ld < n || hist_len < 0) {
+    fail(GPAMD_EINVAL, "cg_create: bad shape");
+    return nullptr;
+  }
+  gpamd_cg* h = new gpamd_cg;
+  CgState<float>& s = h->st;
+  s.X = X; s.R = R; s.D = D; s.Q = Q; s.Z = Z;
+  s.ld = ld; s.n = n; s.t = t; s.nb = (int)col_blocks(n);
+  float* f = fscratch;
+  s.bnorm = f; f += t;
+  s.rnorm = f; f += t;
+  s.rho = f; f += 2 * t;
+  s.stats = f; f += 4;
+  s.alpha_hist = f; f += (int64_t)hist_len * t;
+  s.beta_hist = f; f += (int64_t)hist_len * t;
+  s.part_a = f; f += (int64_t)t * CG_MAXNB;
+  s.part_rz = f; f += (int64_t)t * CG_MAXNB;
+  s.part_rr = f;
+  s.hist_len = hist_len;
+  s.zero_rhs = iscratch;
+  s.converged = iscratch + t;
+  s.done = iscratch + 2 * t;
+  s.eps = eps;
+  s.stop_updating_after = stop_updating_after;
+  return h;
+}
+void gpamd_cg_destroy(gpamd_cg_t* h) { delete h; }
+const int* gpamd_cg_done_ptr(const gpamd_cg_t* h) { return h ? h->st.done : nullptr; }
+
+int gpamd_cg_init_f32(gpamd_cg_t* h, const float* B, int64_t ldb, int have_precond, void* stream) {
+  if (!h || ldb % 4) return fail(GPAMD_EINVAL, "cg_init: bad arguments");
+  CgState<float>& s = h->st;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(s.nb, s.t);
+  hipMemsetAsync(s.done, 0, 2 * sizeof(int), st);
+  hipLaunchKernelGGL((coldot_kernel<float>), grid, dim3(256), 0, st, B, B, ldb, s.n, s.part_a, (const int*)nullptr);
+  hipLaunchKernelGGL((cg_init_kernel<float>), grid, dim3(256), 0, st, s, B, ldb, have_precond ? 0 : 1);
+  if (!have_precond) hipLaunchKernelGGL((cg_begin_kernel<float>), dim3(s.t), dim3(256), 0, st, s);
+  return check_launch("cg_init");
+}
+
+int gpamd_cg_begin_f32(gpamd_cg_t* h, void* stream) {
+  if (!h) return fail(GPAMD_EINVAL, "cg_begin: null handle");
+  CgState<float>& s = h->st;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((coldot_kernel<float>), dim3(s.nb, s.t), dim3(256), 0, st, s.R, s.Z, s.ld, s.n, s.part_rz,
+                     (const int*)nullptr);
+  hipLaunchKernelGGL((cg_begin_kernel<float>), dim3(s.t), dim3(256), 0, st, s);
+  return check_launch("cg_begin");
+}
+
+int gpamd_cg_reduce_q_f32(gpamd_cg_t* h, const float* P, int S, int64_t ldp, const float* scale, const float* dscale,
+                          void* stream) {
+  if (!h || S <= 0 || ldp % 4) return fail(GPAMD_EINVAL, "cg_reduce_q: bad arguments");
+  CgState<float>& s = h->st;
+  hipLaunchKernelGGL((kv_reduce_kernel<float, true>), dim3(s.nb, s.t), dim3(256), 0, (hipStream_t)stream, P, S,
+                     (int64_t)s.t * ldp, ldp, scale, dscale, s.D, s.ld, s.Q, s.ld, s.n, s.part_a, s.done);
+  return check_launch("cg_reduce_q");
+}
+
+int gpamd_cg_update_xr_f32(gpamd_cg_t* h, int k, void* stream) {
+  if (!h) return fail(GPAMD_EINVAL, "cg_update_xr: null handle");
+  CgState<float>& s = h->st;
+  hipLaunchKernelGGL((cg_update_xr_kernel<float>), dim3(s.nb, s.t), dim3(256), 0, (hipStream_t)stream, s, k,
+                     s.Z == s.R ? 1 : 0);
+  return check_launch("cg_update_xr");
+}
+
+int gpamd_cg_update_d_f32(gpamd_cg_t* h, int k, void* stream) {
+  if (!h) return fail(GPAMD_EINVAL, "cg_update_d: null handle");
+  CgState<float>& s = h->st;
+  hipStream_t st = (hipStream_t)stream;
+  if (s.Z != s.R)
+    hipLaunchKernelGGL((coldot_kernel<float>), dim3(s.nb, s.t), dim3(256), 0, st, s.R, s.Z, s.ld, s.n, s.part_rz,
+                       (const int*)s.done);
+  hipLaunchKernelGGL((cg_update_d_kernel<float>), dim3(s.nb, s.t), dim3(256), 0, st, s, k);
+  hipLaunchKernelGGL((cg_stats_kernel<float>), dim3(1), dim3(256), 0, st, s);
+  return check_launch("cg_update_d");
+}
+
+int gpamd_cg_stop_f32(gpamd_cg_t* h, int k, int min_iter, int tridiag_floor, float tol, void* stream) {
+  if (!h) return fail(GPAMD_EINVAL, "cg_stop: null handle");
+  hipLaunchKernelGGL((cg_stop_kernel<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, h->st, k, min_iter,
+                     tridiag_floor, tol);
+  return check_launch("cg_stop");
+}
+
+int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream) {
+  if (!h) return fail(GPAMD_EINVAL, "cg_finish: null handle");
+  CgState<float>& s = h->st;
+  hipLaunchKernelGGL((cg_finish_kernel<float>), dim3(s.nb, s.t), dim3(256), 0, (hipStream_t)stream, s);
+  return check_launch("cg_finish");
+}
+
+// ----------------------------------------------------------------------------- pivoted Cholesky
+int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
+                               float* L, int64_t ldl, int64_t* pivots, float* fwork, int* iwork, void* stream) {
+  if (n <= 0 || rank <= 0 || ldl < n) return fail(GPAMD_EINVAL, "pivoted_cholesky: bad shape");
+  if (rank > 128) return fail(GPAMD_EUNSUPPORTED, "pivoted_cholesky: rank > 128");
+  if (rank > n) rank = n;
+  hipStream_t st = (hipStream_t)stream;
+  PcState s;
+  s.dwork = fwork;
+  s.scal = fwork + n;
+  s.L = L; s.ldl = ldl; s.n = n; s.rank = rank;
+  s.pivots = pivots;
+  s.ctl = iwork;
+  s.tol = tol;
+  hipMemsetAsync(iwork, 0, 2 * sizeof(int), st);
+  // diagonal of the noise-free kernel matrix: scale * k(0)
+  KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_diag_kernel<KK>), dim3((n + 255) / 256), dim3(256), 0, st, Xp, Xp, n, dp,
+                                       scale, s.dwork));
+  for (int m = 0; m < rank; ++m) {
+    hipLaunchKernelGGL(pc_pivot_kernel, dim3(1), dim3(1024), 0, st, s, m);
+    KIND_SWITCH(kind, hipLaunchKernelGGL((pc_update_kernel<KK>), dim3((n + 255) / 256), dim3(256), 0, st, s, m, Xp, dp,
+                                         scale));
+  }
+  return check_launch("pivoted_cholesky");
+}
+
+}  // extern "C"

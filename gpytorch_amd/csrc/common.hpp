@@ -1,0 +1,91 @@
+// Shared device helpers for the gfx950 BBMM kernels (wave = 64 lanes, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpamd {
+
+// Covariance families.  The point clouds handed to every kernel are PRE-SCALED by prep_points():
+//   RBF     : z = x * sqrt(0.5*log2(e)) / l        ->  k = exp2(-|zi-zj|^2)        (= exp(-0.5 |xi-xj|^2 / l^2))
+//   Matern  : z = (x - shift) * sqrt(2 nu) / l     ->  r = |zi-zj|,  k = poly_nu(r) * exp(-r)
+// which are the formulas of gpytorch/functions/rbf_covariance.py:14-19 and
+// gpytorch/functions/matern_covariance.py:18-50 with the pairwise distance taken directly
+// (gpytorch/kernels/keops/rbf_kernel.py:12-15, keops/matern_kernel.py:13-30) instead of through the
+// Gram trick of kernels/kernel.py:26-49.
+enum Kind : int { KIND_RBF = 0, KIND_MATERN12 = 1, KIND_MATERN32 = 2, KIND_MATERN52 = 3 };
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int KIND>
+__device__ __forceinline__ float cov_from_sq(float s) {
+  // s = squared distance between pre-scaled points
+  if constexpr (KIND == KIND_RBF) {
+    return __builtin_amdgcn_exp2f(-s);
+  } else {
+    float r = __builtin_amdgcn_sqrtf(s);
+    float e = __builtin_amdgcn_exp2f(-r * LOG2E);
+    if constexpr (KIND == KIND_MATERN12) return e;
+    if constexpr (KIND == KIND_MATERN32) return (1.0f + r) * e;
+    return __builtin_fmaf(s, 1.0f / 3.0f, 1.0f + r) * e;
+  }
+}
+
+// d k / d s (derivative wrt the squared scaled distance), used by the gradient kernels:
+//   RBF: k = exp2(-s) = exp(-s ln2)      -> dk/ds = -ln2 * k
+//   Matern: with r = sqrt(s): dk/ds = k'(r) / (2 r)
+//     nu=1/2: k' = -e^{-r}            -> dk/ds = -e^{-r} / (2r)      (singular at r=0; guarded)
+//     nu=3/2: k' = -r e^{-r}          -> dk/ds = -e^{-r} / 2
+//     nu=5/2: k' = -(r + r^2)/3 e^{-r}-> dk/ds = -(1 + r) e^{-r} / 6
+template <int KIND>
+__device__ __forceinline__ float dcov_dsq(float s) {
+  if constexpr (KIND == KIND_RBF) {
+    return -0.6931471805599453f * __builtin_amdgcn_exp2f(-s);
+  } else {
+    float r = __builtin_amdgcn_sqrtf(s);
+    float e = __builtin_amdgcn_exp2f(-r * LOG2E);
+    if constexpr (KIND == KIND_MATERN12) return r > 1e-15f ? -0.5f * e / r : 0.0f;
+    if constexpr (KIND == KIND_MATERN32) return -0.5f * e;
+    return -(1.0f + r) * e * (1.0f / 6.0f);
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ double cov_from_sq_f64(double s) {
+  if constexpr (KIND == KIND_RBF) {
+    return exp2(-s);
+  } else {
+    double r = sqrt(s);
+    double e = exp(-r);
+    if constexpr (KIND == KIND_MATERN12) return e;
+    if constexpr (KIND == KIND_MATERN32) return (1.0 + r) * e;
+    return (1.0 + r + s * (1.0 / 3.0)) * e;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread.
+template <typename T>
+__device__ __forceinline__ T block_sum_256(T v, T* smem4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem4[w] = v;
+  __syncthreads();
+  return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}
+
+}  // namespace gpamd

@@ -1,0 +1,220 @@
+"""Modified batched conjugate gradients (mBCG) -- host driver of the device-resident solver.
+
+Mirrors ``linear_operator.utils.linear_cg`` (third-party; restated in ``oracle/linear_cg.py`` and
+SURVEY.md A.2): same normalisation of the right-hand sides, same per-column alpha/beta masks, same
+stopping rule (>= 10 iterations, mean relative residual < tolerance, and >= the Lanczos-quadrature
+floor when tridiagonals are requested), same tridiagonal-matrix formulas.  Reference call sites:
+``gpytorch/distributions/multivariate_normal.py:249`` and
+``gpytorch/models/exact_prediction_strategies.py:286,444``.
+
+Differences, all by design (DESIGN.md "mBCG"):
+  * state is probe-major ``[t, ld]`` and lives on the GPU; one iteration is 4-5 kernel launches
+    (fused K*V partials, reduce+dot, x/r update, d update, stop test) instead of ~15 torch ops;
+  * the host does not synchronise per iteration: it enqueues ahead and polls one ``done`` word;
+    launches issued after convergence are device-side no-ops, so results are identical to a
+    per-iteration check;
+  * with probe columns sharded over ranks, the only communication is an RCCL all-reduce of two
+    floats (sum of residual norms, column count) per iteration for the global stopping rule.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+from dataclasses import dataclass
+
+import torch
+
+from . import backend as B
+from . import settings
+from ._lib import check, lib
+
+
+# When set to a list, every fused K*V launch of the CG loop is bracketed by HIP events on the launch
+# stream and (start, end, n, t) is appended -- bench.py uses it to time the dominant kernel live.
+KV_EVENT_LOG: list | None = None
+
+
+class NumericalWarning(RuntimeWarning):
+    """Same role as ``gpytorch.utils.warnings.NumericalWarning``."""
+
+
+@dataclass
+class CGInfo:
+    iterations: int
+    tolerance_reached: bool
+    residual_norms: torch.Tensor  # [t] relative residual norms (device)
+    t_mats: torch.Tensor | None   # [n_tridiag, m, m] (CPU float64) or None
+
+
+def build_tridiag(alpha: torch.Tensor, beta: torch.Tensor, iters: int, broke: bool, n_tri_iter: int) -> torch.Tensor:
+    """T matrices from the CG coefficient history (linear_cg's tridiagonal update).
+
+    alpha, beta: [hist, n_tridiag] (CPU).  Rows exist for k < min(n_tri_iter, iters - broke)."""
+    nt = alpha.shape[1]
+    rows = min(n_tri_iter, iters - (1 if broke else 0), alpha.shape[0])
+    T = torch.zeros(nt, max(rows, 1), max(rows, 1), dtype=torch.float64)
+    update = True
+    last = 0
+    ainv_prev = b_prev = None
+    for k in range(rows):
+        if not update:
+            break
+        a = alpha[k].to(torch.float64)
+        b = beta[k].to(torch.float64)
+        ainv = 1.0 / torch.where(a == 0, torch.ones_like(a), a)
+        if k == 0:
+            T[:, 0, 0] = ainv
+        else:
+            T[:, k, k] = ainv + b_prev * ainv_prev
+            off = b_prev.sqrt() * ainv_prev
+            T[:, k, k - 1] = off
+            T[:, k - 1, k] = off
+            if float(off.max()) < 1e-6:
+                update = False
+        last = k
+        ainv_prev, b_prev = ainv, b
+    return T[:, : last + 1, : last + 1].contiguous()
+
+
+class Preconditioner:
+    """P = L L^T + s2 I applied through the thin QR of [L; sqrt(s2) I].
+
+    ``q1t``: [k, ld] (rows = columns of Q1), ``sigma2``: 1-element device tensor."""
+
+    def __init__(self, q1t: torch.Tensor, sigma2: torch.Tensor, logdet: torch.Tensor, lt: torch.Tensor):
+        self.q1t, self.sigma2, self.logdet, self.lt = q1t, sigma2, logdet, lt
+
+    def apply_(self, rt: torch.Tensor, out: torch.Tensor):
+        # out = (R - (R Q1) Q1^T) / s2   in probe-major form: rows are vectors
+        w = rt @ self.q1t.t()
+        torch.addmm(rt, w, self.q1t, alpha=-1.0, out=out)
+        out.div_(self.sigma2)
+        return out
+
+
+def linear_cg(
+    x: B.PreparedPoints,
+    scale: torch.Tensor | None,
+    dscale: torch.Tensor | None,
+    rhs_t: torch.Tensor,
+    n_tridiag: int = 0,
+    tolerance: float | None = None,
+    eps: float = 1e-10,
+    stop_updating_after: float = 1e-10,
+    max_iter: int | None = None,
+    max_tridiag_iter: int | None = None,
+    preconditioner: Preconditioner | None = None,
+    group=None,
+    kv_partials=None,
+):
+    """Solve (scale*K(x,x) + dscale*I) X = rhs for all rows of ``rhs_t`` ([t, ld], probe-major).
+
+    ``kv_partials(vt, P, ldp, S, jc, done_ptr, stream)``: optional override of the fused K*V launch
+    (used by the multitask Kronecker operator); defaults to the plain kernel MVM on ``x``.
+    Returns (solves_t [t, ld], CGInfo)."""
+    B._require_gpu(rhs_t, "rhs")
+    L = lib()
+    n = x.n
+    t, ld = rhs_t.shape
+    dev = rhs_t.device
+    if tolerance is None:
+        tolerance = settings.cg_tolerance.value()
+    if max_iter is None:
+        max_iter = settings.max_cg_iterations.value()
+    if max_tridiag_iter is None:
+        max_tridiag_iter = settings.max_lanczos_quadrature_iterations.value()
+    n_tri_iter = min(max_tridiag_iter, n)
+    hist = min(n_tri_iter, max_iter) if n_tridiag else 0
+
+    st = B._stream(dev)
+    Xt = torch.zeros(t, ld, device=dev, dtype=torch.float32)
+    Rt = torch.zeros_like(Xt)
+    Dt = torch.zeros_like(Xt)
+    Qt = torch.zeros_like(Xt)
+    Zt = torch.zeros_like(Xt) if preconditioner is not None else Rt
+    fs = torch.zeros(int(L.gpamd_cg_fscratch_elems(t, hist)), device=dev, dtype=torch.float32)
+    isc = torch.zeros(int(L.gpamd_cg_iscratch_elems(t)), device=dev, dtype=torch.int32)
+    offs = (C.c_int64 * 5)()
+    check(L.gpamd_cg_layout(t, hist, offs), "cg_layout")
+    h = L.gpamd_cg_create_f32(
+        n, t, ld, B._ptr(Xt), B._ptr(Rt), B._ptr(Dt), B._ptr(Qt), B._ptr(Zt), B._ptr(fs), B._ptr(isc), hist,
+        float(eps), float(stop_updating_after),
+    )
+    if not h:
+        check(-1, "cg_create")
+    done_t = isc[2 * t : 2 * t + 2]
+    done_ptr = C.c_void_p(L.gpamd_cg_done_ptr(h))
+    stats = fs[offs[4] : offs[4] + 2]
+    try:
+        check(L.gpamd_cg_init_f32(h, B._ptr(rhs_t), rhs_t.stride(0), 1 if preconditioner is not None else 0, st), "cg_init")
+        if preconditioner is not None:
+            preconditioner.apply_(Rt, Zt)
+            Dt.copy_(Zt)
+            check(L.gpamd_cg_begin_f32(h, st), "cg_begin")
+
+        S, jc, wsn = B.kv_plan(n, n, t, ld)
+        P = B.workspace(dev, wsn)
+        kind_id = B.KIND_IDS[x.kind]
+        min_iter = min(10, max_iter - 1)
+        tri_floor = min(n_tri_iter, max_iter - 1) if n_tridiag else 0
+        first_poll = max(min_iter, tri_floor)
+        poll_every = 1 if float(n) * n * t > 2e11 else 8
+        flag = 0
+        iters = 0
+        for k in range(max_iter):
+            ev = None
+            if KV_EVENT_LOG is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(torch.cuda.current_stream(dev))
+            if kv_partials is None:
+                check(
+                    L.gpamd_kv_partials_f32(
+                        kind_id, B._ptr(x.xp), n, B._ptr(x.xp), n, x.dp, B._ptr(Dt), ld, t, B._ptr(P), ld, S, jc,
+                        done_ptr, st,
+                    ),
+                    "kv_partials",
+                )
+            else:
+                kv_partials(Dt, P, ld, S, jc, done_ptr, st)
+            if ev is not None:
+                ev[1].record(torch.cuda.current_stream(dev))
+                KV_EVENT_LOG.append((ev[0], ev[1], n, t, k))
+            check(L.gpamd_cg_reduce_q_f32(h, B._ptr(P), S, ld, B._ptr(scale), B._ptr(dscale), st), "cg_reduce_q")
+            check(L.gpamd_cg_update_xr_f32(h, k, st), "cg_update_xr")
+            if preconditioner is not None:
+                preconditioner.apply_(Rt, Zt)
+            check(L.gpamd_cg_update_d_f32(h, k, st), "cg_update_d")
+            if group is not None:
+                torch.distributed.all_reduce(stats, group=group)
+            check(L.gpamd_cg_stop_f32(h, k, min_iter, tri_floor, float(tolerance), st), "cg_stop")
+            iters = k + 1
+            if k >= first_poll and ((k - first_poll) % poll_every == 0 or k == max_iter - 1):
+                flag, iters_dev = (int(v) for v in done_t.tolist())
+                if flag:
+                    iters = iters_dev
+                    break
+        if not flag:
+            flag, iters_dev = (int(v) for v in done_t.tolist())
+            iters = iters_dev if flag else max_iter
+        if flag == 2:
+            raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
+        check(L.gpamd_cg_finish_f32(h, st), "cg_finish")
+        rnorm = fs[offs[1] : offs[1] + t].clone()
+        tolerance_reached = flag == 1
+        if not tolerance_reached and max_iter > 0:
+            warnings.warn(
+                f"CG terminated in {iters} iterations with average residual norm {float(rnorm.mean())} "
+                f"which is larger than the tolerance of {tolerance} specified by "
+                "gpytorch_amd.settings.cg_tolerance. If performance is affected, consider raising the "
+                "maximum number of CG iterations by running code in a "
+                "gpytorch_amd.settings.max_cg_iterations(value) context.",
+                NumericalWarning,
+            )
+        t_mats = None
+        if n_tridiag:
+            a_h = fs[offs[2] : offs[2] + hist * t].view(hist, t)[:, :n_tridiag].cpu()
+            b_h = fs[offs[3] : offs[3] + hist * t].view(hist, t)[:, :n_tridiag].cpu()
+            t_mats = build_tridiag(a_h, b_h, iters, tolerance_reached, n_tri_iter)
+    finally:
+        L.gpamd_cg_destroy(h)
+    return Xt, CGInfo(iters, tolerance_reached, rnorm, t_mats)

@@ -1,0 +1,124 @@
+/* gpamd.h -- C ABI of the MI355X-native BBMM hot path (libgpamd.so, gfx950 only).
+ *
+ * The reference (cornellius-gp/gpytorch + the third-party linear_operator package) has NO native
+ * boundary: its hot path is Python calling torch.  These entry points are what a ctypes / cffi /
+ * torch-extension binding for that path binds instead; each one cites the reference interface it
+ * replaces.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; no ownership transfer;
+ *   - `stream` is a hipStream_t (NULL = default stream); all calls are asynchronous on it;
+ *   - return value: 0 on success, a positive hipError_t, or a negative GPAMD_E* argument error;
+ *     gpamd_last_error() returns a thread-local message for the last non-zero return;
+ *   - vectors are "probe-major": a block of t right-hand sides is float[t][ld], ld >= n, ld % 4 == 0,
+ *     base 16-byte aligned (row c = probe c, contiguous over the n data points);
+ *   - point clouds are first converted by gpamd_prep_points_f32 into float[n][dp], dp = 4*ceil(d/4),
+ *     pre-scaled so that every kernel evaluates k = f(|zi - zj|^2) only.
+ */
+#ifndef GPAMD_H
+#define GPAMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPAMD_ABI_VERSION 1
+
+/* covariance families: gpytorch/kernels/rbf_kernel.py:68-85, matern_kernel.py:85-110 (nu = 1/2, 3/2, 5/2) */
+enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3 };
+
+enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
+
+int gpamd_abi_version(void);
+const char* gpamd_last_error(void);
+
+/* x / lengthscale (+ Matern mean-centring) -- gpytorch/kernels/rbf_kernel.py:78-79,
+ * gpytorch/kernels/keops/rbf_kernel.py:45-46, keops/matern_kernel.py:69-71.
+ * ls: nls = 1 (isotropic) or d (ARD) lengthscales; shift: d-vector or NULL. */
+int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, const float* ls, int nls,
+                          const float* shift, float* Xp, int dp, void* stream);
+
+/* Launch plan for one fused K*V: split count S and j-chunk so the grid is a whole number of chip fills.
+ * Outputs on the host. workspace_floats = S * t * ldo. */
+int gpamd_kv_plan(int n, int m, int t, int64_t ldo, int* S_host, int* jchunk_host, int64_t* workspace_floats_host);
+
+/* P[s] = k(X1p, X2p[chunk s]) * Vt[:, chunk s]  for s < S -- the matrix-free K @ V of
+ * KernelLinearOperator._matmul (gpytorch/kernels/keops/rbf_kernel.py:44-55) and
+ * LazyEvaluatedKernelTensor._matmul (gpytorch/lazy/lazy_evaluated_kernel_tensor.py:245-275).
+ * P: float[S][t][ldo].  done: optional device int; non-zero turns the launch into a no-op. */
+int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Vt,
+                          int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, const int* done,
+                          void* stream);
+
+/* Out = scale * sum_s P[s] + dscale * Vd  (scale/dscale device scalars, NULL = 1 / 0; Vd may be NULL):
+ * ScaleKernel.forward (gpytorch/kernels/scale_kernel.py:117-118) and the + sigma^2 I of
+ * _GaussianLikelihoodBase.marginal (gpytorch/likelihoods/gaussian_likelihood.py:117-121). */
+int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const float* scale, const float* dscale,
+                        const float* Vd, int64_t ldd, float* Out, int64_t ldo, const int* done, void* stream);
+
+/* One-call  Out = scale * K(X1p, X2p) Vt + dscale * Vd  using caller workspace (>= plan's workspace_floats). */
+int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Vt, int64_t ldv,
+                 int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
+                 int64_t ldo, float* workspace, int64_t workspace_floats, void* stream);
+
+/* Explicit entries (LinearOperator._getitem / _diagonal / to_dense on a kernel operator):
+ * rows: out[r][j] = scale*k(X1p[rows[r]], X2p[j]);  dense: out[i][j] (row-major, ldo);  diag: out[i]. */
+int gpamd_kernel_rows_f32(int kind, const float* X1p, const int64_t* rows, int nrows, const float* X2p, int m, int dp,
+                          const float* scale, float* out, int64_t ldo, void* stream);
+int gpamd_kernel_dense_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* scale,
+                           float* out, int64_t ldo, void* stream);
+int gpamd_kernel_diag_f32(int kind, const float* X1p, const float* X2p, int n, int dp, const float* scale, float* out,
+                          void* stream);
+
+/* out[c] = sum_i A[c][i] * B[c][i]  (per-column inner products; scratch: float[t*256]) */
+int gpamd_coldot_f32(const float* A, const float* B, int64_t ld, int n, int t, float* out, float* scratch,
+                     void* stream);
+
+/* ---- modified batched CG (linear_operator.utils.linear_cg; called from
+ * gpytorch/distributions/multivariate_normal.py:249 and gpytorch/models/exact_prediction_strategies.py:286,444).
+ * The handle only stores pointers into caller-owned device buffers. ---- */
+typedef struct gpamd_cg gpamd_cg_t;
+
+/* scratch sizes (in elements) for a t-column solve keeping hist_len iterations of (alpha, beta) */
+int64_t gpamd_cg_fscratch_elems(int t, int hist_len);
+int64_t gpamd_cg_iscratch_elems(int t);
+/* offsets (in elements) of the host-visible pieces inside fscratch: bnorm, rnorm, alpha_hist, beta_hist, stats */
+int gpamd_cg_layout(int t, int hist_len, int64_t* offsets5_host);
+
+/* X, R, D, Q: float[t][ld].  Z: float[t][ld] preconditioned residual, or == R without a preconditioner.
+ * iscratch holds [zero_rhs(t) | converged(t) | done(2)]; done = {flag, iterations}. */
+gpamd_cg_t* gpamd_cg_create_f32(int n, int t, int64_t ld, float* X, float* R, float* D, float* Q, float* Z,
+                                float* fscratch, int* iscratch, int hist_len, float eps, float stop_updating_after);
+void gpamd_cg_destroy(gpamd_cg_t* h);
+const int* gpamd_cg_done_ptr(const gpamd_cg_t* h);
+
+/* R = B/|B|, X = 0 (and D = R, rho = r.r when have_precond == 0) */
+int gpamd_cg_init_f32(gpamd_cg_t* h, const float* B, int64_t ldb, int have_precond, void* stream);
+/* with a preconditioner: after the caller wrote Z = P^-1 R and D = Z: rho = r.z */
+int gpamd_cg_begin_f32(gpamd_cg_t* h, void* stream);
+/* Q = scale * sum_s P[s] + dscale * D, and d.q partials */
+int gpamd_cg_reduce_q_f32(gpamd_cg_t* h, const float* P, int S, int64_t ldp, const float* scale, const float* dscale,
+                          void* stream);
+/* alpha; X += alpha D; R -= alpha Q */
+int gpamd_cg_update_xr_f32(gpamd_cg_t* h, int k, void* stream);
+/* (caller applies Z = P^-1 R here when preconditioned)  beta; D = Z + beta D; residual statistics -> stats */
+int gpamd_cg_update_d_f32(gpamd_cg_t* h, int k, void* stream);
+/* stopping rule on stats (all-reduce stats[0:2] across ranks first when probe columns are sharded) */
+int gpamd_cg_stop_f32(gpamd_cg_t* h, int k, int min_iter, int tridiag_floor, float tol, void* stream);
+/* X *= |B| */
+int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream);
+
+/* ---- pivoted Cholesky of the NOISE-FREE kernel matrix (LinearOperator.pivoted_cholesky; wrapper
+ * gpytorch/__init__.py:146-173; consumer AddedDiagLinearOperator._preconditioner). L: float[rank][ldl]
+ * (zero-filled by the caller), rank <= 128; fwork: float[n + 4]; iwork: int[2]; pivots: int64[rank].
+ * Runs `rank` (pivot, update) steps without host synchronisation; steps after the error tolerance is
+ * met are no-ops.  On completion iwork[0] = number of columns produced. ---- */
+int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
+                               float* L, int64_t ldl, int64_t* pivots, float* fwork, int* iwork, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPAMD_H */

@@ -1,0 +1,29 @@
+"""CPU oracle for the BBMM ExactGP hot path.  TEST INFRASTRUCTURE ONLY.
+
+This package is a plain-PyTorch (CPU, float64 by default) restatement of the
+reference algorithms on the hot path named by BASELINE.json:north_star.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it; the product package ``gpytorch_amd`` never does.
+
+Pinning status
+--------------
+* Kernel arithmetic (RBF / Matern / sq_dist / dist): PINNED.  ``tests/golden/
+  make_golden.py`` executes the reference's own ``functions/rbf_covariance.py``,
+  ``functions/matern_covariance.py`` and ``kernels/kernel.py::sq_dist/dist`` in
+  this container and stores their outputs in ``tests/golden/*.npz``;
+  ``tests/test_oracle_golden.py`` checks this oracle against those files and
+  against the hand-computed known answers of the reference's unit tests.
+* MVN log-prob / MLL assembly / predictive equations: PINNED to dense float64
+  Cholesky (the same deterministic ground truth every reference test compares
+  against) and to the known answer -4.8157 of
+  ``test/distributions/test_multivariate_normal.py:40-43``.
+* mBCG / Lanczos / pivoted Cholesky / preconditioner / SLQ (the arithmetic of
+  the third-party ``linear_operator>=0.6.1`` package, which is NOT vendored in
+  /root/reference and is not installable here): restated from the published
+  algorithm.  Iteration-level parity is UNPINNED -- the
+  reference holds no golden vectors for CG iterates, tridiagonal matrices or
+  pivoted-Cholesky factors; these routines are pinned only through their
+  results against dense Cholesky (solve, log-det given probes, predictive
+  mean/variance) within the tolerances the reference's own tests use.
+"""
+from . import kernels, linear_cg, pivoted_cholesky, lanczos, slq, exact_gp  # noqa: F401

@@ -1,0 +1,98 @@
+"""CPU: libgpamd.so loads and exports every symbol declared in include/gpamd.h; host-side logic
+(launch planning, tridiagonal assembly, settings) behaves -- no compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "gpamd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpamd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    from gpytorch_amd._lib import LIB_PATH, SIGNATURES, lib
+
+    assert os.path.exists(LIB_PATH), "run __graft_entry__.build() first"
+    h = lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(h, name), f"{name} declared in gpamd.h but not exported"
+    assert sorted(SIGNATURES) == declared, "ctypes table and gpamd.h disagree"
+    assert h.gpamd_abi_version() == 1
+
+
+def test_kv_plan_covers_and_fills():
+    from gpytorch_amd import backend as B
+
+    for n, m, t in [(2000, 2000, 11), (100_000, 100_000, 65), (500_000, 500_000, 65), (1_000_000, 1_000_000, 33),
+                    (10_000, 100_000, 1), (257, 300, 140)]:
+        S, jc, ws = B.kv_plan(n, m, t, B.round_up(n, 4))
+        assert S >= 1 and jc % 128 == 0 and S * jc >= m and (S - 1) * jc < m
+        assert ws == S * t * B.round_up(n, 4)
+
+
+def test_argument_validation_without_gpu():
+    from gpytorch_amd._lib import lib
+
+    h = lib()
+    assert h.gpamd_kv_plan(0, 10, 1, 12, None, None, None) == -1
+    assert b"bad shape" in h.gpamd_last_error()
+    # padded input dims other than 4/8/12/16 are refused before any launch
+    rc = h.gpamd_kv_partials_f32(0, None, 10, None, 10, 20, None, 12, 1, None, 12, 1, 128, None, None)
+    assert rc == -2
+
+
+def test_build_tridiag_matches_oracle():
+    from gpytorch_amd.linear_cg import build_tridiag
+    from oracle import exact_gp as OG
+    from oracle import linear_cg as OCG
+    from tests.util import make_data
+
+    n = 200
+    X, y = make_data(n, 3)
+    mm = OG.make_matmul("rbf", X, 0.25, 1.0, 0.1)
+    rhs = torch.randn(n, 6, dtype=torch.float64)
+    for tol, max_iter in [(1.0, 1000), (1e-9, 15), (1e-3, 1000)]:
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, T, info = OCG.linear_cg(mm, rhs, n_tridiag=4, tolerance=tol, max_iter=max_iter, return_info=True)
+        a = torch.stack(info["alpha"])[:, :4]
+        b = torch.stack(info["beta"])[:, :4]
+        T2 = build_tridiag(a[:20], b[:20], info["iters"], info["tolerance_reached"], 20)
+        assert T2.shape == T.shape
+        assert torch.allclose(T2, T, rtol=1e-12, atol=1e-12)
+
+
+def test_settings_contexts():
+    from gpytorch_amd import settings
+
+    assert settings.cg_tolerance.value() == 1.0 and settings.eval_cg_tolerance.value() == 0.01
+    with settings.cg_tolerance(1e-4), settings.max_cholesky_size(0), settings.fast_pred_var():
+        assert settings.cg_tolerance.value() == 1e-4
+        assert settings.max_cholesky_size.value() == 0
+        assert settings.fast_pred_var.on()
+    assert settings.cg_tolerance.value() == 1.0 and settings.max_cholesky_size.value() == 800
+    assert settings.fast_pred_var.off()
+    with settings.fast_computations(log_prob=False):
+        assert settings.fast_computations.log_prob.off() and settings.fast_computations.solves.on()
+    assert settings.fast_computations.log_prob.on()
+    assert settings.min_variance.value(torch.float32) == 1e-6
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "gpytorch_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"

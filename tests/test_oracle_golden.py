@@ -1,0 +1,92 @@
+"""CPU: pin the oracle's covariance arithmetic against (a) outputs of the reference's own code
+(tests/golden/kernel_values.npz, produced by tests/golden/make_golden.py executing
+gpytorch/functions/{rbf,matern}_covariance.py and kernels/kernel.py::sq_dist/dist) and (b) the
+hand-computed known answers in the reference's unit tests."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import exact_gp as OG
+from oracle import kernels as OK
+
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "kernel_values.npz"))
+CASES = "abcde"
+
+
+def _t(name):
+    return torch.from_numpy(Z[name])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_sq_dist_and_dist_bitwise(case):
+    x1, x2, same = _t(f"{case}_x1"), _t(f"{case}_x2"), bool(Z[f"{case}_same"])
+    assert torch.equal(OK.sq_dist(x1, x2, same), _t(f"{case}_sq_dist"))
+    assert torch.equal(OK.dist(x1, x2, same), _t(f"{case}_dist"))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rbf_and_matern_values_bitwise(case):
+    x1, x2, ls = _t(f"{case}_x1"), _t(f"{case}_x2"), float(Z[f"{case}_ls"])
+    lsz = torch.tensor([[ls]], dtype=x1.dtype)
+    assert torch.equal(OK.rbf(x1, x2, lsz), _t(f"{case}_rbf"))
+    for nu, key in [(0.5, "matern05"), (1.5, "matern15"), (2.5, "matern25")]:
+        got = OK.matern(x1, x2, lsz, nu)
+        ref = _t(f"{case}_{key}")
+        # identical formula; the reference fuses in-place ops in a different order for nu=2.5
+        assert torch.allclose(got, ref, rtol=1e-6 if x1.dtype == torch.float32 else 1e-13, atol=0)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_lengthscale_gradients(case):
+    """dK/dl restatement vs the reference autograd Functions' backward (rbf_covariance.py:26-29,
+    matern_covariance.py:53-56) contracted with a fixed W."""
+    x1, x2, ls, W = _t(f"{case}_x1"), _t(f"{case}_x2"), float(Z[f"{case}_ls"]), _t(f"{case}_W")
+    lsz = torch.tensor([[ls]], dtype=x1.dtype)
+    rt = 2e-4 if x1.dtype == torch.float32 else 1e-10
+    g = (OK.rbf_dl(x1, x2, lsz) * W).sum()
+    assert torch.allclose(g, _t(f"{case}_rbf_dls").sum(), rtol=rt)
+    for nu, key in [(0.5, "matern05"), (1.5, "matern15"), (2.5, "matern25")]:
+        g = (OK.matern_dl(x1, x2, lsz, nu) * W).sum()
+        assert torch.allclose(g, _t(f"{case}_{key}_dls").sum(), rtol=rt)
+
+
+@pytest.mark.parametrize("case", "abc")
+def test_direct_form_equals_gram_form(case):
+    """The pairwise-difference form the HIP kernels use (keops/*_kernel.py) equals the Gram-trick
+    form (kernels/kernel.py:26-49) to float64 rounding."""
+    x1, x2, ls = _t(f"{case}_x1"), _t(f"{case}_x2"), float(Z[f"{case}_ls"])
+    assert torch.allclose(OK.rbf(x1, x2, ls, direct=True), _t(f"{case}_rbf"), atol=1e-12)
+    assert torch.allclose(OK.matern(x1, x2, ls, 2.5, direct=True), _t(f"{case}_matern25"), atol=1e-7)
+
+
+def test_reference_known_answers():
+    # test/kernels/test_rbf_kernel.py:126-142
+    a = torch.tensor([4.0, 2, 8]).view(3, 1)
+    b = torch.tensor([0.0, 2, 4]).view(3, 1)
+    actual = torch.tensor([[16.0, 4, 0], [4, 0, 4], [64, 36, 16]]).mul_(-0.5).div_(4).exp_()
+    assert torch.norm(OK.rbf(a, b, 2.0) - actual) < 1e-5
+    # test/kernels/test_rbf_kernel.py:21-38 (ARD)
+    a2 = torch.tensor([[1.0, 2], [2, 4]])
+    b2 = torch.tensor([[1.0, 3], [0, 4]])
+    lsv = torch.tensor([[1.0, 2]])
+    act = ((a2 / lsv).unsqueeze(-2) - (b2 / lsv).unsqueeze(-3)).pow(2).sum(-1).mul_(-0.5).exp()
+    assert torch.norm(OK.rbf(a2, b2, lsv) - act) < 1e-5
+    # test/kernels/test_matern_kernel.py:41-77
+    bb = torch.tensor([0.0, 2]).view(2, 1)
+    dd = torch.tensor([[4.0, 2], [2, 0], [8, 6]])
+    assert torch.norm(OK.matern(a, bb, 2.0, 0.5) - dd.div(-2).exp()) < 1e-3
+    d3 = dd * math.sqrt(3) / 2
+    assert torch.norm(OK.matern(a, bb, 2.0, 1.5) - (d3 + 1) * torch.exp(-d3)) < 1e-3
+    d5 = dd * math.sqrt(5) / 2
+    assert torch.norm(OK.matern(a, bb, 2.0, 2.5) - (d5**2 / 3 + d5 + 1) * torch.exp(-d5)) < 1e-3
+
+
+def test_mvn_log_prob_known_answer():
+    # test/distributions/test_multivariate_normal.py:28,40-43: mean [0,1,2], covariance diag [1, 0.75, 1.5]
+    mean = torch.tensor([0.0, 1, 2], dtype=torch.float64)
+    cov = torch.diag(torch.tensor([1.0, 0.75, 1.5], dtype=torch.float64))
+    lp = OG.dense_log_prob(cov, torch.zeros(3, dtype=torch.float64) - mean)
+    assert abs(float(lp) - (-4.8157)) < 1e-4
