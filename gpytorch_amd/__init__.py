@@ -2,11 +2,68 @@
 
 Drop-in (same names / argument meaning) for the hot path of cornellius-gp/gpytorch:
 kernel-matrix MVM, modified batched CG, Lanczos / SLQ, pivoted-Cholesky preconditioner, behind
-``kernels`` / ``LinearOperator``-protocol operators / ``ExactMarginalLogLikelihood``.
+``kernels`` / ``LinearOperator``-protocol operators / ``ExactMarginalLogLikelihood``::
+
+    import gpytorch_amd as gpytorch
+    class GP(gpytorch.models.ExactGP):
+        def __init__(self, x, y, lik):
+            super().__init__(x, y, lik)
+            self.mean_module = gpytorch.means.ConstantMean()
+            self.covar_module = gpytorch.kernels.ScaleKernel(gpytorch.kernels.RBFKernel())
+        def forward(self, x):
+            return gpytorch.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
 The compute path is hand-written HIP for gfx950 (``csrc/``, C ABI in ``include/gpamd.h``);
-there is no CPU fallback.
+there is no CPU fallback.  The functional aliases below mirror ``gpytorch/__init__.py:34-278``.
 """
-from . import settings  # noqa: F401
+from . import distributions, kernels, likelihoods, means, mlls, models, operators, settings  # noqa: F401
 from ._lib import LIB_PATH, GpamdError  # noqa: F401
+from .mlls import ExactMarginalLogLikelihood  # noqa: F401
+from .module import Module  # noqa: F401
+from .operators import to_dense, to_linear_operator
 
 __version__ = "0.1.0"
+
+
+def add_diagonal(input, diag):
+    return to_linear_operator(input).add_diagonal(diag)
+
+
+def add_jitter(input, jitter_val=1e-3):
+    return to_linear_operator(input).add_jitter(jitter_val)
+
+
+def inv_quad(input, inv_quad_rhs, reduce_inv_quad=True):
+    return to_linear_operator(input).inv_quad(inv_quad_rhs, reduce_inv_quad=reduce_inv_quad)
+
+
+def inv_quad_logdet(input, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+    return to_linear_operator(input).inv_quad_logdet(inv_quad_rhs, logdet, reduce_inv_quad=reduce_inv_quad)
+
+
+def logdet(input):
+    return to_linear_operator(input).logdet()
+
+
+def pivoted_cholesky(input, rank, error_tol=None, return_pivots=False):
+    """gpytorch/__init__.py:146-173 (note: the reference wrapper drops error_tol at :173; honoured here)."""
+    return to_linear_operator(input).pivoted_cholesky(rank=rank, error_tol=error_tol, return_pivots=return_pivots)
+
+
+def root_decomposition(input):
+    return to_linear_operator(input).root_decomposition()
+
+
+def root_inv_decomposition(input, initial_vectors=None, test_vectors=None):
+    return to_linear_operator(input).root_inv_decomposition(initial_vectors, test_vectors)
+
+
+def solve(input, rhs, lhs=None):
+    return to_linear_operator(input).solve(rhs, lhs)
+
+
+__all__ = [
+    "ExactMarginalLogLikelihood", "Module", "add_diagonal", "add_jitter", "distributions", "inv_quad", "inv_quad_logdet",
+    "kernels", "likelihoods", "logdet", "means", "mlls", "models", "operators", "pivoted_cholesky", "root_decomposition",
+    "root_inv_decomposition", "settings", "solve", "to_dense",
+]

@@ -189,7 +189,7 @@ def pivoted_cholesky(xp: PreparedPoints, scale, rank: int, tol: float):
     L = torch.zeros(rank, ldl, device=dev, dtype=torch.float32)
     piv = torch.zeros(rank, device=dev, dtype=torch.int64)
     fwork = torch.empty(n + 4, device=dev, dtype=torch.float32)
-    iwork = torch.zeros(2, device=dev, dtype=torch.int32)
+    iwork = torch.zeros(2 + 2 * n, device=dev, dtype=torch.int32)
     check(
         lib().gpamd_pivoted_cholesky_f32(
             KIND_IDS[xp.kind], _ptr(xp.xp), n, xp.dp, _ptr(scale), rank, float(tol), _ptr(L), ldl, _ptr(piv), _ptr(fwork),
@@ -201,4 +201,27 @@ def pivoted_cholesky(xp: PreparedPoints, scale, rank: int, tol: float):
     return L[:m, :n], piv[:m], m
 
 
+def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor) -> torch.Tensor:
+    """Fused bilinear derivative with W = lt^T rt (lt: [t, ld_n] over x1, rt: [t, ld_m] over x2).
+
+    Returns float32 [1 + dp]:  g[0] = sum_ij W_ij k_ij;  g[1+q] = sum_ij W_ij dk/ds_ij (z_iq - z_jq)^2
+    where z are the PREPARED coordinates and s the squared prepared distance."""
+    _require_gpu(lt, "left")
+    assert x1.kind == x2.kind and x1.dp == x2.dp and lt.shape[0] == rt.shape[0]
+    t = lt.shape[0]
+    dev = lt.device
+    nd = int(lib().gpamd_kv_grad_workspace_doubles(x1.n, x2.n, t, x1.dp))
+    ws = torch.empty(nd, device=dev, dtype=torch.float64)
+    out = torch.empty(1 + x1.dp, device=dev, dtype=torch.float32)
+    check(
+        lib().gpamd_kv_grad_f32(
+            KIND_IDS[x1.kind], _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.dp, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0),
+            t, _ptr(out), _ptr(ws), nd, _stream(dev),
+        ),
+        "kv_grad",
+    )
+    return out
+
+
+# d s / d l factors: s = sum_q z_q^2-differences with z = coef * x / l  =>  ds_q/dl_q = -2 s_q / l_q
 RBF_PREP_COEF = math.sqrt(0.5 * 1.4426950408889634)

@@ -341,7 +341,7 @@ int gpamd_cg_init_f32(gpamd_cg_t* h, const float* B, int64_t ldb, int have_preco
   CgState<float>& s = h->st;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(s.nb, s.t);
-  hipMemsetAsync(s.done, 0, 2 * sizeof(int), st);
+  (void)hipMemsetAsync(s.done, 0, 2 * sizeof(int), st);
   hipLaunchKernelGGL((coldot_kernel<float>), grid, dim3(256), 0, st, B, B, ldb, s.n, s.part_a, (const int*)nullptr);
   hipLaunchKernelGGL((cg_init_kernel<float>), grid, dim3(256), 0, st, s, B, ldb, have_precond ? 0 : 1);
   if (!have_precond) hipLaunchKernelGGL((cg_begin_kernel<float>), dim3(s.t), dim3(256), 0, st, s);
@@ -414,8 +414,11 @@ int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const f
   s.L = L; s.ldl = ldl; s.n = n; s.rank = rank;
   s.pivots = pivots;
   s.ctl = iwork;
+  s.perm = iwork + 2;
+  s.pos = iwork + 2 + n;
   s.tol = tol;
-  hipMemsetAsync(iwork, 0, 2 * sizeof(int), st);
+  (void)hipMemsetAsync(iwork, 0, 2 * sizeof(int), st);
+  hipLaunchKernelGGL(pc_init_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.perm, s.pos, n);
   // diagonal of the noise-free kernel matrix: scale * k(0)
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_diag_kernel<KK>), dim3((n + 255) / 256), dim3(256), 0, st, Xp, Xp, n, dp,
                                        scale, s.dwork));

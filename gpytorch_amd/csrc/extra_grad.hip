@@ -1,0 +1,118 @@
+// extern "C" entry points for the fused bilinear-derivative (hyper-parameter gradient) kernel.
+#include "../../include/gpamd.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "kv_grad.hpp"
+
+using namespace gpamd;
+
+namespace {
+thread_local char g_err2[256] = "";
+constexpr int GRAD_TGROUP = 128;  // probe columns per launch
+
+int grad_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+void grad_plan(int n, int m, int* S, int* jchunk, int* nrb) {
+  *nrb = (n + 127) / 128;
+  const int slots = grad_num_cus() * 2;
+  int smax = m / 256;
+  if (smax < 1) smax = 1;
+  if (smax > 64) smax = 64;
+  int best = 1;
+  double best_eff = -1;
+  for (int s = 1; s <= smax; ++s) {
+    int jc = ((m + s - 1) / s + 63) / 64 * 64;
+    int se = (m + jc - 1) / jc;
+    long units = (long)(*nrb) * se;
+    long rounds = (units + slots - 1) / slots;
+    double eff = (double)units / (double)(rounds * slots);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+    if (eff >= 0.92) { best = s; break; }
+  }
+  int jc = ((m + best - 1) / best + 63) / 64 * 64;
+  *jchunk = jc;
+  *S = (m + jc - 1) / jc;
+}
+
+template <int KIND>
+int launch_grad(int dp, const GradArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+#define L(DPV)                                                                                                  \
+  case DPV: {                                                                                                   \
+    auto kfn = kv_grad_kernel<KIND, DPV>;                                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);                                                 \
+    return 0;                                                                                                   \
+  }
+  switch (dp) { L(4) L(8) L(12) L(16) }
+#undef L
+  return -2;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t gpamd_kv_grad_workspace_doubles(int n, int m, int t, int dp) {
+  int S, jc, nrb;
+  if (n <= 0 || m <= 0 || t <= 0) return 0;
+  grad_plan(n, m, &S, &jc, &nrb);
+  int groups = (t + GRAD_TGROUP - 1) / GRAD_TGROUP;
+  return (int64_t)groups * nrb * S * (1 + dp);
+}
+
+int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Lt, int64_t ldl,
+                      const float* Rt, int64_t ldr, int t, float* out, double* workspace, int64_t workspace_doubles,
+                      void* stream) {
+  if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m) {
+    snprintf(g_err2, sizeof(g_err2), "kv_grad: bad arguments");
+    return GPAMD_EINVAL;
+  }
+  if (dp != 4 && dp != 8 && dp != 12 && dp != 16) return GPAMD_EUNSUPPORTED;
+  int S, jc, nrb;
+  grad_plan(n, m, &S, &jc, &nrb);
+  const int groups = (t + GRAD_TGROUP - 1) / GRAD_TGROUP;
+  const int64_t units = (int64_t)nrb * S;
+  if (workspace_doubles < groups * units * (1 + dp)) return GPAMD_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  for (int g = 0; g < groups; ++g) {
+    const int c0 = g * GRAD_TGROUP;
+    const int tg = (t - c0) < GRAD_TGROUP ? (t - c0) : GRAD_TGROUP;
+    GradArgs a;
+    a.X1 = X1p; a.X2 = X2p;
+    a.Lt = Lt + (int64_t)c0 * ldl;
+    a.Rt = Rt + (int64_t)c0 * ldr;
+    a.ldl = ldl; a.ldr = ldr;
+    a.n = n; a.m = m; a.t = tg;
+    a.S = S; a.jchunk = jc; a.nrb = nrb;
+    a.part = workspace + (int64_t)g * units * (1 + dp);
+    const int th = (tg + 1) / 2;
+    const size_t lds = ((size_t)4 * 2 * th * 32 + (size_t)4 * 64 * dp) * sizeof(float);
+    int rc = -2;
+    switch (kind) {
+      case GPAMD_RBF: rc = launch_grad<KIND_RBF>(dp, a, (unsigned)units, lds, st); break;
+      case GPAMD_MATERN12: rc = launch_grad<KIND_MATERN12>(dp, a, (unsigned)units, lds, st); break;
+      case GPAMD_MATERN32: rc = launch_grad<KIND_MATERN32>(dp, a, (unsigned)units, lds, st); break;
+      case GPAMD_MATERN52: rc = launch_grad<KIND_MATERN52>(dp, a, (unsigned)units, lds, st); break;
+    }
+    if (rc) return GPAMD_EUNSUPPORTED;
+  }
+  hipLaunchKernelGGL(grad_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, (int)(groups * units), 1 + dp, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err2, sizeof(g_err2), "kv_grad: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -68,10 +68,12 @@ __global__ void kernel_diag_kernel(const float* __restrict__ X1p, const float* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pivoted Cholesky (wrapper gpytorch/__init__.py:146-173).  Formulated without a
-// physical permutation: `diag[i] < 0` never happens for live entries, pivoted entries are parked
-// at -inf in `dwork` so the arg-max skips them, and L (rank x n, row-major) is written in the
-// original index order exactly like the reference's scatter by pi.
+// Pivoted Cholesky (wrapper gpytorch/__init__.py:146-173).  Data stay in the original
+// index order (L is rank x n row-major, written exactly like the reference's scatter by pi);
+// pivoted entries are parked at -inf in `dwork` so the arg-max skips them.  The reference's arg-max
+// runs over the PERMUTED order pi[m:], so exact ties (very common in fp32: every point far from all
+// pivots still has d_i == theta) resolve to the lowest POSITION in the current permutation; `perm` /
+// `pos` track that permutation (one swap per step) so ties resolve identically here.
 struct PcState {
   float* dwork;      // [n] running Schur-complement diagonal; -inf once pivoted
   float* L;          // [rank][ldl]
@@ -80,6 +82,8 @@ struct PcState {
   int64_t* pivots;   // [rank]
   float* scal;       // [4]: orig_error, current error (l1 of live diag / orig), pivot value
   int* ctl;          // [2]: m (steps done), stop flag
+  int* perm;         // [n] perm[position] = index
+  int* pos;          // [n] pos[index] = position
   float tol;
 };
 
@@ -91,13 +95,15 @@ __global__ __launch_bounds__(1024) void pc_pivot_kernel(PcState st, int m) {
   if (st.ctl[1]) return;
   const int tid = threadIdx.x;
   float best = -INFINITY, sum = 0.f;
-  int bi = 0x7fffffff;
+  int bi = 0x7fffffff;  // best = (value, position in the permutation); ties -> lowest position
   for (int i = tid; i < st.n; i += 1024) {
     float v = st.dwork[i];
-    if (v > -INFINITY) sum += fabsf(v);
-    if (v > best) { best = v; bi = i; }
+    if (v > -INFINITY) {
+      sum += fabsf(v);
+      int ps = st.pos[i];
+      if (v > best || (v == best && ps < bi)) { best = v; bi = ps; }
+    }
   }
-  // wave reduce: max value, ties -> lowest index
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     float ov = __shfl_xor(best, o, 64);
@@ -118,10 +124,19 @@ __global__ __launch_bounds__(1024) void pc_pivot_kernel(PcState st, int m) {
     st.scal[1] = err;
     // reference loop condition: m == 0 or (m < max_iter and max(errors) > tol)
     if (m > 0 && !(err > st.tol)) { st.ctl[1] = 1; return; }
-    st.pivots[m] = bi;
+    // swap positions m and bi of the permutation (reference: pi_m <-> pi_i)
+    const int p = st.perm[bi], q = st.perm[m];
+    st.perm[m] = p; st.perm[bi] = q;
+    st.pos[p] = m; st.pos[q] = bi;
+    st.pivots[m] = p;
     st.scal[2] = best;
     st.ctl[0] = m + 1;
   }
+}
+
+__global__ void pc_init_perm_kernel(int* perm, int* pos, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { perm[i] = i; pos[i] = i; }
 }
 
 // L[m][i] = (K[p][i] - sum_{q<m} L[q][p] L[q][i]) / sqrt(d_p) for live i; L[m][p] = sqrt(d_p); d[i] -= L[m][i]^2

@@ -1,0 +1,176 @@
+"""Autograd Functions that put the HIP path under torch autograd.
+
+Mirror (third-party linear_operator):
+  * ``functions/_inv_quad_logdet.py::InvQuadLogdet``  (forward: mBCG + SLQ; backward: ONE bilinear
+    derivative with left = [K^-1 z c | -K^-1 y], right = [P^-1 z | K^-1 y])
+  * ``functions/_matmul.py::Matmul`` / ``KernelLinearOperator._bilinear_derivative``
+and the kernel-side backward of ``gpytorch/functions/rbf_covariance.py:26-29`` /
+``matern_covariance.py:53-56``.  Like those Functions, gradients with respect to the INPUT
+LOCATIONS x are not provided (``rbf_covariance.py:9-10`` raises for them).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import backend as B
+from . import settings
+from .bbmm import inv_quad_logdet_forward
+
+
+class KernelSpec:
+    """Non-tensor description of a stationary kernel operator (kind, centring shift, probe options)."""
+
+    def __init__(self, kind: str, shift=None):
+        self.kind = kind
+        self.shift = shift
+
+
+def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t):
+    """d/d(lengthscale), d/d(outputscale) of sum_c left[c]^T (outputscale * k(x1, x2)) right[c]."""
+    g = B.kv_grad(xp1, xp2, left_t, right_t)
+    d = xp1.d
+    theta = 1.0 if outputscale is None else outputscale.detach().reshape(()).to(torch.float32)
+    ls = lengthscale.detach().to(torch.float32).reshape(-1)
+    gq = g[1 : 1 + d]
+    if ls.numel() == 1:
+        d_ls = (theta * (-2.0) / ls * gq.sum()).reshape(lengthscale.shape)
+    else:
+        d_ls = (theta * (-2.0) / ls * gq).reshape(lengthscale.shape)
+    d_os = None if outputscale is None else g[0].reshape(outputscale.shape)
+    return d_ls.to(lengthscale.dtype), (None if d_os is None else d_os.to(outputscale.dtype))
+
+
+class InvQuadLogdetFn(torch.autograd.Function):
+    """(inv_quad[c], logdet) of K_hat = outputscale * k(x, x; lengthscale) + noise * I on the BBMM path."""
+
+    @staticmethod
+    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec, opts: dict):
+        n = x.shape[-2]
+        xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        nz = noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        rhs_t = B.to_probe_major(rhs)
+        res = inv_quad_logdet_forward(
+            xp, os_, nz, rhs_t,
+            num_probes=opts.get("num_probes"), precond=opts.get("precond", "auto"), probes=opts.get("probes"),
+            generator=opts.get("generator"), tolerance=opts.get("tolerance"), max_iter=opts.get("max_iter"),
+            group=opts.get("group"), t_total=opts.get("t_total"),
+        )
+        ctx.xp, ctx.res, ctx.n = xp, res, n
+        ctx.group = opts.get("group")
+        ctx.t_total = opts.get("t_total") or res.zt.shape[0]
+        ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0), noise, rhs)
+        ctx.has_os = outputscale is not None
+        opts["_last_info"] = res.info
+        return res.inv_quad.to(rhs.dtype), res.logdet.to(rhs.dtype)
+
+    @staticmethod
+    def backward(ctx, g_iq, g_ld):
+        lengthscale, outputscale, noise, rhs = ctx.saved_tensors
+        outputscale = outputscale if ctx.has_os else None
+        res, xp, n = ctx.res, ctx.xp, ctx.n
+        t = res.zt.shape[0]
+        c = res.solves_t.shape[0] - t
+        g_iq = g_iq.to(torch.float32).reshape(c, 1)
+        g_ld = g_ld.to(torch.float32).reshape(())
+        world = 1 if ctx.group is None else torch.distributed.get_world_size(ctx.group)
+        s_z = res.solves_t[:t] * res.znorm.unsqueeze(-1)
+        s_y = res.solves_t[t:]
+        zr = res.zt * res.znorm.unsqueeze(-1)
+        if res.precond is not None:
+            zr = res.precond.apply_(zr, torch.zeros_like(zr))
+        # the replicated y block is weighted 1/world so the all-reduced sum counts it once
+        left = torch.cat([s_z * (g_ld / ctx.t_total), -s_y * (g_iq / world)], dim=0).contiguous()
+        right = torch.cat([zr, s_y], dim=0).contiguous()
+        d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, left, right)
+        d_noise = B.coldot(left, right, n).sum().reshape(noise.shape).to(noise.dtype)
+        if ctx.group is not None:
+            pack = torch.cat([d_ls.reshape(-1).float(), d_noise.reshape(-1).float()] + ([d_os.reshape(-1).float()] if d_os is not None else []))
+            torch.distributed.all_reduce(pack, group=ctx.group)
+            k = d_ls.numel()
+            d_ls = pack[:k].reshape(d_ls.shape).to(d_ls.dtype)
+            d_noise = pack[k : k + 1].reshape(d_noise.shape).to(d_noise.dtype)
+            if d_os is not None:
+                d_os = pack[k + 1 :].reshape(d_os.shape).to(d_os.dtype)
+        d_rhs = None
+        if ctx.needs_input_grad[4]:
+            d_rhs = (2.0 * B.from_probe_major(s_y, n) * g_iq.reshape(1, c)).to(rhs.dtype)
+        return None, d_ls, d_os, d_noise, d_rhs, None, None
+
+
+class CholeskyInvQuadLogdetFn(torch.autograd.Function):
+    """Small-n branch (n <= max_cholesky_size or fast_computations.log_prob off): K_hat is formed by
+    the HIP dense kernel, factorised by rocSOLVER through torch; exact inv_quad / logdet."""
+
+    @staticmethod
+    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec):
+        n = x.shape[-2]
+        xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        K = B.kernel_dense(xp, xp, os_).to(torch.float64)
+        K.diagonal().add_(noise.detach().reshape(()).to(torch.float64))
+        Lc = torch.linalg.cholesky(K)
+        sol = torch.cholesky_solve(rhs.detach().to(torch.float64), Lc)
+        inv_quad = (sol * rhs.detach().to(torch.float64)).sum(-2)
+        logdet = 2.0 * Lc.diagonal().log().sum()
+        ctx.xp, ctx.n = xp, n
+        ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0), noise, rhs, Lc, sol)
+        ctx.has_os = outputscale is not None
+        return inv_quad.to(rhs.dtype), logdet.to(rhs.dtype)
+
+    @staticmethod
+    def backward(ctx, g_iq, g_ld):
+        lengthscale, outputscale, noise, rhs, Lc, sol = ctx.saved_tensors
+        outputscale = outputscale if ctx.has_os else None
+        n, xp = ctx.n, ctx.xp
+        c = sol.shape[-1]
+        kinv = torch.cholesky_inverse(Lc)
+        # d logdet = tr(K^-1 dK);  d inv_quad = -sol^T dK sol
+        left = torch.cat([kinv * g_ld.to(torch.float64), -(sol * g_iq.to(torch.float64).reshape(1, c)).t()], dim=0)
+        right = torch.cat([torch.eye(n, device=sol.device, dtype=torch.float64), sol.t()], dim=0)
+        ld = B.round_up(n, 4)
+        lt = torch.zeros(n + c, ld, device=sol.device, dtype=torch.float32)
+        rt = torch.zeros(n + c, ld, device=sol.device, dtype=torch.float32)
+        lt[:, :n] = left
+        rt[:, :n] = right
+        d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, lt, rt)
+        d_noise = (left * right).sum().reshape(noise.shape).to(noise.dtype)
+        d_rhs = (2.0 * sol * g_iq.to(torch.float64).reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[4] else None
+        return None, d_ls, d_os, d_noise, d_rhs, None
+
+
+class KernelMatmulFn(torch.autograd.Function):
+    """(outputscale * k(x1, x2)) @ rhs (+ noise * rhs when square and noise is given)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, lengthscale, outputscale, noise, rhs, spec: KernelSpec):
+        xp1 = B.prep_points(spec.kind, x1, lengthscale, spec.shift)
+        xp2 = xp1 if x2 is x1 else B.prep_points(spec.kind, x2, lengthscale, spec.shift)
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        nz = None if noise is None else noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        vt = B.to_probe_major(rhs)
+        out_t = B.kv(xp1, xp2, vt, scale=os_, dscale=nz, vd=vt if nz is not None else None)
+        ctx.xp1, ctx.xp2 = xp1, xp2
+        ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0),
+                              noise if noise is not None else torch.empty(0), rhs)
+        ctx.has_os, ctx.has_noise = outputscale is not None, noise is not None
+        return B.from_probe_major(out_t, xp1.n).to(rhs.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        lengthscale, outputscale, noise, rhs = ctx.saved_tensors
+        outputscale = outputscale if ctx.has_os else None
+        noise = noise if ctx.has_noise else None
+        gt = B.to_probe_major(g)
+        rt = B.to_probe_major(rhs)
+        d_ls = d_os = d_noise = d_rhs = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            d_ls, d_os = hyper_grads(ctx.xp1, ctx.xp2, lengthscale, outputscale, gt, rt)
+        if noise is not None and ctx.needs_input_grad[4]:
+            d_noise = (g * rhs).sum().reshape(noise.shape).to(noise.dtype)
+        if ctx.needs_input_grad[5]:
+            os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+            nz = None if noise is None else noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+            out_t = B.kv(ctx.xp2, ctx.xp1, gt, scale=os_, dscale=nz, vd=gt if nz is not None else None)
+            d_rhs = B.from_probe_major(out_t, ctx.xp2.n).to(rhs.dtype)
+        return None, None, d_ls, d_os, d_noise, d_rhs, None

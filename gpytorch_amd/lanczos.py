@@ -1,0 +1,95 @@
+"""Lanczos tridiagonalisation with full re-orthogonalisation and the root / root-inverse
+decompositions built on it (LOVE predictive-variance cache).
+
+Mirrors ``linear_operator.utils.lanczos.lanczos_tridiag`` / ``lanczos_tridiag_to_diag`` and
+``LinearOperator.root_inv_decomposition`` (third-party; restated in ``oracle/lanczos.py``,
+SURVEY.md A.7).  Reference call sites: ``gpytorch/models/exact_prediction_strategies.py:202,
+234-238,271``.  Each step is one fused K_hat*q (t = 1 -> the VALU kernel: generation-bound) plus
+O(n k) re-orthogonalisation on probe-major rows (rocBLAS GEMV through torch).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import backend as B
+from . import settings
+
+
+def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_t: torch.Tensor | None = None,
+                    tol: float = 1e-5, generator=None):
+    """Returns (Qt [m, ld] with orthonormal rows, T [m, m] float32 on device)."""
+    n = x.n
+    dev = x.xp.device
+    ld = B.round_up(n, 4)
+    num_iter = min(max_iter, n)
+    if init_vec_t is None:
+        init_vec_t = torch.zeros(1, ld, device=dev, dtype=torch.float32)
+        init_vec_t[:, :n] = torch.randn(1, n, device=dev, generator=generator, dtype=torch.float32)
+    Q = torch.zeros(num_iter, ld, device=dev, dtype=torch.float32)
+    T = torch.zeros(num_iter, num_iter, device=dev, dtype=torch.float32)
+
+    def mv(q_row):  # K_hat q, q_row: [1, ld]
+        return B.kv(x, x, q_row, scale=scale, dscale=dscale, vd=q_row if dscale is not None else None)
+
+    q0 = init_vec_t / init_vec_t.norm()
+    Q[0] = q0[0]
+    r = mv(q0)
+    a0 = (q0 * r).sum()
+    r = r - a0 * q0
+    b0 = r.norm()
+    T[0, 0] = a0
+    m = 1
+    if num_iter > 1:
+        T[0, 1] = b0
+        T[1, 0] = b0
+        Q[1] = (r / b0)[0]
+        m = 2
+        for k in range(1, num_iter):
+            q_prev, q = Q[k - 1 : k], Q[k : k + 1]
+            b_prev = T[k, k - 1]
+            r = mv(q) - b_prev * q_prev
+            a = (q * r).sum()
+            T[k, k] = a
+            m = k + 1
+            if k + 1 < num_iter:
+                r = r - a * q
+                basis = Q[: k + 1]
+                r = r - (r @ basis.t()) @ basis
+                b = r.norm()
+                r = r / b
+                T[k, k + 1] = b
+                T[k + 1, k] = b
+                ok = False
+                for _ in range(10):
+                    inner = r @ basis.t()
+                    if not bool((inner.abs() > tol).any()):
+                        ok = True
+                        break
+                    r = r - inner @ basis
+                    r = r / r.norm()
+                Q[k + 1] = r[0]
+                if bool(b.abs() < 1e-6) or not ok:
+                    break
+                m = k + 2
+    return Q[:m], T[:m, :m]
+
+
+def tridiag_to_diag(T: torch.Tensor):
+    """``lanczos_tridiag_to_diag``: eigh on the host in float64 (tiny), negative eigenvalues masked."""
+    evals, evecs = torch.linalg.eigh(T.detach().to(device="cpu", dtype=torch.float64))
+    mask = evals >= 0
+    evecs = evecs * mask.to(evecs.dtype).unsqueeze(-2)
+    evals = evals.masked_fill(~mask, 1.0)
+    return evals, evecs
+
+
+def root_inv_decomposition(x: B.PreparedPoints, scale, dscale, max_iter=None, init_vec_t=None, generator=None):
+    """Rt [m, ld] with Rt^T Rt ~= K_hat^-1 on the Krylov space (the ``covar_cache`` of
+    ``exact_prediction_strategies.py:267-272``)."""
+    max_iter = settings.max_root_decomposition_size.value() if max_iter is None else max_iter
+    Q, T = lanczos_tridiag(x, scale, dscale, max_iter, init_vec_t, generator=generator)
+    jitter = settings.tridiagonal_jitter.value()
+    Tj = T + jitter * torch.eye(T.shape[0], device=T.device, dtype=T.dtype)
+    evals, evecs = tridiag_to_diag(Tj)
+    w = (evecs / evals.sqrt().unsqueeze(-2)).to(device=Q.device, dtype=torch.float32)  # V Lambda^-1/2
+    return w.t() @ Q  # [m, ld]: rows = columns of Q V Lambda^-1/2

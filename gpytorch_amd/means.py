@@ -1,0 +1,40 @@
+"""Mean functions used by the ExactGP hot path (``gpytorch/means/constant_mean.py:111-113``,
+``zero_mean.py``).  Pure PyTorch glue."""
+from __future__ import annotations
+
+import torch
+
+from .module import Module
+
+
+class Mean(Module):
+    def __call__(self, x):
+        if x.dim() == 1:
+            x = x.unsqueeze(1)
+        return self.forward(x)
+
+
+class ZeroMean(Mean):
+    def forward(self, x):
+        return torch.zeros(x.shape[:-1], dtype=x.dtype, device=x.device)
+
+
+class ConstantMean(Mean):
+    def __init__(self, constant_prior=None, constant_constraint=None):
+        super().__init__()
+        self.register_parameter("raw_constant", torch.nn.Parameter(torch.zeros(())))
+        if constant_constraint is not None:
+            self.register_constraint("raw_constant", constant_constraint)
+        if constant_prior is not None:
+            self.register_prior("mean_prior", constant_prior, lambda m: m.constant, lambda m, v: m._set_transformed("raw_constant", v))
+
+    @property
+    def constant(self):
+        return self._get_transformed("raw_constant")
+
+    @constant.setter
+    def constant(self, value):
+        self._set_transformed("raw_constant", value)
+
+    def forward(self, x):
+        return self.constant.unsqueeze(-1).expand(x.shape[:-1])  # constant_mean.py:111-113

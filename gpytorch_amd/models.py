@@ -1,0 +1,197 @@
+"""``ExactGP`` and ``DefaultPredictionStrategy`` -- train / prior / posterior dispatch and the
+prediction caches, following ``gpytorch/models/exact_gp.py:265-333,355-430`` and
+``gpytorch/models/exact_prediction_strategies.py:46-92,267-321,331-478``:
+
+  * mean cache  = K_hat^-1 (y - mu)  by preconditioned mBCG at ``eval_cg_tolerance``   (:278-286, exact_gp.py:324)
+  * mean        = K_*X @ mean_cache + mu_*   (rectangular fused K*V, t = 1)             (:396,411)
+  * covariance  = K_** - (K_*X S)(K_*X S)^T with S the Lanczos root-inverse (LOVE,
+                  ``fast_pred_var``)                                                      (:267-272,464-478)
+                  or K_** - K_*X K_hat^-1 K_X* by an n_test-column mBCG                  (:431-462)
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from . import settings
+from .distributions import MultivariateNormal
+from .module import Module
+from .operators import (
+    DenseLinearOperator,
+    LinearOperator,
+    MatmulLinearOperator,
+    SumLinearOperator,
+    ZeroLinearOperator,
+    to_dense,
+    to_linear_operator,
+)
+
+
+class GPInputWarning(UserWarning):
+    pass
+
+
+class DefaultPredictionStrategy:
+    def __init__(self, train_inputs, train_prior_dist, train_labels, likelihood, root=None, inv_root=None):
+        self._train_shape = train_prior_dist.event_shape
+        self.train_inputs = train_inputs
+        self.train_prior_dist = train_prior_dist
+        self.train_labels = train_labels.reshape(*train_labels.shape[: -len(self._train_shape)], self._train_shape.numel())
+        self.likelihood = likelihood
+        self._last_test_train_covar = None
+        mvn = self.likelihood(train_prior_dist, train_inputs)
+        self.lik_train_train_covar = mvn.lazy_covariance_matrix
+        self._mean_cache = None
+        self._covar_cache = None
+        self._inv_root = inv_root
+
+    @property
+    def num_train(self):
+        return self._train_shape.numel()
+
+    @property
+    def mean_cache(self):
+        """exact_prediction_strategies.py:278-321 (nan policy 'ignore')."""
+        if self._mean_cache is None:
+            mvn = self.likelihood(self.train_prior_dist, self.train_inputs)
+            train_mean, train_train_covar = mvn.loc, mvn.lazy_covariance_matrix
+            offset = (self.train_labels - train_mean).unsqueeze(-1)
+            mc = train_train_covar.evaluate_kernel().solve(offset).squeeze(-1)
+            if settings.detach_test_caches.on():
+                mc = mc.detach()
+            self._mean_cache = mc
+        return self._mean_cache
+
+    @property
+    def covar_cache(self):
+        """exact_prediction_strategies.py:267-272: root of K_hat^-1 (n x m)."""
+        if self._covar_cache is None:
+            cov = self.lik_train_train_covar
+            if settings.detach_test_caches.on():
+                cov = cov.detach()
+            root = self._inv_root if self._inv_root is not None else to_dense(cov.root_inv_decomposition().root)
+            self._covar_cache = root.detach() if settings.detach_test_caches.on() else root
+        return self._covar_cache
+
+    def exact_prediction(self, test_mean, test_test_covar, test_train_covar):
+        """:331-369."""
+        if sum(test_train_covar.shape[-2:]) <= settings.max_eager_kernel_size.value():
+            test_train_covar = to_dense(test_train_covar)
+            test_test_covar = to_dense(test_test_covar)
+        return (
+            self.exact_predictive_mean(test_mean, test_train_covar),
+            self.exact_predictive_covar(test_test_covar, test_train_covar),
+        )
+
+    def exact_predictive_mean(self, test_mean, test_train_covar):
+        """:371-412."""
+        res = (test_train_covar @ self.mean_cache.unsqueeze(-1)).squeeze(-1)
+        return res + test_mean
+
+    def exact_predictive_covar(self, test_test_covar, test_train_covar):
+        """:414-478."""
+        if settings.fast_pred_var.on():
+            self._last_test_train_covar = test_train_covar
+        if settings.skip_posterior_variances.on():
+            return ZeroLinearOperator(*test_test_covar.shape, dtype=test_train_covar.dtype, device=test_train_covar.device)
+        if settings.fast_pred_var.off():
+            dist = self.train_prior_dist.__class__(torch.zeros_like(self.train_prior_dist.mean), self.train_prior_dist.lazy_covariance_matrix)
+            train_train_covar = self.likelihood(dist, self.train_inputs).lazy_covariance_matrix
+            if settings.detach_test_caches.on():
+                train_train_covar = train_train_covar.detach()
+            ttc = to_dense(test_train_covar)
+            rhs = train_train_covar.solve(ttc.mT.contiguous())
+            if torch.is_tensor(test_test_covar):
+                return to_linear_operator(torch.addmm(test_test_covar, ttc, rhs, beta=1, alpha=-1))
+            return test_test_covar + MatmulLinearOperator(DenseLinearOperator(ttc), DenseLinearOperator(rhs.mul(-1)))
+        root = to_linear_operator(test_train_covar) @ self.covar_cache  # [n_test, m]
+        if torch.is_tensor(test_test_covar):
+            return to_linear_operator(torch.add(test_test_covar, root @ root.mT, alpha=-1))
+        return SumLinearOperator(test_test_covar, MatmulLinearOperator(DenseLinearOperator(root), DenseLinearOperator(root.mT.mul(-1))))
+
+
+def prediction_strategy(train_inputs, train_prior_dist, train_labels, likelihood):
+    """exact_prediction_strategies.py:30-36."""
+    return DefaultPredictionStrategy(train_inputs, train_prior_dist, train_labels, likelihood)
+
+
+class GP(Module):
+    pass
+
+
+class ExactGP(GP):
+    def __init__(self, train_inputs, train_targets, likelihood):
+        if train_inputs is not None and torch.is_tensor(train_inputs):
+            train_inputs = (train_inputs,)
+        if train_inputs is not None and not all(torch.is_tensor(t) for t in train_inputs):
+            raise RuntimeError("Train inputs must be a tensor, or a list/tuple of tensors")
+        super().__init__()
+        if train_inputs is not None:
+            self.train_inputs = tuple(t.unsqueeze(-1) if t.ndimension() == 1 else t for t in train_inputs)
+            self.train_targets = train_targets
+        else:
+            self.train_inputs = None
+            self.train_targets = None
+        self.likelihood = likelihood
+        self.prediction_strategy = None
+
+    def set_train_data(self, inputs=None, targets=None, strict=True):
+        """exact_gp.py:113-149."""
+        if inputs is not None:
+            if torch.is_tensor(inputs):
+                inputs = (inputs,)
+            inputs = tuple(i.unsqueeze(-1) if i.ndimension() == 1 else i for i in inputs)
+            if strict:
+                for new, old in zip(inputs, self.train_inputs or (None,)):
+                    if old is not None and (new.shape != old.shape or new.dtype != old.dtype or new.device != old.device):
+                        raise RuntimeError("Cannot modify shape/dtype/device of train inputs with strict=True")
+            self.train_inputs = inputs
+        if targets is not None:
+            if strict and self.train_targets is not None and targets.shape != self.train_targets.shape:
+                raise RuntimeError("Cannot modify shape of train targets with strict=True")
+            self.train_targets = targets
+        self.prediction_strategy = None
+
+    def train(self, mode=True):
+        if mode:
+            self.prediction_strategy = None  # exact_gp.py:99-101
+        return super().train(mode)
+
+    def __call__(self, *args, **kwargs):
+        """exact_gp.py:265-333."""
+        train_inputs = list(self.train_inputs) if self.train_inputs is not None else []
+        inputs = [i.unsqueeze(-1) if i.ndimension() == 1 else i for i in args]
+        if self.training:
+            if self.train_inputs is None:
+                raise RuntimeError("train_inputs, train_targets cannot be None in training mode. Call .eval() for prior predictions, or call .set_train_data() to add training data.")
+            if settings.debug.on():
+                if not all(torch.equal(ti, inp) for ti, inp in zip(train_inputs, inputs)):
+                    raise RuntimeError("You must train on the training inputs!")
+            return Module.__call__(self, *inputs, **kwargs)
+        if self.train_inputs is None or self.train_targets is None:
+            return Module.__call__(self, *inputs, **kwargs)  # prior mode
+        if settings.debug.on():
+            if all(torch.equal(ti, inp) for ti, inp in zip(train_inputs, inputs)):
+                warnings.warn("The input matches the stored training data. Did you forget to call model.train()?", GPInputWarning)
+        if self.prediction_strategy is None:
+            train_output = Module.__call__(self, *train_inputs, **kwargs)
+            self.prediction_strategy = prediction_strategy(train_inputs, train_output, self.train_targets, self.likelihood)
+        full_mean, test_test_covar, test_train_covar = self._get_test_prior_mean_and_covariances(train_inputs, inputs, **kwargs)
+        with settings.cg_tolerance(settings.eval_cg_tolerance.value()):  # exact_gp.py:324
+            predictive_mean, predictive_covar = self.prediction_strategy.exact_prediction(full_mean, test_test_covar, test_train_covar)
+        return MultivariateNormal(predictive_mean, predictive_covar)
+
+    def _get_test_prior_mean_and_covariances(self, train_inputs, inputs, **kwargs):
+        """exact_gp.py:355-430: joint train u test prior, sliced lazily."""
+        full_inputs = [torch.cat([ti, inp], dim=-2) for ti, inp in zip(train_inputs, inputs)]
+        full_output = Module.__call__(self, *full_inputs, **kwargs)
+        full_mean, full_covar = full_output.loc, full_output.lazy_covariance_matrix
+        n = self.prediction_strategy.num_train
+        test_mean = full_mean[..., n:]
+        test_test_covar = full_covar[n:, n:].evaluate_kernel()
+        test_train_covar = full_covar[n:, :n].evaluate_kernel()
+        return test_mean, test_test_covar, test_train_covar
+
+
+_ = LinearOperator

@@ -1,0 +1,576 @@
+"""LinearOperator-protocol classes of the BBMM path.
+
+The reference's operator algebra lives in the third-party ``linear_operator`` package; only the
+members the ExactGP hot path touches are mirrored here, with the same names and argument meaning
+(seam 2):
+
+  ``_matmul / matmul / @``, ``_size / shape``, ``_transpose_nonbatch / mT``, ``diagonal``, ``to_dense``,
+  ``evaluate_kernel``, ``__getitem__`` (row / column slices), ``mul`` (ScaleKernel), ``__add__`` /
+  ``add_diagonal`` (likelihood noise), ``inv_quad_logdet``, ``inv_quad``, ``logdet``, ``solve``,
+  ``pivoted_cholesky``, ``root_inv_decomposition``, ``detach``.
+
+:class:`FusedKernelLinearOperator` plays the role of ``KernelLinearOperator`` as constructed at
+``gpytorch/kernels/keops/rbf_kernel.py:48`` (matrix-free, K never formed) and
+:class:`FusedKernelAddedDiagLinearOperator` that of ``AddedDiagLinearOperator`` built by
+``_GaussianLikelihoodBase.marginal`` (``gpytorch/likelihoods/gaussian_likelihood.py:117-121``); their
+hot methods run on the HIP kernels through :mod:`gpytorch_amd.functions`.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import backend as B
+from . import settings
+from .functions import CholeskyInvQuadLogdetFn, InvQuadLogdetFn, KernelMatmulFn, KernelSpec
+
+
+class LinearOperator:
+    """Minimal protocol base (2-D, no batch dimensions: the fused kernels are non-batched)."""
+
+    def _size(self) -> torch.Size:
+        raise NotImplementedError
+
+    def _matmul(self, rhs: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _transpose_nonbatch(self) -> "LinearOperator":
+        raise NotImplementedError
+
+    # ---- generic API ----
+    @property
+    def shape(self):
+        return self._size()
+
+    def size(self, dim=None):
+        s = self._size()
+        return s if dim is None else s[dim]
+
+    def dim(self):
+        return len(self._size())
+
+    @property
+    def batch_shape(self):
+        return torch.Size([])
+
+    @property
+    def is_square(self):
+        return self.shape[-1] == self.shape[-2]
+
+    def matmul(self, rhs):
+        if isinstance(rhs, LinearOperator):
+            return MatmulLinearOperator(self, rhs)
+        squeeze = rhs.dim() == 1
+        out = self._matmul(rhs.unsqueeze(-1) if squeeze else rhs)
+        return out.squeeze(-1) if squeeze else out
+
+    __matmul__ = matmul
+
+    @property
+    def mT(self):
+        return self._transpose_nonbatch()
+
+    def t(self):
+        return self._transpose_nonbatch()
+
+    def transpose(self, d0, d1):
+        return self._transpose_nonbatch()
+
+    def evaluate_kernel(self):
+        return self
+
+    def to_dense(self) -> torch.Tensor:
+        n = self.shape[-1]
+        return self._matmul(torch.eye(n, device=self.device, dtype=self.dtype))
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return self.to_dense().diagonal()
+
+    def _diagonal(self):
+        return self.diagonal()
+
+    def add_diagonal(self, diag: torch.Tensor):
+        n = self.shape[-1]
+        if diag.numel() == 1:
+            return self + ConstantDiagLinearOperator(diag.reshape(1), n)
+        return self + DiagLinearOperator(diag)
+
+    def add_jitter(self, jitter_val=1e-3):
+        return self.add_diagonal(torch.tensor([jitter_val], device=self.device, dtype=self.dtype))
+
+    def __add__(self, other):
+        if isinstance(other, ZeroLinearOperator):
+            return self
+        if isinstance(other, torch.Tensor):
+            other = DenseLinearOperator(other)
+        return SumLinearOperator(self, other)
+
+    def mul(self, other):
+        if isinstance(other, (int, float)):
+            other = torch.tensor([float(other)], device=self.device, dtype=self.dtype)
+        return self._mul_constant(other)
+
+    __mul__ = mul
+
+    def _mul_constant(self, c):
+        return DenseLinearOperator(self.to_dense() * c.reshape(()))
+
+    def __getitem__(self, index):
+        return DenseLinearOperator(self.to_dense()[index])
+
+    def detach(self):
+        return self
+
+    def numel(self):
+        return self.shape[-1] * self.shape[-2]
+
+    # ---- solves / determinants: dense Cholesky defaults (small operators only) ----
+    def cholesky(self):
+        return torch.linalg.cholesky(self.to_dense().to(torch.float64))
+
+    def solve(self, rhs: torch.Tensor, lhs=None) -> torch.Tensor:
+        squeeze = rhs.dim() == 1
+        r = rhs.unsqueeze(-1) if squeeze else rhs
+        sol = torch.cholesky_solve(r.to(torch.float64), self.cholesky()).to(rhs.dtype)
+        if lhs is not None:
+            sol = lhs @ sol
+        return sol.squeeze(-1) if squeeze else sol
+
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        Lc = self.cholesky()
+        iq = None
+        if inv_quad_rhs is not None:
+            r = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
+            sol = torch.cholesky_solve(r.to(torch.float64), Lc)
+            iq = (sol * r.to(torch.float64)).sum(-2).to(r.dtype)
+            if reduce_inv_quad:
+                iq = iq.sum(-1)
+        ld = (2.0 * Lc.diagonal().log().sum()).to(self.dtype) if logdet else None
+        return iq, ld
+
+    def inv_quad(self, inv_quad_rhs, reduce_inv_quad=True):
+        return self.inv_quad_logdet(inv_quad_rhs, False, reduce_inv_quad)[0]
+
+    def logdet(self):
+        return self.inv_quad_logdet(None, True)[1]
+
+    def root_decomposition(self):
+        return RootLinearOperator(self.cholesky().to(self.dtype))
+
+    def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
+        Lc = self.cholesky()
+        inv_root = torch.linalg.solve_triangular(Lc, torch.eye(Lc.shape[-1], dtype=Lc.dtype, device=Lc.device), upper=False).mT
+        return RootLinearOperator(inv_root.to(self.dtype))
+
+    @property
+    def requires_grad(self):
+        return False
+
+
+class DenseLinearOperator(LinearOperator):
+    def __init__(self, tensor: torch.Tensor):
+        self.tensor = tensor
+
+    dtype = property(lambda self: self.tensor.dtype)
+    device = property(lambda self: self.tensor.device)
+
+    def _size(self):
+        return self.tensor.shape
+
+    def _matmul(self, rhs):
+        return self.tensor @ rhs
+
+    def _transpose_nonbatch(self):
+        return DenseLinearOperator(self.tensor.mT)
+
+    def to_dense(self):
+        return self.tensor
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return self.tensor.diagonal(dim1=-2, dim2=-1)
+
+    def detach(self):
+        return DenseLinearOperator(self.tensor.detach())
+
+
+def to_linear_operator(obj):
+    return obj if isinstance(obj, LinearOperator) else DenseLinearOperator(obj)
+
+
+def to_dense(obj):
+    return obj.to_dense() if isinstance(obj, LinearOperator) else obj
+
+
+class ZeroLinearOperator(LinearOperator):
+    def __init__(self, *sizes, dtype=torch.float32, device=None):
+        self._sizes = torch.Size(sizes)
+        self.dtype, self.device = dtype, device
+
+    def _size(self):
+        return self._sizes
+
+    def _matmul(self, rhs):
+        return torch.zeros(self._sizes[-2], rhs.shape[-1], dtype=rhs.dtype, device=rhs.device)
+
+    def _transpose_nonbatch(self):
+        return ZeroLinearOperator(self._sizes[-1], self._sizes[-2], dtype=self.dtype, device=self.device)
+
+    def to_dense(self):
+        return torch.zeros(*self._sizes, dtype=self.dtype, device=self.device)
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return torch.zeros(self._sizes[-1], dtype=self.dtype, device=self.device)
+
+    def __add__(self, other):
+        return other
+
+
+class DiagLinearOperator(LinearOperator):
+    def __init__(self, diag: torch.Tensor):
+        self._diag = diag
+
+    dtype = property(lambda self: self._diag.dtype)
+    device = property(lambda self: self._diag.device)
+
+    def _size(self):
+        n = self._diag.shape[-1]
+        return torch.Size([n, n])
+
+    def _matmul(self, rhs):
+        return self._diag.unsqueeze(-1) * rhs
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return self._diag
+
+    def to_dense(self):
+        return torch.diag(self._diag)
+
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        iq = None
+        if inv_quad_rhs is not None:
+            r = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
+            iq = (r.pow(2) / self._diag.unsqueeze(-1)).sum(-2)
+            if reduce_inv_quad:
+                iq = iq.sum(-1)
+        return iq, (self._diag.log().sum() if logdet else None)
+
+
+class ConstantDiagLinearOperator(DiagLinearOperator):
+    """``noise_models.py:92``: sigma^2 I as a 1-element tensor + size."""
+
+    def __init__(self, diag_values: torch.Tensor, diag_shape: int):
+        self.diag_values = diag_values
+        self.diag_shape = diag_shape
+
+    @property
+    def _diag(self):
+        return self.diag_values.expand(self.diag_shape)
+
+
+class RootLinearOperator(LinearOperator):
+    def __init__(self, root: torch.Tensor):
+        self.root = root
+
+    dtype = property(lambda self: self.root.dtype)
+    device = property(lambda self: self.root.device)
+
+    def _size(self):
+        n = self.root.shape[-2]
+        return torch.Size([n, n])
+
+    def _matmul(self, rhs):
+        return self.root @ (self.root.mT @ rhs)
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def to_dense(self):
+        return self.root @ self.root.mT
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return self.root.pow(2).sum(-1)
+
+
+class MatmulLinearOperator(LinearOperator):
+    def __init__(self, left, right):
+        self.left, self.right = to_linear_operator(left), to_linear_operator(right)
+
+    dtype = property(lambda self: self.left.dtype)
+    device = property(lambda self: self.left.device)
+
+    def _size(self):
+        return torch.Size([self.left.shape[-2], self.right.shape[-1]])
+
+    def _matmul(self, rhs):
+        return self.left._matmul(self.right._matmul(rhs))
+
+    def _transpose_nonbatch(self):
+        return MatmulLinearOperator(self.right._transpose_nonbatch(), self.left._transpose_nonbatch())
+
+    def to_dense(self):
+        return self.left.to_dense() @ self.right.to_dense()
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return (self.left.to_dense() * self.right.to_dense().mT).sum(-1)
+
+
+class SumLinearOperator(LinearOperator):
+    def __init__(self, *ops):
+        self.ops = [to_linear_operator(o) for o in ops]
+
+    dtype = property(lambda self: self.ops[0].dtype)
+    device = property(lambda self: self.ops[0].device)
+
+    def _size(self):
+        return self.ops[0].shape
+
+    def _matmul(self, rhs):
+        out = self.ops[0]._matmul(rhs)
+        for o in self.ops[1:]:
+            out = out + o._matmul(rhs)
+        return out
+
+    def _transpose_nonbatch(self):
+        return SumLinearOperator(*[o._transpose_nonbatch() for o in self.ops])
+
+    def to_dense(self):
+        out = self.ops[0].to_dense()
+        for o in self.ops[1:]:
+            out = out + o.to_dense()
+        return out
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        out = self.ops[0].diagonal()
+        for o in self.ops[1:]:
+            out = out + o.diagonal()
+        return out
+
+
+# =================================================================================================
+class FusedKernelLinearOperator(LinearOperator):
+    """outputscale * k(x1, x2; lengthscale) -- matrix-free; every product runs on the fused HIP kernels.
+
+    ``spec.shift`` is the Matern centring vector (``matern_kernel.py:94``: mean of x1 of the ORIGINAL
+    kernel call; slices keep it)."""
+
+    def __init__(self, x1, x2, spec: KernelSpec, lengthscale, outputscale=None):
+        self.x1, self.x2 = x1, x2
+        self.spec = spec
+        self.lengthscale, self.outputscale = lengthscale, outputscale
+        self._prep = None
+
+    dtype = property(lambda self: self.x1.dtype)
+    device = property(lambda self: self.x1.device)
+
+    @property
+    def requires_grad(self):
+        return bool(self.lengthscale.requires_grad or (self.outputscale is not None and self.outputscale.requires_grad))
+
+    @property
+    def square_same_inputs(self):
+        return self.x1 is self.x2 or (self.x1.shape == self.x2.shape and self.x1.data_ptr() == self.x2.data_ptr())
+
+    def _size(self):
+        return torch.Size([self.x1.shape[-2], self.x2.shape[-2]])
+
+    def _os(self):
+        return None if self.outputscale is None else self.outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+
+    def prepared(self):
+        if self._prep is None:
+            p1 = B.prep_points(self.spec.kind, self.x1, self.lengthscale, self.spec.shift)
+            p2 = p1 if self.square_same_inputs else B.prep_points(self.spec.kind, self.x2, self.lengthscale, self.spec.shift)
+            self._prep = (p1, p2)
+        return self._prep
+
+    def _matmul(self, rhs):
+        x2 = self.x1 if self.square_same_inputs else self.x2
+        return KernelMatmulFn.apply(self.x1, x2, self.lengthscale, self.outputscale, None, rhs, self.spec)
+
+    def _transpose_nonbatch(self):
+        return FusedKernelLinearOperator(self.x2, self.x1, self.spec, self.lengthscale, self.outputscale)
+
+    def _mul_constant(self, c):
+        os_ = c if self.outputscale is None else self.outputscale.reshape(()) * c.reshape(())
+        return FusedKernelLinearOperator(self.x1, self.x2, self.spec, self.lengthscale, os_.reshape(1))
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        n = self.x1.shape[-2]
+        if self.square_same_inputs:  # stationary kernel: k(0) = 1 (kernels/kernel.py:332-334)
+            one = torch.ones(n, device=self.device, dtype=self.dtype)
+            return one if self.outputscale is None else one * self.outputscale.reshape(())
+        p1, p2 = self.prepared()
+        return B.kernel_diag(p1, p2, self._os()).to(self.dtype)
+
+    def to_dense(self):
+        p1, p2 = self.prepared()
+        return B.kernel_dense(p1, p2, self._os()).to(self.dtype)
+
+    def __getitem__(self, index):
+        if not isinstance(index, tuple):
+            index = (index, slice(None))
+        r, c = index
+        if isinstance(r, int) or isinstance(c, int):
+            return self.to_dense()[index]
+        x1 = self.x1[r]
+        x2 = x1 if (self.square_same_inputs and _same_index(r, c)) else self.x2[c]
+        return FusedKernelLinearOperator(x1, x2, self.spec, self.lengthscale, self.outputscale)
+
+    def rows(self, idx):
+        p1, p2 = self.prepared()
+        return B.kernel_rows(p1, idx, p2, self._os())
+
+    def __add__(self, other):
+        if isinstance(other, ConstantDiagLinearOperator) and self.is_square:
+            return FusedKernelAddedDiagLinearOperator(self, other.diag_values)
+        if isinstance(other, DiagLinearOperator) and self.is_square and bool((other._diag == other._diag[0]).all()):
+            return FusedKernelAddedDiagLinearOperator(self, other._diag[:1])
+        return super().__add__(other)
+
+    def detach(self):
+        return FusedKernelLinearOperator(
+            self.x1, self.x2, self.spec, self.lengthscale.detach(), None if self.outputscale is None else self.outputscale.detach()
+        )
+
+    def pivoted_cholesky(self, rank, error_tol=None, return_pivots=False):
+        """``LinearOperator.pivoted_cholesky`` (wrapper ``gpytorch/__init__.py:146-173``): returns L (n x m)."""
+        p1, _ = self.prepared()
+        tol = settings.preconditioner_tolerance.value() if error_tol is None else error_tol
+        Lt, piv, m = B.pivoted_cholesky(p1, self._os(), rank, tol)
+        L = Lt.t().contiguous().to(self.dtype)
+        return (L, piv) if return_pivots else L
+
+
+def _same_index(r, c):
+    if isinstance(r, slice) and isinstance(c, slice):
+        return (r.start, r.stop, r.step) == (c.start, c.stop, c.step)
+    return r is c
+
+
+class FusedKernelAddedDiagLinearOperator(LinearOperator):
+    """K_hat = outputscale * k(x, x) + noise * I  (constant diagonal) -- the operator the MLL and the
+    prediction caches solve with.  ``bbmm_opts`` forwards probe / sharding options to the solver."""
+
+    def __init__(self, kernel_op: FusedKernelLinearOperator, noise: torch.Tensor, bbmm_opts: dict | None = None):
+        self.kernel_op = kernel_op
+        self.noise = noise.reshape(-1)[:1]
+        self.bbmm_opts = {} if bbmm_opts is None else bbmm_opts
+        self._cache = {}
+
+    dtype = property(lambda self: self.kernel_op.dtype)
+    device = property(lambda self: self.kernel_op.device)
+
+    @property
+    def requires_grad(self):
+        return self.kernel_op.requires_grad or self.noise.requires_grad
+
+    def _size(self):
+        return self.kernel_op._size()
+
+    def _matmul(self, rhs):
+        k = self.kernel_op
+        return KernelMatmulFn.apply(k.x1, k.x1, k.lengthscale, k.outputscale, self.noise, rhs, k.spec)
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return self.kernel_op.diagonal() + self.noise.reshape(())
+
+    def to_dense(self):
+        K = self.kernel_op.to_dense()
+        return K + self.noise.reshape(()) * torch.eye(K.shape[-1], device=K.device, dtype=K.dtype)
+
+    def __add__(self, other):
+        if isinstance(other, ConstantDiagLinearOperator):
+            return FusedKernelAddedDiagLinearOperator(self.kernel_op, self.noise + other.diag_values.reshape(-1)[:1], self.bbmm_opts)
+        return super().__add__(other)
+
+    def detach(self):
+        return FusedKernelAddedDiagLinearOperator(self.kernel_op.detach(), self.noise.detach(), self.bbmm_opts)
+
+    def _use_cholesky(self, flag) -> bool:
+        return flag.off() or self.shape[-1] <= settings.max_cholesky_size.value()
+
+    def _nz(self):
+        return self.noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+
+    # ---- A.1 dispatch ----
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        k = self.kernel_op
+        n = self.shape[-1]
+        if inv_quad_rhs is None:
+            inv_quad_rhs = torch.zeros(n, 0, device=self.device, dtype=self.dtype)
+        rhs = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
+        if self._use_cholesky(settings.fast_computations.log_prob):
+            iq, ld = CholeskyInvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, k.spec)
+        else:
+            if rhs.shape[-1] == 0:
+                rhs = torch.zeros(n, 1, device=self.device, dtype=self.dtype)
+                drop = True
+            else:
+                drop = False
+            iq, ld = InvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, k.spec, self.bbmm_opts)
+            if drop:
+                iq = iq[:0]
+        if reduce_inv_quad:
+            iq = iq.sum(-1)
+        return iq, (ld if logdet else None)
+
+    def _preconditioner(self):
+        """``AddedDiagLinearOperator._preconditioner``: (closure on [n, c] tensors, None, logdet) or Nones."""
+        from .bbmm import build_preconditioner
+
+        if "precond" not in self._cache:
+            p1, _ = self.kernel_op.prepared()
+            self._cache["precond"] = build_preconditioner(p1, self.kernel_op._os(), self._nz())
+        pre = self._cache["precond"]
+        if pre is None:
+            return None, None, None
+
+        def closure(v):
+            vt = B.to_probe_major(v)
+            return B.from_probe_major(pre.apply_(vt, torch.zeros_like(vt)), v.shape[-2]).to(v.dtype)
+
+        return closure, None, pre.logdet
+
+    def solve(self, rhs: torch.Tensor, lhs=None) -> torch.Tensor:
+        """K_hat^-1 rhs (``exact_prediction_strategies.py:286,444``).  No autograd through the solve
+        (prediction caches are detached: ``settings.detach_test_caches``)."""
+        from .bbmm import build_preconditioner
+        from .linear_cg import linear_cg
+
+        squeeze = rhs.dim() == 1
+        r = rhs.unsqueeze(-1) if squeeze else rhs
+        if self._use_cholesky(settings.fast_computations.solves):
+            sol = torch.cholesky_solve(r.detach().to(torch.float64), torch.linalg.cholesky(self.to_dense().detach().to(torch.float64))).to(rhs.dtype)
+        else:
+            p1, _ = self.kernel_op.prepared()
+            if "precond" not in self._cache:
+                self._cache["precond"] = build_preconditioner(p1, self.kernel_op._os(), self._nz())
+            sol_t, info = linear_cg(
+                p1, self.kernel_op._os(), self._nz(), B.to_probe_major(r.detach()), n_tridiag=0,
+                tolerance=settings.cg_tolerance.value(), preconditioner=self._cache["precond"],
+            )
+            self._cache["last_cg_info"] = info
+            sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
+        if lhs is not None:
+            sol = lhs @ sol
+        return sol.squeeze(-1) if squeeze else sol
+
+    def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
+        """Lanczos root-inverse (``exact_prediction_strategies.py:271``) -> RootLinearOperator(n x m)."""
+        from .lanczos import root_inv_decomposition
+
+        if self._use_cholesky(settings.fast_computations.covar_root_decomposition):
+            return super().root_inv_decomposition()
+        p1, _ = self.kernel_op.prepared()
+        init_t = None if initial_vectors is None else B.to_probe_major(initial_vectors.reshape(self.shape[-1], -1)[:, :1])
+        rt = root_inv_decomposition(p1, self.kernel_op._os(), self._nz(), init_vec_t=init_t,
+                                    generator=self.bbmm_opts.get("generator"))
+        return RootLinearOperator(B.from_probe_major(rt, self.shape[-1]).to(self.dtype))
+
+    def pivoted_cholesky(self, rank, error_tol=None, return_pivots=False):
+        raise NotImplementedError("pivoted_cholesky is defined on the noise-free kernel operator (self.kernel_op)")

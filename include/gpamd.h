@@ -112,11 +112,20 @@ int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream);
 
 /* ---- pivoted Cholesky of the NOISE-FREE kernel matrix (LinearOperator.pivoted_cholesky; wrapper
  * gpytorch/__init__.py:146-173; consumer AddedDiagLinearOperator._preconditioner). L: float[rank][ldl]
- * (zero-filled by the caller), rank <= 128; fwork: float[n + 4]; iwork: int[2]; pivots: int64[rank].
+ * (zero-filled by the caller), rank <= 128; fwork: float[n + 4]; iwork: int[2 + 2n]; pivots: int64[rank].
  * Runs `rank` (pivot, update) steps without host synchronisation; steps after the error tolerance is
  * met are no-ops.  On completion iwork[0] = number of columns produced. ---- */
 int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
                                float* L, int64_t ldl, int64_t* pivots, float* fwork, int* iwork, void* stream);
+
+/* ---- fused bilinear derivative: out[0] = sum_ij W_ij k_ij, out[1+q] = sum_ij W_ij dk/ds_ij (z_iq - z_jq)^2,
+ * W = Lt^T Rt (never formed).  Replaces LinearOperator._bilinear_derivative on the kernel operator and the
+ * dense backward of gpytorch/functions/rbf_covariance.py:26-29 / matern_covariance.py:53-56 (chunked variant:
+ * gpytorch/lazy/lazy_evaluated_kernel_tensor.py:69-104).  out: float[1 + dp]; workspace: double[>= the query]. ---- */
+int64_t gpamd_kv_grad_workspace_doubles(int n, int m, int t, int dp);
+int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Lt, int64_t ldl,
+                      const float* Rt, int64_t ldr, int t, float* out, double* workspace, int64_t workspace_doubles,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,9 @@ Iteration-level parity with the reference is UNPINNED (no golden vectors exist);
 pinned against dense Cholesky in tests/test_oracle_bbmm.py.
 
 Layout here is the reference's: rhs is (n, c) with one right-hand side per COLUMN.
+
+``mean_residual_fn`` (not in the reference): hook that replaces ``rnorm.mean()`` in the stopping rule,
+used by the world_size-2 tests to restate the probe-sharded solve (global mean via all-reduce).
 """
 from __future__ import annotations
 
@@ -30,6 +33,7 @@ def linear_cg(
     initial_guess: torch.Tensor | None = None,
     preconditioner=None,
     return_info: bool = False,
+    mean_residual_fn=None,
 ):
     n, c = rhs.shape[-2], rhs.shape[-1]
     if preconditioner is None:
@@ -95,7 +99,7 @@ def linear_cg(
 
         if (
             k >= min_iter
-            and bool(rnorm.mean() < tolerance)
+            and bool((rnorm.mean() if mean_residual_fn is None else mean_residual_fn(rnorm)) < tolerance)
             and not (n_tridiag and k < min(n_tri_iter, max_iter - 1))
         ):
             tolerance_reached = True

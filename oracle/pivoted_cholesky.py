@@ -16,12 +16,17 @@ import math
 import torch
 
 
-def pivoted_cholesky(diag: torch.Tensor, row_fn, rank: int, error_tol: float = 1e-3, return_pivots: bool = False):
+def pivoted_cholesky(diag: torch.Tensor, row_fn, rank: int, error_tol: float = 1e-3, return_pivots: bool = False,
+                     forced_pivots=None, return_gaps: bool = False):
     """Greedy partial Cholesky of a PSD matrix given its diagonal and a row oracle.
 
     ``row_fn(p)`` returns row ``K[p, :]`` (n,).  Returns L of shape (n, m), m <= rank.
     Ties in the pivot search resolve to the lowest position in the current permutation
     (torch.max semantics on CPU), exactly as the sequential reference does.
+
+    ``forced_pivots`` (test aid): follow a given pivot sequence instead of the arg-max and, with
+    ``return_gaps``, report for each step ``max(live d) - d[forced pivot]`` so a test can assert the
+    device's choice was an arg-max up to rounding (exact ties are legion in float32).
     """
     d = diag.clone()
     n = d.shape[-1]
@@ -31,9 +36,17 @@ def pivoted_cholesky(diag: torch.Tensor, row_fn, rank: int, error_tol: float = 1
     errors = d.abs().sum() / orig_error
     perm = torch.arange(n)
     m = 0
+    gaps = []
     while m == 0 or (m < max_iter and errors > error_tol):
+        if forced_pivots is not None and m >= len(forced_pivots):
+            break
         vals = d[perm[m:]]
         j = int(torch.argmax(vals)) + m
+        if forced_pivots is not None:
+            jf = int((perm == int(forced_pivots[m])).nonzero()[0])
+            assert jf >= m, "forced pivot was already used"
+            gaps.append(float(vals[j - m] - vals[jf - m]))
+            j = jf
         maxval = vals[j - m]
         tmp = perm[m].clone()
         perm[m] = perm[j]
@@ -52,6 +65,8 @@ def pivoted_cholesky(diag: torch.Tensor, row_fn, rank: int, error_tol: float = 1
             errors = d[idx].abs().sum() / orig_error
         m += 1
     Lt = L[:m].t().contiguous()
+    if return_gaps:
+        return Lt, perm, gaps
     return (Lt, perm) if return_pivots else Lt
 
 

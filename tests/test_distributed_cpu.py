@@ -1,0 +1,93 @@
+"""CPU, world_size = 2, gloo: the probe-column sharding design is exact -- two ranks that
+each own half of the probes (+ the replicated y column), exchanging only the 2-float residual
+statistics per iteration and the scalar SLQ sums, reproduce the single-process solve bit for bit:
+same iteration count, same solutions, same log-det.  Exercises gpytorch_amd.distributed (host logic)
+with the oracle standing in for the device kernels (no GPU here)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from gpytorch_amd import distributed as D
+    from oracle import exact_gp as OG
+    from oracle import linear_cg as OCG
+    from oracle import slq as OS
+    from tests.util import make_data
+
+    group = D.init_from_env("gloo")
+    n, t_total = 300, 6
+    X, y = make_data(n, 3)
+    Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
+    Z = Z / Z.norm(dim=-2, keepdim=True)
+    mm = OG.make_matmul("rbf", X, 0.25, 1.0, 0.1)
+    a, b = D.probe_shard(t_total, world, rank)
+    t = b - a
+    rhs = torch.cat([Z[:, a:b], y.unsqueeze(-1)], dim=-1)
+
+    def mean_fn(rnorm):
+        return D.allreduce_residual_stats(rnorm.sum(), torch.tensor(float(rnorm.numel())), group)
+
+    sol, T, info = OCG.linear_cg(mm, rhs, n_tridiag=t, tolerance=0.5, return_info=True, mean_residual_fn=mean_fn)
+    ld = OS.slq_logdet(T, n) * (t / t_total)
+    D.allreduce_sum_(ld, group)
+    q.put((rank, info["iters"], sol, float(ld), (a, b)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_probe_sharding_matches_single_process():
+    sys.path.insert(0, ROOT)
+    from oracle import exact_gp as OG
+    from oracle import linear_cg as OCG
+    from oracle import slq as OS
+    from tests.util import make_data
+
+    world, port = 2, 29000 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    n, t_total = 300, 6
+    X, y = make_data(n, 3)
+    Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
+    Z = Z / Z.norm(dim=-2, keepdim=True)
+    mm = OG.make_matmul("rbf", X, 0.25, 1.0, 0.1)
+    # single process: all probes + y replicated `world` times so the global mean matches the sharded one
+    rhs = torch.cat([Z, y.unsqueeze(-1).repeat(1, world)], dim=-1)
+    sol, T, info = OCG.linear_cg(mm, rhs, n_tridiag=t_total, tolerance=0.5, return_info=True)
+    ld = OS.slq_logdet(T, n)
+    for rank, iters, s, ldr, (a, b) in results:
+        assert iters == info["iters"]
+        assert torch.allclose(s[:, : b - a], sol[:, a:b], rtol=0, atol=1e-12)
+        assert torch.allclose(s[:, -1], sol[:, t_total], rtol=0, atol=1e-12)
+        assert abs(ldr - float(ld)) < 1e-9 * abs(float(ld))
+
+
+def test_probe_shard_partition():
+    sys.path.insert(0, ROOT)
+    from gpytorch_amd.distributed import probe_shard
+
+    for t_total, world in [(64, 8), (65, 8), (7, 3), (2, 4), (256, 8)]:
+        spans = [probe_shard(t_total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == t_total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        probe_shard(4, 2, 2)
