@@ -73,7 +73,12 @@ def test_cg_iteration_parity_with_oracle(dev):
     assert torch.equal(sol[:, -1].cpu(), torch.zeros(n))
     assert rel_err(sol, ref) < 5e-3
     assert info.t_mats.shape == Tref.shape
-    assert rel_err(info.t_mats, Tref) < 5e-3
+    # Lanczos/CG coefficients are chaotic in finite precision: late rows of T differ between any two
+    # float32 implementations (summation order), the early rows and the quadrature they feed do not
+    assert rel_err(info.t_mats[:, :8, :8], Tref[:, :8, :8]) < 5e-3
+    from oracle import slq as OS
+    from gpytorch_amd.bbmm import slq_logdet
+    assert abs(float(slq_logdet(info.t_mats, n)) - float(OS.slq_logdet(Tref, n))) < 2e-3 * abs(float(OS.slq_logdet(Tref, n)))
     # and the float64 restatement agrees on the solution to the CG tolerance
     ref64 = OCG.linear_cg(OG.make_matmul(kind, X, ls, 1.0, 0.1), rhs, tolerance=1e-3, max_iter=200)
     assert rel_err(sol, ref64) < 5e-3
@@ -159,6 +164,17 @@ def test_preconditioner_matches_dense_inverse(dev):
     assert build_preconditioner(xp, sc, s2, rank=15, min_size=5000) is None
 
 
+def _probes(kind, X, ls, os_, s2, rank, t, seed=1234):
+    """Probe matrix shared by both sides: N(0, I) without a preconditioner, N(0, L L^T + s2 I) with one
+    (SURVEY.md A.5 -- the SLQ / trace estimators are only unbiased for probes with covariance P)."""
+    n = X.shape[0]
+    g = torch.Generator().manual_seed(seed)
+    if rank == 0:
+        return torch.randn(n, t, generator=g, dtype=torch.float64)
+    _, _, L = OG.make_preconditioner(kind, X, ls, os_, s2, rank, min_size=0)
+    return L @ torch.randn(L.shape[1], t, generator=g, dtype=torch.float64) + math.sqrt(s2) * torch.randn(n, t, generator=g, dtype=torch.float64)
+
+
 @pytest.mark.parametrize("precond_rank", [0, 20])
 def test_inv_quad_logdet_given_probes(precond_rank, dev):
     """Same probe matrix Z on both sides: inv_quad and SLQ log-det match the oracle to 1e-3 and
@@ -170,7 +186,7 @@ def test_inv_quad_logdet_given_probes(precond_rank, dev):
     kind, n, d, ls, t = "rbf", 2200, 3, 0.25, 32
     X, y, xp = _setup(kind, n, d, ls, dev)
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
-    Z = torch.randn(n, t, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
+    Z = _probes(kind, X, ls, 1.0, 0.1, precond_rank, t)
     pre = build_preconditioner(xp, sc, s2, rank=precond_rank, tol=1e-3, min_size=2000)
     res = inv_quad_logdet_forward(xp, sc, s2, B.to_probe_major(y.unsqueeze(-1).to(dev)), precond=pre, probes=Z, tolerance=1e-4)
     # oracle with identical probes (and, when preconditioned, the identical L via its own pivoted Cholesky)
@@ -182,3 +198,24 @@ def test_inv_quad_logdet_given_probes(precond_rank, dev):
         assert abs(float(res.logdet) - float(aux["logdet"])) < tol * abs(float(aux["logdet"]))
     _, ld_exact = OG.dense_solve_logdet(kind, X, y.unsqueeze(-1), ls, 1.0, 0.1)
     assert abs(float(res.logdet) - float(ld_exact)) < 0.05 * abs(float(ld_exact))
+
+
+def test_lanczos_properties_and_parity(dev):
+    """Device Lanczos (full re-orthogonalisation): Q orthonormal, Q K_hat Q^T = T, early T block equal to the
+    float64 restatement started from the same vector."""
+    from gpytorch_amd import backend as B
+    from gpytorch_amd.lanczos import lanczos_tridiag
+    from oracle import lanczos as OL
+
+    kind, n, d, ls, k = "matern52", 1200, 4, 0.5, 60
+    X, y, xp = _setup(kind, n, d, ls, dev)
+    sc, s2 = torch.tensor([1.2], device=dev), torch.tensor([0.1], device=dev)
+    init = torch.randn(n, 1, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    Qt, T = lanczos_tridiag(xp, sc, s2, k, B.to_probe_major(init.to(dev)))
+    Q = Qt[:, :n].double().cpu()
+    assert Q.shape[0] == k
+    assert (Q @ Q.t() - torch.eye(k, dtype=torch.float64)).abs().max() < 1e-4
+    Kh = OK.kernel_matrix(kind, X, X, ls, 1.2, x1_eq_x2=True, direct=True) + 0.1 * torch.eye(n, dtype=torch.float64)
+    assert rel_err(Q @ Kh @ Q.t(), T) < 1e-3
+    Qr, Tr = OL.lanczos_tridiag(lambda v: Kh @ v, k, n, init)
+    assert rel_err(T[:6, :6], Tr[:6, :6]) < 1e-3

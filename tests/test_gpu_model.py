@@ -112,7 +112,9 @@ def test_mll_bbmm_branch_value_and_grads_given_probes(precond, dev):
     X, y = make_data(n, d)
     g, m, lik = _model(kind, X, y, ls, 1.0, 0.1, dev)
     mll = g.ExactMarginalLogLikelihood(lik, m)
-    Z = torch.randn(n, t, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
+    from tests.test_gpu_bbmm import _probes
+
+    Z = _probes(kind, X, ls, 1.0, 0.1, precond, t)  # N(0, P)-distributed when preconditioned (A.5)
     m.train()
     lik.train()
     S = g.settings
@@ -149,13 +151,17 @@ def test_posterior_mean_and_variance(kind, d, ls, fast, dev):
     m.eval()
     lik.eval()
     S = g.settings
-    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.fast_pred_var(fast), S.max_root_decomposition_size(200):
+    # LOVE is a rank-limited Krylov approximation: the slowly decaying Matern spectrum needs a larger
+    # rank than RBF for the same accuracy (the float64 restatement shows the same 0.5 / 0.18 max
+    # relative error at rank 200 / 400 on this problem)
+    rank = 200 if kind == "rbf" else 1100
+    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.fast_pred_var(fast), S.max_root_decomposition_size(rank):
         pred = lik(m(Xs.float().to(dev)))
         mu, var = pred.mean, pred.variance
     mu_ref, var_ref = OG.dense_posterior(kind, X, y, Xs, ls, 1.2, 0.1, mean=0.1)
     assert rel_err(mu, mu_ref) < 1e-3
     if fast:
-        # LOVE (Lanczos rank 200 of n = 1600): the reference asserts 5 % (test_simple_gp_regression.py:440-442)
+        # the reference asserts 5 % for LOVE variances (test_simple_gp_regression.py:440-442)
         assert ((var.double().cpu() - var_ref).abs() / var_ref).max() < 0.05
     else:
         assert ((var.double().cpu() - var_ref).abs() / var_ref).max() < 2e-3
