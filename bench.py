@@ -144,6 +144,16 @@ def main():
     flop_per_launch = 2.0 * n * n * cols
     achieved = flop_per_launch / (kv_ms * 1e-3) / 1e12
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the
+    # figure comes from the committed rocprofv3 --pmc passes of the same kernel at the same shape
+    # (scripts/gpu_session.sh -> scripts/collect_profiles.py -> profiles/kv_pmc_current.json), else null.
+    traffic = None
+    try:
+        if (n, d, t) == (100_000, 3, 64):
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "kv_pmc_current.json"))).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
+
     flops_step_rank = flop_per_launch * (iters_total / args.steps)
     value = flops_step_rank * world * args.steps / elapsed / 1e12
 
@@ -173,7 +183,8 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
                 "kernel": "kv_mfma_kernel<RBF,DP=4,CT=2,NI=2,EX=1>",
                 "kernel_ms": kv_ms,
                 "launches_timed": len(live),

@@ -97,32 +97,21 @@ int group_cols(int t, int g0) {
 }
 
 void plan_split(int n, int m, int t, int* S, int* jchunk) {
-  // the dominant group decides the grid shape
+  // The grid is (row blocks) x (S chunks of the contracted index).  Workgroups are dispatched
+  // dynamically as slots free up, so the tail costs about one unit-time: aim for >= 6 units per
+  // resident-workgroup slot (measured optimum at n = 1e5: S = 7..12, profiles/r01_s4_kv_tune_variants.jsonl),
+  // but keep every chunk >= 16 LDS tiles so the per-unit prologue / partial-slab write stays < 1 %.
   KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t);
   const int nrb = (n + v.bm - 1) / v.bm;
-  const int slots = num_cus() * 2;  // two resident workgroups per CU (register-limited)
-  const int min_chunk = 4 * v.bn;
+  const int wg_per_cu = v.valu ? 4 : (v.ct <= 2 ? 3 : 2);
+  const long slots = (long)num_cus() * wg_per_cu;
+  const int min_chunk = 16 * v.bn;
   int smax = m / min_chunk;
-  if (smax < 1) smax = 1;
+  if (smax < 1) smax = (m >= 4 * v.bn) ? m / (4 * v.bn) : 1;  // small problems: favour parallelism
   if (smax > 64) smax = 64;
-  int best_s = 1;
-  double best_eff = -1.0;
-  for (int s = 1; s <= smax; ++s) {
-    int jc = ((m + s - 1) / s + v.bn - 1) / v.bn * v.bn;
-    int s_eff = (m + jc - 1) / jc;
-    long units = (long)nrb * s_eff;
-    long rounds = (units + slots - 1) / slots;
-    double eff = (double)units / (double)(rounds * slots);
-    if (eff > best_eff + 1e-9) {
-      best_eff = eff;
-      best_s = s;
-    }
-    if (eff >= 0.92) {
-      best_s = s;
-      break;
-    }
-  }
-  int jc = ((m + best_s - 1) / best_s + v.bn - 1) / v.bn * v.bn;
+  long want = (6 * slots + nrb - 1) / nrb;
+  int s = (int)(want < 1 ? 1 : (want > smax ? smax : want));
+  int jc = ((m + s - 1) / s + v.bn - 1) / v.bn * v.bn;
   *jchunk = jc;
   *S = (m + jc - 1) / jc;
 }

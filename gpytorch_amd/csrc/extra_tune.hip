@@ -33,12 +33,19 @@ struct VariantDesc {
   X(15, 2, 2, 1, 128, 0, 0, 1, 1, 1)     \
   X(16, 2, 2, 1, 128, 1, 0, 1, 1, 1)     \
   X(17, 2, 2, 1, 256, 0, 0, 1, 1, 1)     \
-  X(18, 2, 3, 1, 128, 0, 0, 1, 1, 1)
+  X(18, 2, 3, 1, 128, 0, 0, 1, 1, 1)     \
+  X(19, 2, 2, 1, 128, 0, 0, 2, 1, 0)     \
+  X(20, 2, 2, 1, 128, 0, 0, 3, 1, 0)     \
+  X(21, 2, 2, 1, 128, 0, 0, 2, 1, 1)     \
+  X(22, 2, 2, 1, 128, 0, 0, 3, 1, 1)     \
+  X(23, 2, 2, 1, 128, 1, 1, 0, 1, 1)     \
+  X(24, 2, 2, 1, 128, 1, 0, 0, 1, 1)     \
+  X(25, 2, 4, 1, 128, 0, 0, 3, 1, 1)
 }  // namespace
 
 extern "C" {
 
-int gpamd_kv_variant_count(void) { return 19; }
+int gpamd_kv_variant_count(void) { return 26; }
 
 int gpamd_kv_variant_info(int variant, int* bm_host, int* bn_host) {
   switch (variant) {

@@ -5,6 +5,7 @@
 namespace gpamd {
 
 // MFMA variants: CT 32-column tiles (1..4) + EX extra VALU column; NI row tiles per wave by CT.
+// NI*CT*16 accumulator registers: 64 (CT <= 2: three waves resident per SIMD) .. 128 (CT = 4: two)
 constexpr int kv_ni_for_ct(int ct) { return ct == 1 ? 4 : 2; }
 inline int kv_bm_for_ct(int ct) { return 4 * kv_ni_for_ct(ct) * 32; }
 

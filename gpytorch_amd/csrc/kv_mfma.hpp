@@ -82,47 +82,57 @@ __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
       for (int r = 0; r < 16; ++r) acc[ni][ct][r] = 0.f;
   }
 
-  // staging registers (global -> reg early, reg -> LDS after the barrier)
+  // staging: global -> registers -> LDS between the two barriers of a tile.  Measured (profiles/
+  // r01_s4_kv_tune_variants.jsonl): prefetching the next tile into registers across the MFMA phase costs
+  // ~30 VGPRs and one resident wave per SIMD; three waves/SIMD with synchronous staging is faster (+3 %).
   constexpr int VQ = TC * (BN / 4) / 256;  // float4 per thread for the V tile (= 8*CT)
+  constexpr int VCH = VQ < 8 ? VQ : 8;     // staged in chunks of <= 8 float4 (32 VGPRs) per thread
   constexpr int XQ = (BN * DQ + 255) / 256;
-  f32x4 vreg[VQ];
-  f32x4 xreg[XQ];
-  f32x4 ereg;
 
-  auto stage_load = [&](int j0) {
+  auto stage_tile = [&](int j0) {
 #pragma unroll
-    for (int r = 0; r < VQ; ++r) {
-      int idx = tid + 256 * r;
-      int c = idx / (BN / 4), q = idx % (BN / 4);
-      int j = j0 + 4 * q;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (c < a.t) {
-        const float* src = a.Vt + (int64_t)c * a.ldv + j;
-        if (j + 4 <= jend) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {
+    for (int r0 = 0; r0 < VQ; r0 += VCH) {
+      f32x4 vreg[VCH];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (j + e < jend) v[e] = src[e];
+      for (int rr = 0; rr < VCH; ++rr) {
+        const int idx = tid + 256 * (r0 + rr);
+        const int c = idx / (BN / 4), q = idx % (BN / 4);
+        const int j = j0 + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < a.t) {
+          const float* src = a.Vt + (int64_t)c * a.ldv + j;
+          if (j + 4 <= jend) {
+            v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (j + e < jend) v[e] = src[e];
+          }
         }
+        vreg[rr] = v;
       }
-      vreg[r] = v;
+#pragma unroll
+      for (int rr = 0; rr < VCH; ++rr) {
+        const int idx = tid + 256 * (r0 + rr);
+        const int c = idx / (BN / 4), q = idx % (BN / 4);
+        *reinterpret_cast<f32x4*>(&Vs[c * LDT + 4 * q]) = vreg[rr];
+      }
     }
 #pragma unroll
     for (int r = 0; r < XQ; ++r) {
-      int idx = tid + 256 * r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int idx = tid + 256 * r;
       if (idx < BN * DQ) {
-        int j = j0 + idx / DQ;
+        const int j = j0 + idx / DQ;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP + 4 * (idx % DQ));
+        *reinterpret_cast<f32x4*>(&Xs[4 * idx]) = v;
       }
-      xreg[r] = v;
     }
     if constexpr (EX) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (tid < BN / 4) {
-        int j = j0 + 4 * tid;
+        const int j = j0 + 4 * tid;
         const float* src = a.Vt + (int64_t)TC * a.ldv + j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (j + 4 <= jend) {
           v = *reinterpret_cast<const f32x4*>(src);
         } else {
@@ -130,33 +140,35 @@ __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
           for (int e = 0; e < 4; ++e)
             if (j + e < jend) v[e] = src[e];
         }
+        *reinterpret_cast<f32x4*>(&Es[4 * tid]) = v;
       }
-      ereg = v;
-    }
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int r = 0; r < VQ; ++r) {
-      int idx = tid + 256 * r;
-      int c = idx / (BN / 4), q = idx % (BN / 4);
-      *reinterpret_cast<f32x4*>(&Vs[c * LDT + 4 * q]) = vreg[r];
-    }
-#pragma unroll
-    for (int r = 0; r < XQ; ++r) {
-      int idx = tid + 256 * r;
-      if (idx < BN * DQ) *reinterpret_cast<f32x4*>(&Xs[4 * idx]) = xreg[r];
-    }
-    if constexpr (EX) {
-      if (tid < BN / 4) *reinterpret_cast<f32x4*>(&Es[4 * tid]) = ereg;
     }
   };
 
-  if (jbeg < jend) stage_load(jbeg);
+  auto keval = [&](const float (&x)[DP], int jrow) -> float {
+    float sq = 0.f;
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Xs[jrow * DP + 4 * q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float df = x[4 * q + e] - v[e];
+        sq = __builtin_fmaf(df, df, sq);
+      }
+    }
+    return cov_from_sq<KIND>(sq);
+  };
+
   for (int j0 = jbeg; j0 < jend; j0 += BN) {
     __syncthreads();  // previous tile fully consumed
-    stage_write();
+    stage_tile(j0);
     __syncthreads();
-    if (j0 + BN < jend) stage_load(j0 + BN);  // in flight during the MFMA phase below
+
+    // K elements are generated one MFMA step ahead (software pipeline) so the VALU chain of step s+1
+    // issues in the shadow of the 4 x 64-cycle MFMAs of step s
+    float kvn[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) kvn[ni] = keval(xi[ni], 4 * h);
 
 #pragma unroll 2
     for (int g = 0; g < BN / 8; ++g) {
@@ -168,23 +180,14 @@ __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
       if constexpr (EX) ev = *reinterpret_cast<const f32x4*>(&Es[jl]);
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        float xj[DP];
-#pragma unroll
-        for (int q = 0; q < DQ; ++q) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(&Xs[(jl + st) * DP + 4 * q]);
-          xj[4 * q + 0] = v[0]; xj[4 * q + 1] = v[1]; xj[4 * q + 2] = v[2]; xj[4 * q + 3] = v[3];
-        }
         float kv[NI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          float sq = 0.f;
+        for (int ni = 0; ni < NI; ++ni) kv[ni] = kvn[ni];
+        // next step's row (wraps harmlessly to the tile start after the last step)
+        const int jn = ((st == 3) ? (8 * (g + 1) + 4 * h) : (jl + st + 1)) & (BN - 1);
 #pragma unroll
-          for (int k = 0; k < DP; ++k) {
-            float df = xi[ni][k] - xj[k];
-            sq = __builtin_fmaf(df, df, sq);
-          }
-          kv[ni] = cov_from_sq<KIND>(sq);
-        }
+        for (int ni = 0; ni < NI; ++ni) kvn[ni] = keval(xi[ni], jn);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
             acc[ni][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct][st], kv[ni], acc[ni][ct], 0, 0, 0);
           if constexpr (EX) eacc[ni] = __builtin_fmaf(kv[ni], ev[st], eacc[ni]);
         }
+        __builtin_amdgcn_s_setprio(0);
       }
     }
   }

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, MINW) void kv_mfma_tune_kernel(KvArgs a) {
   for (int ni = 0; ni < NI; ++ni) {
     int i = min(ibase + ni * 32 + l31, a.n - 1);
     f32x4 v = *reinterpret_cast<const f32x4*>(a.X1 + (int64_t)i * DP);
-    if constexpr (GRAM) {
+    if constexpr (GRAM == 1) {
       // s = |xi|^2 + dot4([xi, 1], [-2 xj, |xj|^2]); slot 3 of xi holds |xi|^2 (used as the fma seed)
       xi[ni][0] = v[0]; xi[ni][1] = v[1]; xi[ni][2] = v[2];
       xi[ni][3] = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, MINW) void kv_mfma_tune_kernel(KvArgs a) {
       if (idx < BN) {
         int j = j0 + idx;
         if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP);
-        if constexpr (GRAM) {
+        if constexpr (GRAM == 1) {
           float nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
           v[0] *= -2.f; v[1] *= -2.f; v[2] *= -2.f; v[3] = nn;
         }
@@ -127,7 +127,11 @@ __global__ __launch_bounds__(256, MINW) void kv_mfma_tune_kernel(KvArgs a) {
   };
 
   auto keval = [&](const float (&x)[DP], const f32x4& xj) -> float {
-    if constexpr (GRAM) {
+    if constexpr (GRAM == 2) {  // ablation: no kernel generation (one dependent VALU op)
+      return x[0] + xj[0];
+    } else if constexpr (GRAM == 3) {  // ablation: no generation, no use of x_j
+      return x[0];
+    } else if constexpr (GRAM == 1) {
       float sq = __builtin_fmaf(x[0], xj[0], x[3]);
       sq = __builtin_fmaf(x[1], xj[1], sq);
       sq = __builtin_fmaf(x[2], xj[2], sq);

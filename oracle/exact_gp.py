@@ -114,12 +114,20 @@ def make_preconditioner(kind, X, ls, os_, s2, rank, error_tol=1e-3, min_size=200
 def bbmm_mll(
     kind, X, y, ls, os_, s2, mean=0.0, num_probes=10, precond_rank=15, min_precond_size=2000,
     cg_tol=1.0, max_cg_iter=1000, max_lanczos_iter=20, probes=None, seed=1234, dense=True, return_aux=False,
+    precond_L=None,
 ):
     """MLL through mBCG + SLQ.  ``probes``: optional pre-drawn (n, t) UN-normalised probe matrix
-    (so GPU and CPU runs can share Z); otherwise drawn per A.5 with ``seed``."""
+    (so GPU and CPU runs can share Z); otherwise drawn per A.5 with ``seed``.
+    ``precond_L``: optional (n, k) pivoted-Cholesky factor to build the preconditioner from (test aid:
+    float32 ties make the pivot sequence implementation-dependent, and the SLQ / trace estimators
+    are only unbiased when the probes' covariance is the preconditioner actually applied)."""
     n = X.shape[-2]
     mm = make_matmul(kind, X, ls, os_, s2, dense)
-    papply, plogdet, L = make_preconditioner(kind, X, ls, os_, s2, precond_rank, min_size=min_precond_size)
+    if precond_L is not None:
+        L = precond_L.to(X.dtype)
+        papply, plogdet, _ = build_preconditioner(L, float(s2))
+    else:
+        papply, plogdet, L = make_preconditioner(kind, X, ls, os_, s2, precond_rank, min_size=min_precond_size)
     if probes is None:
         g = torch.Generator().manual_seed(seed)
         Z, Znorm = probe_vectors(n, num_probes, L, float(s2), g, X.dtype)

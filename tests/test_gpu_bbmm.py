@@ -164,14 +164,13 @@ def test_preconditioner_matches_dense_inverse(dev):
     assert build_preconditioner(xp, sc, s2, rank=15, min_size=5000) is None
 
 
-def _probes(kind, X, ls, os_, s2, rank, t, seed=1234):
+def _probes(n, t, L, s2, seed=1234):
     """Probe matrix shared by both sides: N(0, I) without a preconditioner, N(0, L L^T + s2 I) with one
-    (SURVEY.md A.5 -- the SLQ / trace estimators are only unbiased for probes with covariance P)."""
-    n = X.shape[0]
+    (SURVEY.md A.5 -- the SLQ / trace estimators are only unbiased for probes whose covariance is the
+    preconditioner actually applied, so L is the DEVICE's pivoted-Cholesky factor)."""
     g = torch.Generator().manual_seed(seed)
-    if rank == 0:
+    if L is None:
         return torch.randn(n, t, generator=g, dtype=torch.float64)
-    _, _, L = OG.make_preconditioner(kind, X, ls, os_, s2, rank, min_size=0)
     return L @ torch.randn(L.shape[1], t, generator=g, dtype=torch.float64) + math.sqrt(s2) * torch.randn(n, t, generator=g, dtype=torch.float64)
 
 
@@ -186,14 +185,15 @@ def test_inv_quad_logdet_given_probes(precond_rank, dev):
     kind, n, d, ls, t = "rbf", 2200, 3, 0.25, 32
     X, y, xp = _setup(kind, n, d, ls, dev)
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
-    Z = _probes(kind, X, ls, 1.0, 0.1, precond_rank, t)
     pre = build_preconditioner(xp, sc, s2, rank=precond_rank, tol=1e-3, min_size=2000)
+    Ldev = None if pre is None else pre.lt[:, :n].t().double().cpu()
+    Z = _probes(n, t, Ldev, 0.1)
     res = inv_quad_logdet_forward(xp, sc, s2, B.to_probe_major(y.unsqueeze(-1).to(dev)), precond=pre, probes=Z, tolerance=1e-4)
     # oracle with identical probes (and, when preconditioned, the identical L via its own pivoted Cholesky)
     # float32 restatement (what the reference executes for float32 inputs): rtol 1e-3; float64: 3e-3
     for dt, tol in ((torch.float32, 1e-3), (torch.float64, 3e-3)):
         mll, aux = OG.bbmm_mll(kind, X.to(dt), y.to(dt), ls, 1.0, 0.1, precond_rank=precond_rank, min_precond_size=2000,
-                               cg_tol=1e-4, probes=Z.to(dt), return_aux=True)
+                               cg_tol=1e-4, probes=Z.to(dt), return_aux=True, precond_L=Ldev)
         assert abs(float(res.inv_quad.sum()) - float(aux["inv_quad"])) < tol * abs(float(aux["inv_quad"]))
         assert abs(float(res.logdet) - float(aux["logdet"])) < tol * abs(float(aux["logdet"]))
     _, ld_exact = OG.dense_solve_logdet(kind, X, y.unsqueeze(-1), ls, 1.0, 0.1)

@@ -112,9 +112,16 @@ def test_mll_bbmm_branch_value_and_grads_given_probes(precond, dev):
     X, y = make_data(n, d)
     g, m, lik = _model(kind, X, y, ls, 1.0, 0.1, dev)
     mll = g.ExactMarginalLogLikelihood(lik, m)
+    from gpytorch_amd import backend as B
+    from gpytorch_amd.bbmm import build_preconditioner
     from tests.test_gpu_bbmm import _probes
 
-    Z = _probes(kind, X, ls, 1.0, 0.1, precond, t)  # N(0, P)-distributed when preconditioned (A.5)
+    # the preconditioner the MLL will build internally (deterministic): draw the shared probes from N(0, P)
+    xp = B.prep_points(kind, m.train_inputs[0], m.covar_module.base_kernel.lengthscale.detach())
+    pre = build_preconditioner(xp, m.covar_module.outputscale.detach().reshape(1), lik.noise.detach().reshape(1),
+                               rank=precond, tol=1e-3, min_size=2000)
+    Ldev = None if pre is None else pre.lt[:, :n].t().double().cpu()
+    Z = _probes(n, t, Ldev, 0.1)
     m.train()
     lik.train()
     S = g.settings
@@ -128,7 +135,7 @@ def test_mll_bbmm_branch_value_and_grads_given_probes(precond, dev):
         S.deterministic_probes.probe_vectors = None
     # float32 restatement with identical probes
     ref, aux = OG.bbmm_mll(kind, X.float(), y.float(), ls, 1.0, 0.1, precond_rank=precond, min_precond_size=2000, cg_tol=1e-4,
-                           probes=Z.float(), return_aux=True)
+                           probes=Z.float(), return_aux=True, precond_L=Ldev)
     assert abs(float(val) - float(ref)) < 1e-3 * max(1.0, abs(float(ref)))
     gref = OG.bbmm_mll_grads(kind, X.float(), aux, ls, 1.0, 0.1)  # A.6 backward on the oracle's own solves
     c = _chain(ls, 1.0, 0.1)
