@@ -103,9 +103,10 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     rhs_t = B.to_probe_major(yd.unsqueeze(-1))
     t_total = t * world
+    shift = Xd.mean(dim=0)
 
     def step():
-        xp = B.prep_points("rbf", Xd, lengthscale)
+        xp = B.prep_points("rbf", Xd, lengthscale, shift)  # centred, as RBFKernel.forward does
         res = inv_quad_logdet_forward(
             xp, outputscale, noise, rhs_t, num_probes=t, precond=None, generator=gen, group=group, t_total=t_total
         )

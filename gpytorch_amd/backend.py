@@ -42,13 +42,35 @@ def padded_dim(d: int) -> int:
     return round_up(d, 4)
 
 
+KV_GRAM = 1              # flag of gpamd_kv_partials_f32 (include/gpamd.h)
+GRAM_MAX_SQNORM = 32.0   # max |z|^2 for which the quadratic expansion keeps K within 1e-5 (kv_gram.hpp)
+FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or KV_GRAM regardless of |z|
+
+
 class PreparedPoints:
     """A point cloud converted for the fused kernels: float32 [n, dp], scaled by 1/lengthscale."""
 
-    __slots__ = ("xp", "n", "d", "dp", "kind")
+    __slots__ = ("xp", "n", "d", "dp", "kind", "_zmax2")
 
     def __init__(self, xp, n, d, dp, kind):
         self.xp, self.n, self.d, self.dp, self.kind = xp, n, d, dp, kind
+        self._zmax2 = None
+
+    @property
+    def zmax2(self) -> float:
+        """max_i |z_i|^2 of the prepared (scaled, centred) points; one device reduction + sync, cached."""
+        if self._zmax2 is None:
+            self._zmax2 = float(self.xp.pow(2).sum(-1).max().item())
+        return self._zmax2
+
+
+def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
+    """Select the Gram-form generation kernel when it is both applicable and accurate (see kv_gram.hpp)."""
+    if FORCE_KV_FLAGS is not None:
+        return FORCE_KV_FLAGS
+    if t <= 8 or x1.kind == "matern12":
+        return 0
+    return KV_GRAM if max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) <= GRAM_MAX_SQNORM else 0
 
 
 def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: torch.Tensor | None = None) -> PreparedPoints:
@@ -120,7 +142,8 @@ def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dsc
     L = lib()
     check(
         L.gpamd_kv_partials_f32(
-            KIND_IDS[x1.kind], _ptr(x1.xp), n, _ptr(x2.xp), m, x1.dp, _ptr(vt), ldv, t, _ptr(ws), ldo, S, jc, None, st
+            KIND_IDS[x1.kind], _ptr(x1.xp), n, _ptr(x2.xp), m, x1.d, _ptr(vt), ldv, t, _ptr(ws), ldo, S, jc,
+            kv_flags(x1, x2, t), None, st
         ),
         "kv_partials",
     )

@@ -125,6 +125,14 @@ int launch_family_mfma(int kind, int dp, int ct, int ex, const KvArgs& a, unsign
   }
   return -2;
 }
+int launch_family_gram(int kind, int dp, int ct, int ex, const KvArgs& a, unsigned grid, hipStream_t st) {
+  switch (kind) {
+    case GPAMD_RBF: return launch_kv_gram_rbf(dp, ct, ex, a, grid, st);
+    case GPAMD_MATERN32: return launch_kv_gram_matern32(dp, ct, ex, a, grid, st);
+    case GPAMD_MATERN52: return launch_kv_gram_matern52(dp, ct, ex, a, grid, st);
+  }
+  return -2;
+}
 int launch_family_valu(int kind, int dp, int tpad, const KvArgs& a, unsigned grid, hipStream_t st) {
   switch (kind) {
     case GPAMD_RBF: return launch_kv_valu_rbf(dp, tpad, a, grid, st);
@@ -171,12 +179,15 @@ int gpamd_kv_plan(int n, int m, int t, int64_t ldo, int* S_host, int* jchunk_hos
   return 0;
 }
 
-int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Vt,
-                          int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, const int* done,
+int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt,
+                          int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream) {
   if (kind < 0 || kind > 3) return fail(GPAMD_EINVAL, "kv: unknown kind");
   if (n <= 0 || m <= 0 || t <= 0 || S <= 0) return fail(GPAMD_EINVAL, "kv: bad shape");
-  if (dp != 4 && dp != 8 && dp != 12 && dp != 16) return fail(GPAMD_EUNSUPPORTED, "kv: padded input dim must be 4, 8, 12 or 16 (d <= 16)");
+  if (d < 1 || d > 16) return fail(GPAMD_EUNSUPPORTED, "kv: input dimension must be in 1..16");
+  // kernels are instantiated for D in {1,2,3,4,5,6,8,10,12,16} valid dimensions; other d use the next one
+  // (same padded stride, the extra coordinates are the zeros written by prep_points)
+  const int dp = d <= 6 ? d : (d <= 8 ? 8 : (d <= 10 ? 10 : (d <= 12 ? 12 : 16)));
   if (ldv % 4 || ldv < m || ldo < n) return fail(GPAMD_EINVAL, "kv: leading dimensions must be >= extent and ldv % 4 == 0");
   if (!aligned16(Vt) || !aligned16(X1p) || !aligned16(X2p)) return fail(GPAMD_EINVAL, "kv: buffers must be 16-byte aligned");
   if (jchunk % 4 || (int64_t)jchunk * S < m) return fail(GPAMD_EINVAL, "kv: jchunk*S must cover m and jchunk % 4 == 0");
@@ -194,7 +205,9 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
-    int rc = v.valu ? launch_family_valu(kind, dp, v.tpad, a, grid, st) : launch_family_mfma(kind, dp, v.ct, v.ex, a, grid, st);
+    const bool gram = (flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12 && !v.valu;
+    int rc = v.valu ? launch_family_valu(kind, dp, v.tpad, a, grid, st)
+                    : (gram ? launch_family_gram(kind, dp, v.ct, v.ex, a, grid, st) : launch_family_mfma(kind, dp, v.ct, v.ex, a, grid, st));
     if (rc) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
     rc = check_launch("kv_partials");
     if (rc) return rc;
@@ -213,15 +226,15 @@ int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const 
   return check_launch("kv_reduce");
 }
 
-int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Vt, int64_t ldv,
+int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt, int64_t ldv,
                  int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
-                 int64_t ldo, float* workspace, int64_t workspace_floats, void* stream) {
+                 int64_t ldo, float* workspace, int64_t workspace_floats, int flags, void* stream) {
   int S, jc;
   if (n <= 0 || m <= 0 || t <= 0) return fail(GPAMD_EINVAL, "kv: bad shape");
   plan_split(n, m, t, &S, &jc);
   const int64_t ldp = (n + 3) / 4 * 4;
   if (workspace_floats < (int64_t)S * t * ldp) return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4))");
-  int rc = gpamd_kv_partials_f32(kind, X1p, n, X2p, m, dp, Vt, ldv, t, workspace, ldp, S, jc, nullptr, stream);
+  int rc = gpamd_kv_partials_f32(kind, X1p, n, X2p, m, d, Vt, ldv, t, workspace, ldp, S, jc, flags, nullptr, stream);
   if (rc) return rc;
   return gpamd_kv_reduce_f32(workspace, S, ldp, t, n, scale, dscale, Vd, ldd, Out, ldo, nullptr, stream);
 }

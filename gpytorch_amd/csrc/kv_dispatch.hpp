@@ -11,6 +11,7 @@ inline int kv_bm_for_ct(int ct) { return 4 * kv_ni_for_ct(ct) * 32; }
 
 #define GPAMD_DECL_FAMILY(NAME)                                                                          \
   int launch_kv_mfma_##NAME(int dp, int ct, int ex, const KvArgs& a, unsigned grid, hipStream_t stream); \
+  int launch_kv_gram_##NAME(int dp, int ct, int ex, const KvArgs& a, unsigned grid, hipStream_t stream); \
   int launch_kv_valu_##NAME(int dp, int tpad, const KvArgs& a, unsigned grid, hipStream_t stream);
 GPAMD_DECL_FAMILY(rbf)
 GPAMD_DECL_FAMILY(matern12)

@@ -1,0 +1,224 @@
+// Fused K*V with the squared-distance tile ALSO generated on the matrix pipe ("Gram form").
+//
+// Same contract, layout and work decomposition as kv_mfma.hpp.  Difference: instead of every lane
+// evaluating |z_i - z_j|^2 with 2*D VALU ops per pair, a 32x32 block of squared distances is produced
+// by KA = ceil((D+2)/2) extra MFMAs from augmented coordinates -- exactly the quadratic expansion of the
+// reference's sq_dist (gpytorch/kernels/kernel.py:26-49:  [-2x, |x|^2, 1] . [x', 1, |x'|^2]^T ):
+//     S[j][i] = sum_k Aaug[j][k] * Baug[k][i],   Aaug[j] = [z_j, |z_j|^2, 1, 0..],  Baug[:,i] = [-2 z_i, 1, |z_i|^2, 0..]
+// The MFMA D layout hands lane (h, i) the 16 values S[(r&3)+8(r>>2)+4h][i], r = 0..15 -- which is precisely
+// the set of K elements that lane must feed as the B operand of the 16 contraction steps of that 32-row
+// j block (step r pairs rows (r&3)+8(r>>2) and +4), so NO cross-lane movement is needed: the VALU only
+// applies k = f(max(S,0)) (one v_exp_f32 for RBF) in place.  VALU work per K element drops from
+// 2D+1 (+1) to 2 (+1) instructions; cost: KA extra MFMAs per 16*CT useful ones (9 % at D=3, CT=2).
+//
+// Numerics: S carries the cancellation error of the quadratic expansion, <= ~8 eps * (|z_i|+|z_j|)^2 in
+// fp32 (the reference's fp32 path has the same error; it mean-centres for this reason).  The host only
+// selects this kernel when max |z|^2 (after centring) <= 32, i.e. a relative error <= 1e-5 in K, and never
+// for Matern nu = 1/2 (k = exp(-sqrt(s)) is not Lipschitz in s at 0).  Otherwise kv_mfma.hpp is used.
+#pragma once
+#include "kv_mfma.hpp"
+
+namespace gpamd {
+
+template <int KIND, int D, int CT, int NI, int EX>
+__global__ __launch_bounds__(256) void kv_gram_kernel(KvArgs a) {
+  constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
+  constexpr int KA = (D + 2 + 1) / 2;   // MFMA k-steps (2 augmented coordinates each)
+  constexpr int LDA = 2 * KA + 1;       // odd LDS row stride of the augmented x_j tile -> conflict-free b32 reads
+  constexpr int BN = KV_BN, LDT = KV_LDT, TC = 32 * CT;
+  __shared__ __attribute__((aligned(16))) float smem[TC * LDT + BN * LDA + BN + 3];
+  float* Vs = smem;
+  float* Es = smem + TC * LDT;          // 16-B aligned (TC*LDT*4 is a multiple of 16)
+  float* Xa = Es + BN;
+
+  if (a.done && *a.done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int unit = blockIdx.x;
+  const int s = unit / a.nrb, rb = unit - s * a.nrb;
+  const int jbeg = s * a.jchunk;
+  const int jend = min(a.m, jbeg + a.jchunk);
+  const int ibase = rb * (4 * NI * 32) + wave * (NI * 32);
+
+  // B operand of the Gram MFMAs: Baug[k = 2q + h][i]
+  float bq[NI][KA];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int i = min(ibase + ni * 32 + l31, a.n - 1);
+    float z[DP];
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.X1 + (int64_t)i * DP + 4 * q);
+      z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
+    }
+    float nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) nn = __builtin_fmaf(z[k], z[k], nn);
+#pragma unroll
+    for (int q = 0; q < KA; ++q) {
+      float v0, v1;  // rows 2q, 2q+1 of Baug
+      {
+        const int k0 = 2 * q, k1 = 2 * q + 1;
+        v0 = (k0 < D) ? -2.f * z[k0 < D ? k0 : 0] : (k0 == D ? 1.f : (k0 == D + 1 ? nn : 0.f));
+        v1 = (k1 < D) ? -2.f * z[k1 < D ? k1 : 0] : (k1 == D ? 1.f : (k1 == D + 1 ? nn : 0.f));
+      }
+      bq[ni][q] = h ? v1 : v0;
+    }
+  }
+
+  f32x16 acc[NI][CT];
+  float eacc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    eacc[ni] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][ct][r] = 0.f;
+  }
+
+  constexpr int VQ = TC * (BN / 4) / 256;
+  constexpr int VCH = VQ < 8 ? VQ : 8;
+
+  auto stage_tile = [&](int j0) {
+#pragma unroll
+    for (int r0 = 0; r0 < VQ; r0 += VCH) {
+      f32x4 vreg[VCH];
+#pragma unroll
+      for (int rr = 0; rr < VCH; ++rr) {
+        const int idx = tid + 256 * (r0 + rr);
+        const int c = idx / (BN / 4), q = idx % (BN / 4);
+        const int j = j0 + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + rr < VQ && c < a.t) {
+          const float* src = a.Vt + (int64_t)c * a.ldv + j;
+          if (j + 4 <= jend) {
+            v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (j + e < jend) v[e] = src[e];
+          }
+        }
+        vreg[rr] = v;
+      }
+#pragma unroll
+      for (int rr = 0; rr < VCH; ++rr) {
+        const int idx = tid + 256 * (r0 + rr);
+        const int c = idx / (BN / 4), q = idx % (BN / 4);
+        if (r0 + rr < VQ) *reinterpret_cast<f32x4*>(&Vs[c * LDT + 4 * q]) = vreg[rr];
+      }
+    }
+    // augmented x_j rows: [z_j (D), |z_j|^2, 1, 0-pad]   (rows beyond jend: all zero -> S = |z_i|^2, k finite;
+    // their V entries are zero so they contribute nothing)
+    if (tid < BN) {
+      const int j = j0 + tid;
+      float z[DP];
+#pragma unroll
+      for (int q = 0; q < DQ; ++q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP + 4 * q);
+        z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
+      }
+      float nn = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) nn = __builtin_fmaf(z[k], z[k], nn);
+#pragma unroll
+      for (int k = 0; k < 2 * KA; ++k) {
+        float v = (k < D) ? z[k < D ? k : 0] : (k == D ? nn : (k == D + 1 ? (j < jend ? 1.f : 0.f) : 0.f));
+        Xa[tid * LDA + k] = v;
+      }
+    }
+    if constexpr (EX) {
+      if (tid < BN / 4) {
+        const int j = j0 + 4 * tid;
+        const float* src = a.Vt + (int64_t)TC * a.ldv + j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j + 4 <= jend) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j + e < jend) v[e] = src[e];
+        }
+        *reinterpret_cast<f32x4*>(&Es[4 * tid]) = v;
+      }
+    }
+  };
+
+  for (int j0 = jbeg; j0 < jend; j0 += BN) {
+    __syncthreads();
+    stage_tile(j0);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int jb = 0; jb < BN; jb += 32) {
+      // ---- squared distances of the 32 x (NI*32) block on the matrix pipe, then k = f(S) in place ----
+      f32x16 kk[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kk[ni][r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < KA; ++q) {
+        const float aq = Xa[(jb + l31) * LDA + 2 * q + h];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) kk[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, bq[ni][q], kk[ni], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // RBF: a slightly negative S (cancellation) only makes k = 2^-S exceed 1 by <= 1e-5 -- no clamp needed;
+          // Matern takes sqrt(S): clamp with one v_med3_f32
+          float sv = kk[ni][r];
+          if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
+          kk[ni][r] = cov_from_sq<KIND>(sv);
+        }
+
+      // ---- contraction: 16 steps (4 groups of 4), step r pairs rows (r&3)+8(r>>2) and +4 ----
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int jl = jb + 8 * g + 4 * h;
+        f32x4 av[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(&Vs[(ct * 32 + l31) * LDT + jl]);
+        f32x4 ev;
+        if constexpr (EX) ev = *reinterpret_cast<const f32x4*>(&Es[jl]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+              acc[ni][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct][st], kk[ni][4 * g + st], acc[ni][ct], 0, 0, 0);
+            if constexpr (EX) eacc[ni] = __builtin_fmaf(kk[ni][4 * g + st], ev[st], eacc[ni]);
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+
+  float* Pout = a.P + (int64_t)s * a.pstride;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int i = ibase + ni * 32 + l31;
+    if (i < a.n) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (c < a.t) Pout[(int64_t)c * a.ldo + i] = acc[ni][ct][r];
+        }
+    }
+    if constexpr (EX) {
+      float tot = eacc[ni] + __shfl_xor(eacc[ni], 32, 64);
+      if (h == 0 && i < a.n) Pout[(int64_t)TC * a.ldo + i] = tot;
+    }
+  }
+}
+
+}  // namespace gpamd

@@ -40,8 +40,9 @@ struct KvArgs {
 constexpr int KV_BN = 128;           // j-tile staged in LDS per iteration
 constexpr int KV_LDT = KV_BN + 4;    // padded LDS row (keeps 16-B alignment, conflict-free b128 reads)
 
-template <int KIND, int DP, int CT, int NI, int EX>
+template <int KIND, int D, int CT, int NI, int EX>
 __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
+  constexpr int DP = (D + 3) / 4 * 4;  // storage stride; only the D valid dimensions are evaluated
   constexpr int BN = KV_BN, LDT = KV_LDT, TC = 32 * CT;
   constexpr int DQ = DP / 4;
   __shared__ __attribute__((aligned(16))) float smem[TC * LDT + BN * DP + BN];
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
         const int c = idx / (BN / 4), q = idx % (BN / 4);
         const int j = j0 + 4 * q;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c < a.t) {
+        if (r0 + rr < VQ && c < a.t) {
           const float* src = a.Vt + (int64_t)c * a.ldv + j;
           if (j + 4 <= jend) {
             v = *reinterpret_cast<const f32x4*>(src);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
       for (int rr = 0; rr < VCH; ++rr) {
         const int idx = tid + 256 * (r0 + rr);
         const int c = idx / (BN / 4), q = idx % (BN / 4);
-        *reinterpret_cast<f32x4*>(&Vs[c * LDT + 4 * q]) = vreg[rr];
+        if (r0 + rr < VQ) *reinterpret_cast<f32x4*>(&Vs[c * LDT + 4 * q]) = vreg[rr];
       }
     }
 #pragma unroll
@@ -146,14 +147,16 @@ __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
   };
 
   auto keval = [&](const float (&x)[DP], int jrow) -> float {
-    float sq = 0.f;
+    float sq;
 #pragma unroll
     for (int q = 0; q < DQ; ++q) {
       f32x4 v = *reinterpret_cast<const f32x4*>(&Xs[jrow * DP + 4 * q]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float df = x[4 * q + e] - v[e];
-        sq = __builtin_fmaf(df, df, sq);
+        if (4 * q + e < D) {
+          float df = x[4 * q + e] - v[e];
+          sq = (4 * q + e == 0) ? df * df : __builtin_fmaf(df, df, sq);
+        }
       }
     }
     return cov_from_sq<KIND>(sq);

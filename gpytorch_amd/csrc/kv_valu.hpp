@@ -18,8 +18,9 @@ constexpr int KVV_BN = 256;   // j-tile
 constexpr int KVV_RPT = 2;    // rows per thread
 constexpr int KVV_BM = 256 * KVV_RPT;
 
-template <int KIND, int DP, int T>
+template <int KIND, int D, int T>
 __global__ __launch_bounds__(256) void kv_valu_kernel(KvArgs a) {
+  constexpr int DP = (D + 3) / 4 * 4;
   constexpr int BN = KVV_BN, RPT = KVV_RPT, DQ = DP / 4;
   __shared__ __attribute__((aligned(16))) float Xs[BN * DP];
   __shared__ __attribute__((aligned(16))) float Vs[BN * T];
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void kv_valu_kernel(KvArgs a) {
       for (int r = 0; r < RPT; ++r) {
         float sq = 0.f;
 #pragma unroll
-        for (int k = 0; k < DP; ++k) {
+        for (int k = 0; k < D; ++k) {
           float df = xi[r][k] - xj[k];
           sq = __builtin_fmaf(df, df, sq);
         }

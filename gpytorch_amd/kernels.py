@@ -97,7 +97,9 @@ class _StationaryFused(Kernel):
     kind = None
 
     def _shift(self, x1):
-        return None
+        # stationary kernel: any common shift is exact; centring keeps |z| small, which the Gram-form
+        # generation kernel needs (the reference's sq_dist centres for the same reason, kernel.py:29-30)
+        return x1.detach().mean(dim=-2)
 
     def forward(self, x1, x2, diag=False, **params):
         if x1.shape[-1] > B.MAX_INPUT_DIM:

@@ -155,6 +155,7 @@ def linear_cg(
         S, jc, wsn = B.kv_plan(n, n, t, ld)
         P = B.workspace(dev, wsn)
         kind_id = B.KIND_IDS[x.kind]
+        flags = B.kv_flags(x, x, t)
         min_iter = min(10, max_iter - 1)
         tri_floor = min(n_tri_iter, max_iter - 1) if n_tridiag else 0
         first_poll = max(min_iter, tri_floor)
@@ -169,8 +170,8 @@ def linear_cg(
             if kv_partials is None:
                 check(
                     L.gpamd_kv_partials_f32(
-                        kind_id, B._ptr(x.xp), n, B._ptr(x.xp), n, x.dp, B._ptr(Dt), ld, t, B._ptr(P), ld, S, jc,
-                        done_ptr, st,
+                        kind_id, B._ptr(x.xp), n, B._ptr(x.xp), n, x.d, B._ptr(Dt), ld, t, B._ptr(P), ld, S, jc,
+                        flags, done_ptr, st,
                     ),
                     "kv_partials",
                 )

@@ -31,6 +31,12 @@ enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3
 
 enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 
+/* kv flags.  GPAMD_KV_GRAM: the caller asserts max |z|^2 <= 32 over both prepared clouds (after centring), so
+ * the squared distances may be formed by the quadratic expansion on the matrix pipe (kv_gram.hpp; the expansion
+ * the reference itself uses, gpytorch/kernels/kernel.py:26-49) with <= 1e-5 relative error in K.  Ignored for
+ * Matern nu = 1/2 and for t <= 8. */
+enum { GPAMD_KV_GRAM = 1 };
+
 int gpamd_abi_version(void);
 const char* gpamd_last_error(void);
 
@@ -47,9 +53,10 @@ int gpamd_kv_plan(int n, int m, int t, int64_t ldo, int* S_host, int* jchunk_hos
 /* P[s] = k(X1p, X2p[chunk s]) * Vt[:, chunk s]  for s < S -- the matrix-free K @ V of
  * KernelLinearOperator._matmul (gpytorch/kernels/keops/rbf_kernel.py:44-55) and
  * LazyEvaluatedKernelTensor._matmul (gpytorch/lazy/lazy_evaluated_kernel_tensor.py:245-275).
+ * d: input dimension (1..16; the prepared clouds have stride dp = 4*ceil(d/4)).
  * P: float[S][t][ldo].  done: optional device int; non-zero turns the launch into a no-op. */
-int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Vt,
-                          int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, const int* done,
+int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt,
+                          int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream);
 
 /* Out = scale * sum_s P[s] + dscale * Vd  (scale/dscale device scalars, NULL = 1 / 0; Vd may be NULL):
@@ -59,9 +66,9 @@ int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const 
                         const float* Vd, int64_t ldd, float* Out, int64_t ldo, const int* done, void* stream);
 
 /* One-call  Out = scale * K(X1p, X2p) Vt + dscale * Vd  using caller workspace (>= plan's workspace_floats). */
-int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Vt, int64_t ldv,
+int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt, int64_t ldv,
                  int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
-                 int64_t ldo, float* workspace, int64_t workspace_floats, void* stream);
+                 int64_t ldo, float* workspace, int64_t workspace_floats, int flags, void* stream);
 
 /* Explicit entries (LinearOperator._getitem / _diagonal / to_dense on a kernel operator):
  * rows: out[r][j] = scale*k(X1p[rows[r]], X2p[j]);  dense: out[i][j] (row-major, ldo);  diag: out[i]. */

@@ -106,6 +106,8 @@ def test_golden_kernel_values(dev):
     ],
 )
 def test_kv_matches_oracle(kind, n, m, d, t, dev):
+    """Both generation paths: direct differences (kv_mfma.hpp / kv_valu.hpp) and, for t > 8 and nu != 1/2,
+    the Gram form on the matrix pipe (kv_gram.hpp; tolerance 5e-5: quadratic-expansion cancellation)."""
     from gpytorch_amd import backend as B
 
     if kind != "rbf" and (t in (3, 8, 70, 128, 129, 140)):
@@ -115,12 +117,41 @@ def test_kv_matches_oracle(kind, n, m, d, t, dev):
     X2 = torch.rand(m, d, generator=g, dtype=torch.float64)
     V = torch.randn(m, t, generator=g, dtype=torch.float64)  # asymmetric, full-range
     ls = 0.2 + 0.08 * d
-    p1, p2 = _prep(kind, X1, ls, dev), _prep(kind, X2, ls, dev)
+    shift = X1.mean(0).float().to(dev)
+    p1, p2 = _prep(kind, X1, ls, dev, shift), _prep(kind, X2, ls, dev, shift)
     vt = B.to_probe_major(V.to(dev))
-    out = B.from_probe_major(B.kv(p1, p2, vt), n)
     ref = _oracle_K(kind, X1, X2, ls) @ V
-    assert out.shape == (n, t)
-    assert rel_err(out, ref) < 2e-5
+    try:
+        B.FORCE_KV_FLAGS = 0
+        out = B.from_probe_major(B.kv(p1, p2, vt), n)
+        assert out.shape == (n, t)
+        assert rel_err(out, ref) < 2e-5
+        if t > 8 and kind != "matern12":
+            assert max(p1.zmax2, p2.zmax2) <= B.GRAM_MAX_SQNORM  # the automatic policy would pick Gram here
+            B.FORCE_KV_FLAGS = B.KV_GRAM
+            out = B.from_probe_major(B.kv(p1, p2, vt), n)
+            assert rel_err(out, ref) < 5e-5
+    finally:
+        B.FORCE_KV_FLAGS = None
+
+
+def test_kv_gram_policy(dev):
+    """Gram-form generation is only selected when max |z|^2 <= 32 (short lengthscales fall back to the
+    direct-difference kernel) and never for Matern nu = 1/2 or t <= 8."""
+    from gpytorch_amd import backend as B
+
+    X = torch.rand(500, 3, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    sh = X.mean(0).float().to(dev)
+    wide = _prep("rbf", X, 0.5, dev, sh)
+    narrow = _prep("rbf", X, 0.02, dev, sh)
+    assert B.kv_flags(wide, wide, 65) == B.KV_GRAM
+    assert B.kv_flags(narrow, narrow, 65) == 0
+    assert B.kv_flags(wide, wide, 4) == 0
+    assert B.kv_flags(_prep("matern12", X, 0.5, dev, sh), _prep("matern12", X, 0.5, dev, sh), 65) == 0
+    # and the short-lengthscale problem is still accurate (direct path)
+    V = torch.randn(500, 33, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    out = B.from_probe_major(B.kv(narrow, narrow, B.to_probe_major(V.to(dev))), 500)
+    assert rel_err(out, OK.rbf(X, X, 0.02, direct=True) @ V) < 2e-5
 
 
 def test_kv_scale_and_diag_epilogue(dev):
@@ -147,7 +178,7 @@ def test_kv_linearity_full_size(dev):
     n, d, t = 100_000, 3, 65
     g = torch.Generator().manual_seed(0)
     X = torch.rand(n, d, generator=g)
-    p = _prep("rbf", X, 0.25, dev)
+    p = _prep("rbf", X, 0.25, dev, X.mean(0).to(dev))  # centred -> Gram-form generation is selected
     V1 = torch.randn(t, B.round_up(n, 4), device=dev)
     V2 = torch.randn(t, B.round_up(n, 4), device=dev)
     o1 = B.kv(p, p, V1).clone()

@@ -45,8 +45,8 @@ def test_argument_validation_without_gpu():
     h = lib()
     assert h.gpamd_kv_plan(0, 10, 1, 12, None, None, None) == -1
     assert b"bad shape" in h.gpamd_last_error()
-    # padded input dims other than 4/8/12/16 are refused before any launch
-    rc = h.gpamd_kv_partials_f32(0, None, 10, None, 10, 20, None, 12, 1, None, 12, 1, 128, None, None)
+    # input dimensions beyond 16 are refused before any launch
+    rc = h.gpamd_kv_partials_f32(0, None, 10, None, 10, 20, None, 12, 1, None, 12, 1, 128, 0, None, None)
     assert rc == -2
 
 
