@@ -23,7 +23,7 @@ SIGNATURES = {
     "gpamd_abi_version": (_i, []),
     "gpamd_last_error": (C.c_char_p, []),
     "gpamd_prep_points_f32": (_i, [_i, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
-    "gpamd_kv_plan": (_i, [_i, _i, _i, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
+    "gpamd_kv_plan": (_i, [_i, _i, _i, _i, _i, _i, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
     "gpamd_kv_partials_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _p]),
     "gpamd_kv_reduce_f32": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "gpamd_kv_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p]),

@@ -119,9 +119,10 @@ def workspace(device, nfloats: int) -> torch.Tensor:
     return buf
 
 
-def kv_plan(n: int, m: int, t: int, ldo: int):
+def kv_plan(kind: str, n: int, m: int, d: int, t: int, flags: int, ldo: int):
+    """(S, jchunk, workspace floats) for the kernel variant that (kind, d, t, flags) selects."""
     S, jc, ws = C.c_int(0), C.c_int(0), C.c_int64(0)
-    check(lib().gpamd_kv_plan(n, m, t, ldo, C.byref(S), C.byref(jc), C.byref(ws)), "kv_plan")
+    check(lib().gpamd_kv_plan(KIND_IDS[kind], n, m, d, t, flags, ldo, C.byref(S), C.byref(jc), C.byref(ws)), "kv_plan")
     return S.value, jc.value, ws.value
 
 
@@ -136,14 +137,15 @@ def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dsc
     ldo = round_up(n, 4)
     if out is None:
         out = torch.empty(t, ldo, device=vt.device, dtype=torch.float32)
-    S, jc, wsn = kv_plan(n, m, t, ldo)
+    flags = kv_flags(x1, x2, t)
+    S, jc, wsn = kv_plan(x1.kind, n, m, x1.d, t, flags, ldo)
     ws = workspace(vt.device, wsn)
     st = _stream(vt.device)
     L = lib()
     check(
         L.gpamd_kv_partials_f32(
             KIND_IDS[x1.kind], _ptr(x1.xp), n, _ptr(x2.xp), m, x1.d, _ptr(vt), ldv, t, _ptr(ws), ldo, S, jc,
-            kv_flags(x1, x2, t), None, st
+            flags, None, st
         ),
         "kv_partials",
     )

@@ -96,51 +96,69 @@ int group_cols(int t, int g0) {
   return KV_GROUP;
 }
 
-void plan_split(int n, int m, int t, int* S, int* jchunk) {
-  // The grid is (row blocks) x (S chunks of the contracted index).  Workgroups are dispatched
-  // dynamically as slots free up, so the tail costs about one unit-time: aim for >= 6 units per
-  // resident-workgroup slot (measured optimum at n = 1e5: S = 7..12, profiles/r01_s4_kv_tune_variants.jsonl),
-  // but keep every chunk >= 16 LDS tiles so the per-unit prologue / partial-slab write stays < 1 %.
+int kernel_dims(int d) {  // kernels exist for these valid-dimension counts; other d use the next one
+  return d <= 6 ? d : (d <= 8 ? 8 : (d <= 10 ? 10 : (d <= 12 ? 12 : 16)));
+}
+
+const void* family_ptr(int kind, int mode, int d, int v, int ex) {
+  switch (kind) {
+    case GPAMD_RBF: return kv_kernel_ptr_rbf(mode, d, v, ex);
+    case GPAMD_MATERN12: return kv_kernel_ptr_matern12(mode, d, v, ex);
+    case GPAMD_MATERN32: return kv_kernel_ptr_matern32(mode, d, v, ex);
+    case GPAMD_MATERN52: return kv_kernel_ptr_matern52(mode, d, v, ex);
+  }
+  return nullptr;
+}
+
+int kv_mode(int kind, int flags, const KvVariant& v) {
+  if (v.valu) return KV_MODE_VALU;
+  return ((flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12) ? KV_MODE_GRAM : KV_MODE_MFMA;
+}
+
+// resident workgroups per CU of the selected kernel (runtime occupancy query; static table without a device)
+int wg_per_cu(int kind, int mode, int dk, const KvVariant& v) {
+  const void* fn = family_ptr(kind, mode, dk, v.valu ? v.tpad : v.ct, v.ex);
+  int nb = 0;
+  if (fn && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) return nb;
+  (void)hipGetLastError();
+  if (v.valu) return 4;
+  if (mode == KV_MODE_GRAM) return 2;
+  return v.ct <= 2 ? 3 : 2;
+}
+
+void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jchunk) {
+  // Grid = (row blocks) x (S chunks of the contracted index).  All units cost the same, so the launch
+  // runs in ceil(units / slots) rounds of resident workgroups: pick the S whose last round is nearly
+  // full (efficiency = units / (rounds * slots)), keeping every chunk >= 16 LDS tiles (per-unit prologue
+  // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
   KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t);
+  const int mode = kv_mode(kind, flags, v);
   const int nrb = (n + v.bm - 1) / v.bm;
-  const int wg_per_cu = v.valu ? 4 : (v.ct <= 2 ? 3 : 2);
-  const long slots = (long)num_cus() * wg_per_cu;
+  const long slots = (long)num_cus() * wg_per_cu(kind, mode, kernel_dims(d), v);
   const int min_chunk = 16 * v.bn;
   int smax = m / min_chunk;
   if (smax < 1) smax = (m >= 4 * v.bn) ? m / (4 * v.bn) : 1;  // small problems: favour parallelism
-  if (smax > 64) smax = 64;
-  long want = (6 * slots + nrb - 1) / nrb;
-  int s = (int)(want < 1 ? 1 : (want > smax ? smax : want));
-  int jc = ((m + s - 1) / s + v.bn - 1) / v.bn * v.bn;
+  if (smax > 48) smax = 48;
+  int best_s = 1;
+  double best = -1.0;
+  for (int s = 1; s <= smax; ++s) {
+    const int jc = ((m + s - 1) / s + v.bn - 1) / v.bn * v.bn;
+    const int se = (m + jc - 1) / jc;
+    if (se != s) continue;  // rounding collapsed this split onto a smaller one
+    const long units = (long)nrb * se;
+    const long rounds = (units + slots - 1) / slots;
+    // the last chunk is shorter than the others: count its units at their true relative cost
+    const double last = (double)(m - (long)(se - 1) * jc) / (double)jc;
+    const double work = (double)nrb * ((se - 1) + last);
+    const double eff = work / ((double)rounds * (double)slots);
+    if (eff > best + 0.01) {
+      best = eff;
+      best_s = s;
+    }
+  }
+  const int jc = ((m + best_s - 1) / best_s + v.bn - 1) / v.bn * v.bn;
   *jchunk = jc;
   *S = (m + jc - 1) / jc;
-}
-
-int launch_family_mfma(int kind, int dp, int ct, int ex, const KvArgs& a, unsigned grid, hipStream_t st) {
-  switch (kind) {
-    case GPAMD_RBF: return launch_kv_mfma_rbf(dp, ct, ex, a, grid, st);
-    case GPAMD_MATERN12: return launch_kv_mfma_matern12(dp, ct, ex, a, grid, st);
-    case GPAMD_MATERN32: return launch_kv_mfma_matern32(dp, ct, ex, a, grid, st);
-    case GPAMD_MATERN52: return launch_kv_mfma_matern52(dp, ct, ex, a, grid, st);
-  }
-  return -2;
-}
-int launch_family_gram(int kind, int dp, int ct, int ex, const KvArgs& a, unsigned grid, hipStream_t st) {
-  switch (kind) {
-    case GPAMD_RBF: return launch_kv_gram_rbf(dp, ct, ex, a, grid, st);
-    case GPAMD_MATERN32: return launch_kv_gram_matern32(dp, ct, ex, a, grid, st);
-    case GPAMD_MATERN52: return launch_kv_gram_matern52(dp, ct, ex, a, grid, st);
-  }
-  return -2;
-}
-int launch_family_valu(int kind, int dp, int tpad, const KvArgs& a, unsigned grid, hipStream_t st) {
-  switch (kind) {
-    case GPAMD_RBF: return launch_kv_valu_rbf(dp, tpad, a, grid, st);
-    case GPAMD_MATERN12: return launch_kv_valu_matern12(dp, tpad, a, grid, st);
-    case GPAMD_MATERN32: return launch_kv_valu_matern32(dp, tpad, a, grid, st);
-    case GPAMD_MATERN52: return launch_kv_valu_matern52(dp, tpad, a, grid, st);
-  }
-  return -2;
 }
 
 unsigned col_blocks(int n) {
@@ -169,10 +187,11 @@ int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, c
   return check_launch("prep_points");
 }
 
-int gpamd_kv_plan(int n, int m, int t, int64_t ldo, int* S_host, int* jchunk_host, int64_t* workspace_floats_host) {
-  if (n <= 0 || m <= 0 || t <= 0) return fail(GPAMD_EINVAL, "kv_plan: bad shape");
+int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, int* S_host, int* jchunk_host,
+                  int64_t* workspace_floats_host) {
+  if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return fail(GPAMD_EINVAL, "kv_plan: bad shape");
   int S, jc;
-  plan_split(n, m, t, &S, &jc);
+  plan_split(kind, n, m, d, t, flags, &S, &jc);
   if (S_host) *S_host = S;
   if (jchunk_host) *jchunk_host = jc;
   if (workspace_floats_host) *workspace_floats_host = (int64_t)S * t * ldo;
@@ -187,7 +206,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
   if (d < 1 || d > 16) return fail(GPAMD_EUNSUPPORTED, "kv: input dimension must be in 1..16");
   // kernels are instantiated for D in {1,2,3,4,5,6,8,10,12,16} valid dimensions; other d use the next one
   // (same padded stride, the extra coordinates are the zeros written by prep_points)
-  const int dp = d <= 6 ? d : (d <= 8 ? 8 : (d <= 10 ? 10 : (d <= 12 ? 12 : 16)));
+  const int dk = kernel_dims(d);
   if (ldv % 4 || ldv < m || ldo < n) return fail(GPAMD_EINVAL, "kv: leading dimensions must be >= extent and ldv % 4 == 0");
   if (!aligned16(Vt) || !aligned16(X1p) || !aligned16(X2p)) return fail(GPAMD_EINVAL, "kv: buffers must be 16-byte aligned");
   if (jchunk % 4 || (int64_t)jchunk * S < m) return fail(GPAMD_EINVAL, "kv: jchunk*S must cover m and jchunk % 4 == 0");
@@ -205,11 +224,11 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
-    const bool gram = (flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12 && !v.valu;
-    int rc = v.valu ? launch_family_valu(kind, dp, v.tpad, a, grid, st)
-                    : (gram ? launch_family_gram(kind, dp, v.ct, v.ex, a, grid, st) : launch_family_mfma(kind, dp, v.ct, v.ex, a, grid, st));
-    if (rc) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
-    rc = check_launch("kv_partials");
+    const void* fn = family_ptr(kind, kv_mode(kind, flags, v), dk, v.valu ? v.tpad : v.ct, v.ex);
+    if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
+    void* kargs[] = {(void*)&a};
+    (void)hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, 0, st);
+    int rc = check_launch("kv_partials");
     if (rc) return rc;
     g0 += tg;
   }
@@ -230,8 +249,8 @@ int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int
                  int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
                  int64_t ldo, float* workspace, int64_t workspace_floats, int flags, void* stream) {
   int S, jc;
-  if (n <= 0 || m <= 0 || t <= 0) return fail(GPAMD_EINVAL, "kv: bad shape");
-  plan_split(n, m, t, &S, &jc);
+  if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return fail(GPAMD_EINVAL, "kv: bad shape");
+  plan_split(kind, n, m, d, t, flags, &S, &jc);
   const int64_t ldp = (n + 3) / 4 * 4;
   if (workspace_floats < (int64_t)S * t * ldp) return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4))");
   int rc = gpamd_kv_partials_f32(kind, X1p, n, X2p, m, d, Vt, ldv, t, workspace, ldp, S, jc, flags, nullptr, stream);

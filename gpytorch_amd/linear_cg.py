@@ -152,10 +152,10 @@ def linear_cg(
             Dt.copy_(Zt)
             check(L.gpamd_cg_begin_f32(h, st), "cg_begin")
 
-        S, jc, wsn = B.kv_plan(n, n, t, ld)
+        flags = B.kv_flags(x, x, t)
+        S, jc, wsn = B.kv_plan(x.kind, n, n, x.d, t, flags, ld)
         P = B.workspace(dev, wsn)
         kind_id = B.KIND_IDS[x.kind]
-        flags = B.kv_flags(x, x, t)
         min_iter = min(10, max_iter - 1)
         tri_floor = min(n_tri_iter, max_iter - 1) if n_tridiag else 0
         first_poll = max(min_iter, tri_floor)

@@ -46,9 +46,10 @@ const char* gpamd_last_error(void);
 int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, const float* ls, int nls,
                           const float* shift, float* Xp, int dp, void* stream);
 
-/* Launch plan for one fused K*V: split count S and j-chunk so the grid is a whole number of chip fills.
- * Outputs on the host. workspace_floats = S * t * ldo. */
-int gpamd_kv_plan(int n, int m, int t, int64_t ldo, int* S_host, int* jchunk_host, int64_t* workspace_floats_host);
+/* Launch plan for one fused K*V: split count S and j-chunk so the grid is a whole number of chip fills of the
+ * kernel variant that (kind, d, t, flags) selects.  Outputs on the host. workspace_floats = S * t * ldo. */
+int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, int* S_host, int* jchunk_host,
+                  int64_t* workspace_floats_host);
 
 /* P[s] = k(X1p, X2p[chunk s]) * Vt[:, chunk s]  for s < S -- the matrix-free K @ V of
  * KernelLinearOperator._matmul (gpytorch/kernels/keops/rbf_kernel.py:44-55) and

@@ -23,7 +23,7 @@ for name in ("mfma", "insts", "fetch", "write"):
     for f in glob.glob(f"{src}/pmc_{name}/**/*counter_collection*.csv", recursive=True)[:1]:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "kv_mfma" in r["Kernel_Name"]:
+            if "kv_mfma" in r["Kernel_Name"] or "kv_gram" in r["Kernel_Name"]:
                 kname = r["Kernel_Name"]
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():

@@ -15,7 +15,7 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 X = torch.rand(n, 3, device=dev)
-xp = B.prep_points("rbf", X, torch.tensor(0.25))
+xp = B.prep_points("rbf", X, torch.tensor(0.25), X.mean(0))  # centred, like RBFKernel.forward -> Gram-form kernel
 V = torch.randn(t, B.round_up(n, 4), device=dev)
 for _ in range(reps):
     out = B.kv(xp, xp, V)

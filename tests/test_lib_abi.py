@@ -34,16 +34,17 @@ def test_kv_plan_covers_and_fills():
 
     for n, m, t in [(2000, 2000, 11), (100_000, 100_000, 65), (500_000, 500_000, 65), (1_000_000, 1_000_000, 33),
                     (10_000, 100_000, 1), (257, 300, 140)]:
-        S, jc, ws = B.kv_plan(n, m, t, B.round_up(n, 4))
-        assert S >= 1 and jc % 128 == 0 and S * jc >= m and (S - 1) * jc < m
-        assert ws == S * t * B.round_up(n, 4)
+        for kind, flags in (("rbf", 0), ("rbf", B.KV_GRAM), ("matern52", 0)):
+            S, jc, ws = B.kv_plan(kind, n, m, 3, t, flags, B.round_up(n, 4))
+            assert S >= 1 and jc % 128 == 0 and S * jc >= m and (S - 1) * jc < m
+            assert ws == S * t * B.round_up(n, 4)
 
 
 def test_argument_validation_without_gpu():
     from gpytorch_amd._lib import lib
 
     h = lib()
-    assert h.gpamd_kv_plan(0, 10, 1, 12, None, None, None) == -1
+    assert h.gpamd_kv_plan(0, 0, 10, 3, 1, 0, 12, None, None, None) == -1
     assert b"bad shape" in h.gpamd_last_error()
     # input dimensions beyond 16 are refused before any launch
     rc = h.gpamd_kv_partials_f32(0, None, 10, None, 10, 20, None, 12, 1, None, 12, 1, 128, 0, None, None)
