@@ -25,7 +25,7 @@ SIGNATURES = {
     "gpamd_prep_points_f32": (_i, [_i, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
     "gpamd_kv_plan": (_i, [_i, _i, _i, _i, _i, _i, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
     "gpamd_kv_partials_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _p]),
-    "gpamd_kv_reduce_f32": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _p]),
+    "gpamd_kv_reduce_f32": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "gpamd_kv_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "gpamd_kernel_rows_f32": (_i, [_i, _p, _p, _i, _p, _i, _i, _p, _p, _i64, _p]),
     "gpamd_kernel_dense_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _p, _i64, _p]),
@@ -39,7 +39,7 @@ SIGNATURES = {
     "gpamd_cg_done_ptr": (_p, [_p]),
     "gpamd_cg_init_f32": (_i, [_p, _p, _i64, _i, _p]),
     "gpamd_cg_begin_f32": (_i, [_p, _p]),
-    "gpamd_cg_reduce_q_f32": (_i, [_p, _p, _i, _i64, _p, _p, _p]),
+    "gpamd_cg_reduce_q_f32": (_i, [_p, _p, _i, _i64, _p, _p, _p, _p]),
     "gpamd_cg_update_xr_f32": (_i, [_p, _i, _p]),
     "gpamd_cg_update_d_f32": (_i, [_p, _i, _p]),
     "gpamd_cg_stop_f32": (_i, [_p, _i, _i, _i, _f, _p]),

@@ -126,10 +126,10 @@ def kv_plan(kind: str, n: int, m: int, d: int, t: int, flags: int, ldo: int):
     return S.value, jc.value, ws.value
 
 
-def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dscale=None, vd=None, out=None):
-    """out[t, ld_n] = scale * k(x1, x2) @ V + dscale * Vd in probe-major layout.
+def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dscale=None, vd=None, out=None, dvec=None):
+    """out[t, ld_n] = scale * k(x1, x2) @ V + (dscale + dvec) .* Vd in probe-major layout.
 
-    vt: [t, ldv] with ldv >= m; scale/dscale: 1-element device tensors or None."""
+    vt: [t, ldv] with ldv >= m; scale/dscale: 1-element device tensors or None; dvec: float32 [>= n] or None."""
     _require_gpu(vt, "vt")
     assert x1.kind == x2.kind and x1.dp == x2.dp
     t, ldv = vt.shape
@@ -151,7 +151,7 @@ def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dsc
     )
     check(
         L.gpamd_kv_reduce_f32(
-            _ptr(ws), S, ldo, t, n, _ptr(scale), _ptr(dscale), _ptr(vd), 0 if vd is None else vd.stride(0),
+            _ptr(ws), S, ldo, t, n, _ptr(scale), _ptr(dscale), _ptr(dvec), _ptr(vd), 0 if vd is None else vd.stride(0),
             _ptr(out), out.stride(0), None, st,
         ),
         "kv_reduce",

@@ -16,6 +16,7 @@ from dataclasses import dataclass
 import torch
 
 from . import backend as B
+from .distributed import allreduce_sum_
 from . import settings
 from .linear_cg import CGInfo, Preconditioner, linear_cg
 
@@ -131,6 +132,7 @@ def inv_quad_logdet_forward(
     max_iter=None,
     group=None,
     t_total=None,
+    dvec=None,
 ) -> InvQuadLogdetResult:
     """A.6 forward for K_hat = scale*K(x,x) + sigma2*I.
 
@@ -142,6 +144,8 @@ def inv_quad_logdet_forward(
     n = x.n
     dev = rhs_t.device
     t = settings.num_trace_samples.value() if num_probes is None else num_probes
+    if dvec is not None:
+        precond = None  # the pivoted-Cholesky preconditioner is built for the constant-diagonal branch only (A.4)
     if precond == "auto":
         precond = build_preconditioner(x, scale, sigma2)
     if probes is not None:
@@ -151,11 +155,12 @@ def inv_quad_logdet_forward(
         t_total = t
         if group is not None:
             tt = torch.tensor([float(t)], device=dev)
-            torch.distributed.all_reduce(tt, group=group)
+            allreduce_sum_(tt, group)
             t_total = int(tt.item())
     full = torch.cat([zt, rhs_t.to(torch.float32)], dim=0).contiguous()
     solves_t, info = linear_cg(
-        x, scale, sigma2, full, n_tridiag=t, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, group=group
+        x, scale, sigma2, full, n_tridiag=t, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, group=group,
+        dvec=dvec,
     )
     if settings.skip_logdet_forward.on():
         ld_slq = torch.zeros((), dtype=torch.float64)
@@ -164,7 +169,7 @@ def inv_quad_logdet_forward(
         ld_slq = slq_logdet(info.t_mats, n) * (t / t_total)
     ld_slq = ld_slq.to(device=dev, dtype=torch.float32)
     if group is not None:
-        torch.distributed.all_reduce(ld_slq, group=group)
+        allreduce_sum_(ld_slq, group)
     logdet = ld_slq + (precond.logdet if precond is not None else 0.0)
     c = rhs_t.shape[0]
     inv_quad = B.coldot(solves_t[t : t + c], rhs_t.to(torch.float32), n)

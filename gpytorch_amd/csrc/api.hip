@@ -236,12 +236,13 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
 }
 
 int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const float* scale, const float* dscale,
-                        const float* Vd, int64_t ldd, float* Out, int64_t ldo, const int* done, void* stream) {
+                        const float* dvec, const float* Vd, int64_t ldd, float* Out, int64_t ldo, const int* done,
+                        void* stream) {
   if (S <= 0 || t <= 0 || n <= 0) return fail(GPAMD_EINVAL, "kv_reduce: bad shape");
   if (ldp % 4 || ldo % 4 || (Vd && ldd % 4)) return fail(GPAMD_EINVAL, "kv_reduce: leading dimensions must be multiples of 4");
   dim3 grid(col_blocks(n), t);
   hipLaunchKernelGGL((kv_reduce_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, P, S, (int64_t)t * ldp, ldp,
-                     scale, dscale, Vd, ldd, Out, ldo, n, (float*)nullptr, done);
+                     scale, dscale, dvec, Vd, ldd, Out, ldo, n, (float*)nullptr, done);
   return check_launch("kv_reduce");
 }
 
@@ -255,7 +256,7 @@ int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int
   if (workspace_floats < (int64_t)S * t * ldp) return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4))");
   int rc = gpamd_kv_partials_f32(kind, X1p, n, X2p, m, d, Vt, ldv, t, workspace, ldp, S, jc, flags, nullptr, stream);
   if (rc) return rc;
-  return gpamd_kv_reduce_f32(workspace, S, ldp, t, n, scale, dscale, Vd, ldd, Out, ldo, nullptr, stream);
+  return gpamd_kv_reduce_f32(workspace, S, ldp, t, n, scale, dscale, nullptr, Vd, ldd, Out, ldo, nullptr, stream);
 }
 
 #define KIND_SWITCH(kind, CALL)                     \
@@ -380,11 +381,11 @@ int gpamd_cg_begin_f32(gpamd_cg_t* h, void* stream) {
 }
 
 int gpamd_cg_reduce_q_f32(gpamd_cg_t* h, const float* P, int S, int64_t ldp, const float* scale, const float* dscale,
-                          void* stream) {
+                          const float* dvec, void* stream) {
   if (!h || S <= 0 || ldp % 4) return fail(GPAMD_EINVAL, "cg_reduce_q: bad arguments");
   CgState<float>& s = h->st;
   hipLaunchKernelGGL((kv_reduce_kernel<float, true>), dim3(s.nb, s.t), dim3(256), 0, (hipStream_t)stream, P, S,
-                     (int64_t)s.t * ldp, ldp, scale, dscale, s.D, s.ld, s.Q, s.ld, s.n, s.part_a, s.done);
+                     (int64_t)s.t * ldp, ldp, scale, dscale, dvec, s.D, s.ld, s.Q, s.ld, s.n, s.part_a, s.done);
   return check_launch("cg_reduce_q");
 }
 

@@ -97,13 +97,15 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const T* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// Out[c][i] = scale * sum_s P[s][c][i] + dscale * Vd[c][i]     (the K_hat = theta*K + sigma^2 I epilogue:
-// gpytorch/kernels/scale_kernel.py:117-118 and gpytorch/likelihoods/gaussian_likelihood.py:117-121)
+// Out[c][i] = scale * sum_s P[s][c][i] + (dscale + dvec[i]) * Vd[c][i]   (the K_hat = theta*K + noise epilogue:
+// gpytorch/kernels/scale_kernel.py:117-118 and gpytorch/likelihoods/gaussian_likelihood.py:117-121; dvec is the
+// heteroskedastic / per-task noise diagonal of FixedNoiseGaussianLikelihood and MultitaskGaussianLikelihood)
 // optionally also part[c][b] = sum_i Dv[c][i] * Out[c][i]  (CG denominator d^T K_hat d).
 template <typename T, bool WITH_DOT>
 __global__ __launch_bounds__(256) void kv_reduce_kernel(const T* __restrict__ P, int S, int64_t pstride, int64_t ldp,
                                                         const T* __restrict__ scale, const T* __restrict__ dscale,
-                                                        const T* __restrict__ Vd, int64_t ldd, T* __restrict__ Out,
+                                                        const T* __restrict__ dvec, const T* __restrict__ Vd,
+                                                        int64_t ldd, T* __restrict__ Out,
                                                         int64_t ldo, int n, T* __restrict__ part,
                                                         const int* __restrict__ done) {
   __shared__ T sm[4];
@@ -121,10 +123,12 @@ __global__ __launch_bounds__(256) void kv_reduce_kernel(const T* __restrict__ P,
     }
     V4<T> d = {{T(0), T(0), T(0), T(0)}};
     if (Vd) d = ld4(Vd + (int64_t)c * ldd, i, n);
+    V4<T> dv = {{T(0), T(0), T(0), T(0)}};
+    if (dvec) dv = ld4(dvec, i, n);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       q.v[e] *= sc;
-      if (Vd) q.v[e] += ds * d.v[e];
+      if (Vd) q.v[e] += (ds + dv.v[e]) * d.v[e];
       if (WITH_DOT) acc += d.v[e] * q.v[e];
     }
     st4(Out + (int64_t)c * ldo, i, n, q);

@@ -53,6 +53,13 @@ def allreduce_residual_stats(sum_rnorm: torch.Tensor, count: torch.Tensor, group
 
 
 def allreduce_sum_(t: torch.Tensor, group=None):
+    """In-place sum all-reduce.  RCCL ("nccl") reduces device tensors directly over xGMI; the gloo backend
+    (CPU tests, or several ranks sharing one GPU) is given a host copy."""
     if group is not None or (dist.is_initialized() and dist.get_world_size() > 1):
-        dist.all_reduce(t, group=group)
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            tmp = t.detach().cpu()
+            dist.all_reduce(tmp, group=group)
+            t.copy_(tmp)
+        else:
+            dist.all_reduce(t, group=group)
     return t

@@ -13,6 +13,7 @@ from __future__ import annotations
 import torch
 
 from . import backend as B
+from .distributed import allreduce_sum_
 from . import settings
 from .bbmm import inv_quad_logdet_forward
 
@@ -20,9 +21,13 @@ from .bbmm import inv_quad_logdet_forward
 class KernelSpec:
     """Non-tensor description of a stationary kernel operator (kind, centring shift, probe options)."""
 
-    def __init__(self, kind: str, shift=None):
+    def __init__(self, kind: str, shift=None, dvec=None):
         self.kind = kind
         self.shift = shift
+        self.dvec = dvec  # optional fixed (non-learnable) per-point noise diagonal, float32 [n] on the device
+
+    def with_dvec(self, dvec):
+        return KernelSpec(self.kind, self.shift, dvec)
 
 
 def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t):
@@ -54,7 +59,7 @@ class InvQuadLogdetFn(torch.autograd.Function):
             xp, os_, nz, rhs_t,
             num_probes=opts.get("num_probes"), precond=opts.get("precond", "auto"), probes=opts.get("probes"),
             generator=opts.get("generator"), tolerance=opts.get("tolerance"), max_iter=opts.get("max_iter"),
-            group=opts.get("group"), t_total=opts.get("t_total"),
+            group=opts.get("group"), t_total=opts.get("t_total"), dvec=spec.dvec,
         )
         ctx.xp, ctx.res, ctx.n = xp, res, n
         ctx.group = opts.get("group")
@@ -86,7 +91,7 @@ class InvQuadLogdetFn(torch.autograd.Function):
         d_noise = B.coldot(left, right, n).sum().reshape(noise.shape).to(noise.dtype)
         if ctx.group is not None:
             pack = torch.cat([d_ls.reshape(-1).float(), d_noise.reshape(-1).float()] + ([d_os.reshape(-1).float()] if d_os is not None else []))
-            torch.distributed.all_reduce(pack, group=ctx.group)
+            allreduce_sum_(pack, ctx.group)
             k = d_ls.numel()
             d_ls = pack[:k].reshape(d_ls.shape).to(d_ls.dtype)
             d_noise = pack[k : k + 1].reshape(d_noise.shape).to(d_noise.dtype)
@@ -109,6 +114,8 @@ class CholeskyInvQuadLogdetFn(torch.autograd.Function):
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
         K = B.kernel_dense(xp, xp, os_).to(torch.float64)
         K.diagonal().add_(noise.detach().reshape(()).to(torch.float64))
+        if spec.dvec is not None:
+            K.diagonal().add_(spec.dvec[:n].to(torch.float64))
         Lc = torch.linalg.cholesky(K)
         sol = torch.cholesky_solve(rhs.detach().to(torch.float64), Lc)
         inv_quad = (sol * rhs.detach().to(torch.float64)).sum(-2)
@@ -149,8 +156,9 @@ class KernelMatmulFn(torch.autograd.Function):
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
         nz = None if noise is None else noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
         vt = B.to_probe_major(rhs)
-        out_t = B.kv(xp1, xp2, vt, scale=os_, dscale=nz, vd=vt if nz is not None else None)
-        ctx.xp1, ctx.xp2 = xp1, xp2
+        out_t = B.kv(xp1, xp2, vt, scale=os_, dscale=nz, vd=vt if nz is not None else None,
+                     dvec=spec.dvec if nz is not None else None)
+        ctx.xp1, ctx.xp2, ctx.dvec = xp1, xp2, (spec.dvec if nz is not None else None)
         ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0),
                               noise if noise is not None else torch.empty(0), rhs)
         ctx.has_os, ctx.has_noise = outputscale is not None, noise is not None
@@ -171,6 +179,6 @@ class KernelMatmulFn(torch.autograd.Function):
         if ctx.needs_input_grad[5]:
             os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
             nz = None if noise is None else noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
-            out_t = B.kv(ctx.xp2, ctx.xp1, gt, scale=os_, dscale=nz, vd=gt if nz is not None else None)
+            out_t = B.kv(ctx.xp2, ctx.xp1, gt, scale=os_, dscale=nz, vd=gt if nz is not None else None, dvec=ctx.dvec)
             d_rhs = B.from_probe_major(out_t, ctx.xp2.n).to(rhs.dtype)
         return None, None, d_ls, d_os, d_noise, d_rhs, None

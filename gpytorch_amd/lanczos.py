@@ -16,7 +16,7 @@ from . import settings
 
 
 def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_t: torch.Tensor | None = None,
-                    tol: float = 1e-5, generator=None):
+                    tol: float = 1e-5, generator=None, dvec=None):
     """Returns (Qt [m, ld] with orthonormal rows, T [m, m] float32 on device)."""
     n = x.n
     dev = x.xp.device
@@ -29,7 +29,7 @@ def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_
     T = torch.zeros(num_iter, num_iter, device=dev, dtype=torch.float32)
 
     def mv(q_row):  # K_hat q, q_row: [1, ld]
-        return B.kv(x, x, q_row, scale=scale, dscale=dscale, vd=q_row if dscale is not None else None)
+        return B.kv(x, x, q_row, scale=scale, dscale=dscale, vd=q_row if dscale is not None else None, dvec=dvec)
 
     q0 = init_vec_t / init_vec_t.norm()
     Q[0] = q0[0]
@@ -83,11 +83,11 @@ def tridiag_to_diag(T: torch.Tensor):
     return evals, evecs
 
 
-def root_inv_decomposition(x: B.PreparedPoints, scale, dscale, max_iter=None, init_vec_t=None, generator=None):
+def root_inv_decomposition(x: B.PreparedPoints, scale, dscale, max_iter=None, init_vec_t=None, generator=None, dvec=None):
     """Rt [m, ld] with Rt^T Rt ~= K_hat^-1 on the Krylov space (the ``covar_cache`` of
     ``exact_prediction_strategies.py:267-272``)."""
     max_iter = settings.max_root_decomposition_size.value() if max_iter is None else max_iter
-    Q, T = lanczos_tridiag(x, scale, dscale, max_iter, init_vec_t, generator=generator)
+    Q, T = lanczos_tridiag(x, scale, dscale, max_iter, init_vec_t, generator=generator, dvec=dvec)
     jitter = settings.tridiagonal_jitter.value()
     Tj = T + jitter * torch.eye(T.shape[0], device=T.device, dtype=T.dtype)
     evals, evecs = tridiag_to_diag(Tj)

@@ -25,6 +25,7 @@ from dataclasses import dataclass
 import torch
 
 from . import backend as B
+from .distributed import allreduce_sum_
 from . import settings
 from ._lib import check, lib
 
@@ -106,8 +107,9 @@ def linear_cg(
     preconditioner: Preconditioner | None = None,
     group=None,
     kv_partials=None,
+    dvec: torch.Tensor | None = None,
 ):
-    """Solve (scale*K(x,x) + dscale*I) X = rhs for all rows of ``rhs_t`` ([t, ld], probe-major).
+    """Solve (scale*K(x,x) + dscale*I + diag(dvec)) X = rhs for all rows of ``rhs_t`` ([t, ld], probe-major).
 
     ``kv_partials(vt, P, ldp, S, jc, done_ptr, stream)``: optional override of the fused K*V launch
     (used by the multitask Kronecker operator); defaults to the plain kernel MVM on ``x``.
@@ -180,13 +182,13 @@ def linear_cg(
             if ev is not None:
                 ev[1].record(torch.cuda.current_stream(dev))
                 KV_EVENT_LOG.append((ev[0], ev[1], n, t, k))
-            check(L.gpamd_cg_reduce_q_f32(h, B._ptr(P), S, ld, B._ptr(scale), B._ptr(dscale), st), "cg_reduce_q")
+            check(L.gpamd_cg_reduce_q_f32(h, B._ptr(P), S, ld, B._ptr(scale), B._ptr(dscale), B._ptr(dvec), st), "cg_reduce_q")
             check(L.gpamd_cg_update_xr_f32(h, k, st), "cg_update_xr")
             if preconditioner is not None:
                 preconditioner.apply_(Rt, Zt)
             check(L.gpamd_cg_update_d_f32(h, k, st), "cg_update_d")
             if group is not None:
-                torch.distributed.all_reduce(stats, group=group)
+                allreduce_sum_(stats, group)
             check(L.gpamd_cg_stop_f32(h, k, min_iter, tri_floor, float(tolerance), st), "cg_stop")
             iters = k + 1
             if k >= first_poll and ((k - first_poll) % poll_every == 0 or k == max_iter - 1):

@@ -425,8 +425,12 @@ class FusedKernelLinearOperator(LinearOperator):
     def __add__(self, other):
         if isinstance(other, ConstantDiagLinearOperator) and self.is_square:
             return FusedKernelAddedDiagLinearOperator(self, other.diag_values)
-        if isinstance(other, DiagLinearOperator) and self.is_square and bool((other._diag == other._diag[0]).all()):
-            return FusedKernelAddedDiagLinearOperator(self, other._diag[:1])
+        if isinstance(other, DiagLinearOperator) and self.is_square:
+            if bool((other._diag == other._diag[0]).all()):
+                return FusedKernelAddedDiagLinearOperator(self, other._diag[:1])
+            # heteroskedastic fixed noise (FixedNoiseGaussianLikelihood): rides in the fused epilogue as a vector
+            zero = torch.zeros(1, device=self.device, dtype=self.dtype)
+            return FusedKernelAddedDiagLinearOperator(self, zero, noise_vec=other._diag)
         return super().__add__(other)
 
     def detach(self):
@@ -453,11 +457,26 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
     """K_hat = outputscale * k(x, x) + noise * I  (constant diagonal) -- the operator the MLL and the
     prediction caches solve with.  ``bbmm_opts`` forwards probe / sharding options to the solver."""
 
-    def __init__(self, kernel_op: FusedKernelLinearOperator, noise: torch.Tensor, bbmm_opts: dict | None = None):
+    def __init__(self, kernel_op: FusedKernelLinearOperator, noise: torch.Tensor, bbmm_opts: dict | None = None, noise_vec=None):
         self.kernel_op = kernel_op
         self.noise = noise.reshape(-1)[:1]
+        self.noise_vec = noise_vec  # optional fixed per-point diagonal [n] (added on top of the scalar noise)
         self.bbmm_opts = {} if bbmm_opts is None else bbmm_opts
         self._cache = {}
+
+    def _dvec(self):
+        if self.noise_vec is None:
+            return None
+        if "dvec" not in self._cache:
+            n = self.shape[-1]
+            dv = torch.zeros(B.round_up(n, 4), device=self.device, dtype=torch.float32)
+            dv[:n] = self.noise_vec.detach().to(torch.float32)
+            self._cache["dvec"] = dv
+        return self._cache["dvec"]
+
+    def _spec(self):
+        k = self.kernel_op
+        return k.spec if self.noise_vec is None else k.spec.with_dvec(self._dvec())
 
     dtype = property(lambda self: self.kernel_op.dtype)
     device = property(lambda self: self.kernel_op.device)
@@ -471,25 +490,31 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
 
     def _matmul(self, rhs):
         k = self.kernel_op
-        return KernelMatmulFn.apply(k.x1, k.x1, k.lengthscale, k.outputscale, self.noise, rhs, k.spec)
+        return KernelMatmulFn.apply(k.x1, k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec())
 
     def _transpose_nonbatch(self):
         return self
 
     def diagonal(self, offset=0, dim1=-2, dim2=-1):
-        return self.kernel_op.diagonal() + self.noise.reshape(())
+        d = self.kernel_op.diagonal() + self.noise.reshape(())
+        return d if self.noise_vec is None else d + self.noise_vec
 
     def to_dense(self):
         K = self.kernel_op.to_dense()
-        return K + self.noise.reshape(()) * torch.eye(K.shape[-1], device=K.device, dtype=K.dtype)
+        K = K + self.noise.reshape(()) * torch.eye(K.shape[-1], device=K.device, dtype=K.dtype)
+        return K if self.noise_vec is None else K + torch.diag(self.noise_vec.to(K.dtype))
 
     def __add__(self, other):
         if isinstance(other, ConstantDiagLinearOperator):
-            return FusedKernelAddedDiagLinearOperator(self.kernel_op, self.noise + other.diag_values.reshape(-1)[:1], self.bbmm_opts)
+            return FusedKernelAddedDiagLinearOperator(self.kernel_op, self.noise + other.diag_values.reshape(-1)[:1], self.bbmm_opts,
+                                                      self.noise_vec)
+        if isinstance(other, DiagLinearOperator):
+            nv = other._diag if self.noise_vec is None else self.noise_vec + other._diag
+            return FusedKernelAddedDiagLinearOperator(self.kernel_op, self.noise, self.bbmm_opts, nv)
         return super().__add__(other)
 
     def detach(self):
-        return FusedKernelAddedDiagLinearOperator(self.kernel_op.detach(), self.noise.detach(), self.bbmm_opts)
+        return FusedKernelAddedDiagLinearOperator(self.kernel_op.detach(), self.noise.detach(), self.bbmm_opts, self.noise_vec)
 
     def _use_cholesky(self, flag) -> bool:
         return flag.off() or self.shape[-1] <= settings.max_cholesky_size.value()
@@ -505,14 +530,14 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             inv_quad_rhs = torch.zeros(n, 0, device=self.device, dtype=self.dtype)
         rhs = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
         if self._use_cholesky(settings.fast_computations.log_prob):
-            iq, ld = CholeskyInvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, k.spec)
+            iq, ld = CholeskyInvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec())
         else:
             if rhs.shape[-1] == 0:
                 rhs = torch.zeros(n, 1, device=self.device, dtype=self.dtype)
                 drop = True
             else:
                 drop = False
-            iq, ld = InvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, k.spec, self.bbmm_opts)
+            iq, ld = InvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec(), self.bbmm_opts)
             if drop:
                 iq = iq[:0]
         if reduce_inv_quad:
@@ -525,7 +550,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
 
         if "precond" not in self._cache:
             p1, _ = self.kernel_op.prepared()
-            self._cache["precond"] = build_preconditioner(p1, self.kernel_op._os(), self._nz())
+            self._cache["precond"] = None if self.noise_vec is not None else build_preconditioner(p1, self.kernel_op._os(), self._nz())
         pre = self._cache["precond"]
         if pre is None:
             return None, None, None
@@ -549,10 +574,10 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         else:
             p1, _ = self.kernel_op.prepared()
             if "precond" not in self._cache:
-                self._cache["precond"] = build_preconditioner(p1, self.kernel_op._os(), self._nz())
+                self._cache["precond"] = None if self.noise_vec is not None else build_preconditioner(p1, self.kernel_op._os(), self._nz())
             sol_t, info = linear_cg(
                 p1, self.kernel_op._os(), self._nz(), B.to_probe_major(r.detach()), n_tridiag=0,
-                tolerance=settings.cg_tolerance.value(), preconditioner=self._cache["precond"],
+                tolerance=settings.cg_tolerance.value(), preconditioner=self._cache["precond"], dvec=self._dvec(),
             )
             self._cache["last_cg_info"] = info
             sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
@@ -569,7 +594,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         p1, _ = self.kernel_op.prepared()
         init_t = None if initial_vectors is None else B.to_probe_major(initial_vectors.reshape(self.shape[-1], -1)[:, :1])
         rt = root_inv_decomposition(p1, self.kernel_op._os(), self._nz(), init_vec_t=init_t,
-                                    generator=self.bbmm_opts.get("generator"))
+                                    generator=self.bbmm_opts.get("generator"), dvec=self._dvec())
         return RootLinearOperator(B.from_probe_major(rt, self.shape[-1]).to(self.dtype))
 
     def pivoted_cholesky(self, rank, error_tol=None, return_pivots=False):

@@ -60,11 +60,13 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream);
 
-/* Out = scale * sum_s P[s] + dscale * Vd  (scale/dscale device scalars, NULL = 1 / 0; Vd may be NULL):
- * ScaleKernel.forward (gpytorch/kernels/scale_kernel.py:117-118) and the + sigma^2 I of
- * _GaussianLikelihoodBase.marginal (gpytorch/likelihoods/gaussian_likelihood.py:117-121). */
+/* Out = scale * sum_s P[s] + (dscale + dvec) .* Vd  (scale/dscale device scalars, NULL = 1 / 0; dvec: optional
+ * float[n] diagonal; Vd may be NULL): ScaleKernel.forward (gpytorch/kernels/scale_kernel.py:117-118) and the
+ * + noise of _GaussianLikelihoodBase.marginal (gpytorch/likelihoods/gaussian_likelihood.py:117-121; dvec carries
+ * FixedNoiseGaussianLikelihood's heteroskedastic diagonal, gaussian_likelihood.py:245-362). */
 int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const float* scale, const float* dscale,
-                        const float* Vd, int64_t ldd, float* Out, int64_t ldo, const int* done, void* stream);
+                        const float* dvec, const float* Vd, int64_t ldd, float* Out, int64_t ldo, const int* done,
+                        void* stream);
 
 /* One-call  Out = scale * K(X1p, X2p) Vt + dscale * Vd  using caller workspace (>= plan's workspace_floats). */
 int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt, int64_t ldv,
@@ -106,9 +108,9 @@ const int* gpamd_cg_done_ptr(const gpamd_cg_t* h);
 int gpamd_cg_init_f32(gpamd_cg_t* h, const float* B, int64_t ldb, int have_precond, void* stream);
 /* with a preconditioner: after the caller wrote Z = P^-1 R and D = Z: rho = r.z */
 int gpamd_cg_begin_f32(gpamd_cg_t* h, void* stream);
-/* Q = scale * sum_s P[s] + dscale * D, and d.q partials */
+/* Q = scale * sum_s P[s] + (dscale + dvec) .* D, and d.q partials */
 int gpamd_cg_reduce_q_f32(gpamd_cg_t* h, const float* P, int S, int64_t ldp, const float* scale, const float* dscale,
-                          void* stream);
+                          const float* dvec, void* stream);
 /* alpha; X += alpha D; R -= alpha Q */
 int gpamd_cg_update_xr_f32(gpamd_cg_t* h, int k, void* stream);
 /* (caller applies Z = P^-1 R here when preconditioned)  beta; D = Z + beta D; residual statistics -> stats */
