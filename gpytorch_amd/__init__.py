@@ -21,6 +21,13 @@ from ._lib import LIB_PATH, GpamdError  # noqa: F401
 from .mlls import ExactMarginalLogLikelihood  # noqa: F401
 from .module import Module  # noqa: F401
 from .operators import to_dense, to_linear_operator
+from . import multitask as _mt  # noqa: E402
+
+# multitask members live where the reference keeps them
+kernels.IndexKernel, kernels.MultitaskKernel = _mt.IndexKernel, _mt.MultitaskKernel
+means.MultitaskMean = _mt.MultitaskMean
+distributions.MultitaskMultivariateNormal = _mt.MultitaskMultivariateNormal
+likelihoods.MultitaskGaussianLikelihood = _mt.MultitaskGaussianLikelihood
 
 __version__ = "0.1.0"
 

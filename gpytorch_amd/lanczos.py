@@ -16,10 +16,13 @@ from . import settings
 
 
 def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_t: torch.Tensor | None = None,
-                    tol: float = 1e-5, generator=None, dvec=None):
-    """Returns (Qt [m, ld] with orthonormal rows, T [m, m] float32 on device)."""
-    n = x.n
-    dev = x.xp.device
+                    tol: float = 1e-5, generator=None, dvec=None, matvec=None, nvec=None, device=None):
+    """Returns (Qt [m, ld] with orthonormal rows, T [m, m] float32 on device).
+
+    ``matvec(q_row [1, ld]) -> [1, ld]``: optional operator override (multitask Kronecker); then ``x`` may be
+    None and ``nvec`` / ``device`` give the vector length and device."""
+    n = x.n if nvec is None else nvec
+    dev = x.xp.device if device is None else device
     ld = B.round_up(n, 4)
     num_iter = min(max_iter, n)
     if init_vec_t is None:
@@ -29,6 +32,8 @@ def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_
     T = torch.zeros(num_iter, num_iter, device=dev, dtype=torch.float32)
 
     def mv(q_row):  # K_hat q, q_row: [1, ld]
+        if matvec is not None:
+            return matvec(q_row)
         return B.kv(x, x, q_row, scale=scale, dscale=dscale, vd=q_row if dscale is not None else None, dvec=dvec)
 
     q0 = init_vec_t / init_vec_t.norm()
@@ -83,11 +88,13 @@ def tridiag_to_diag(T: torch.Tensor):
     return evals, evecs
 
 
-def root_inv_decomposition(x: B.PreparedPoints, scale, dscale, max_iter=None, init_vec_t=None, generator=None, dvec=None):
+def root_inv_decomposition(x: B.PreparedPoints, scale, dscale, max_iter=None, init_vec_t=None, generator=None, dvec=None,
+                           matvec=None, nvec=None, device=None):
     """Rt [m, ld] with Rt^T Rt ~= K_hat^-1 on the Krylov space (the ``covar_cache`` of
     ``exact_prediction_strategies.py:267-272``)."""
     max_iter = settings.max_root_decomposition_size.value() if max_iter is None else max_iter
-    Q, T = lanczos_tridiag(x, scale, dscale, max_iter, init_vec_t, generator=generator, dvec=dvec)
+    Q, T = lanczos_tridiag(x, scale, dscale, max_iter, init_vec_t, generator=generator, dvec=dvec, matvec=matvec,
+                           nvec=nvec, device=device)
     jitter = settings.tridiagonal_jitter.value()
     Tj = T + jitter * torch.eye(T.shape[0], device=T.device, dtype=T.dtype)
     evals, evecs = tridiag_to_diag(Tj)

@@ -108,15 +108,17 @@ def linear_cg(
     group=None,
     kv_partials=None,
     dvec: torch.Tensor | None = None,
+    nvec: int | None = None,
 ):
     """Solve (scale*K(x,x) + dscale*I + diag(dvec)) X = rhs for all rows of ``rhs_t`` ([t, ld], probe-major).
 
-    ``kv_partials(vt, P, ldp, S, jc, done_ptr, stream)``: optional override of the fused K*V launch
-    (used by the multitask Kronecker operator); defaults to the plain kernel MVM on ``x``.
+    ``kv_partials(Dt) -> (P, S, ldp)``: optional override of the noise-free operator product (used by the
+    multitask Kronecker operator, whose vectors have length n*T): returns partial slabs ``P[S][t][ldp]`` whose
+    sum is ``K_op @ D``; ``x`` may then be ``None`` and the vector length is taken from ``nvec``.
     Returns (solves_t [t, ld], CGInfo)."""
     B._require_gpu(rhs_t, "rhs")
     L = lib()
-    n = x.n
+    n = x.n if nvec is None else nvec
     t, ld = rhs_t.shape
     dev = rhs_t.device
     if tolerance is None:
@@ -154,10 +156,12 @@ def linear_cg(
             Dt.copy_(Zt)
             check(L.gpamd_cg_begin_f32(h, st), "cg_begin")
 
-        flags = B.kv_flags(x, x, t)
-        S, jc, wsn = B.kv_plan(x.kind, n, n, x.d, t, flags, ld)
-        P = B.workspace(dev, wsn)
-        kind_id = B.KIND_IDS[x.kind]
+        if kv_partials is None:
+            flags = B.kv_flags(x, x, t)
+            S, jc, wsn = B.kv_plan(x.kind, n, n, x.d, t, flags, ld)
+            P = B.workspace(dev, wsn)
+            kind_id = B.KIND_IDS[x.kind]
+        ldp = ld
         min_iter = min(10, max_iter - 1)
         tri_floor = min(n_tri_iter, max_iter - 1) if n_tridiag else 0
         first_poll = max(min_iter, tri_floor)
@@ -178,11 +182,11 @@ def linear_cg(
                     "kv_partials",
                 )
             else:
-                kv_partials(Dt, P, ld, S, jc, done_ptr, st)
+                P, S, ldp = kv_partials(Dt)
             if ev is not None:
                 ev[1].record(torch.cuda.current_stream(dev))
                 KV_EVENT_LOG.append((ev[0], ev[1], n, t, k))
-            check(L.gpamd_cg_reduce_q_f32(h, B._ptr(P), S, ld, B._ptr(scale), B._ptr(dscale), B._ptr(dvec), st), "cg_reduce_q")
+            check(L.gpamd_cg_reduce_q_f32(h, B._ptr(P), S, ldp, B._ptr(scale), B._ptr(dscale), B._ptr(dvec), st), "cg_reduce_q")
             check(L.gpamd_cg_update_xr_f32(h, k, st), "cg_update_xr")
             if preconditioner is not None:
                 preconditioner.apply_(Rt, Zt)

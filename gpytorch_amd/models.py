@@ -180,13 +180,18 @@ class ExactGP(GP):
         full_mean, test_test_covar, test_train_covar = self._get_test_prior_mean_and_covariances(train_inputs, inputs, **kwargs)
         with settings.cg_tolerance(settings.eval_cg_tolerance.value()):  # exact_gp.py:324
             predictive_mean, predictive_covar = self.prediction_strategy.exact_prediction(full_mean, test_test_covar, test_train_covar)
-        return MultivariateNormal(predictive_mean, predictive_covar)
+        # exact_gp.py:330-333: reshape to the (possibly multitask n x T) event shape of the prior
+        cls, tail = self._posterior_class
+        if tail:
+            predictive_mean = predictive_mean.view(-1, *tail)
+        return cls(predictive_mean, predictive_covar)
 
     def _get_test_prior_mean_and_covariances(self, train_inputs, inputs, **kwargs):
         """exact_gp.py:355-430: joint train u test prior, sliced lazily."""
         full_inputs = [torch.cat([ti, inp], dim=-2) for ti, inp in zip(train_inputs, inputs)]
         full_output = Module.__call__(self, *full_inputs, **kwargs)
         full_mean, full_covar = full_output.loc, full_output.lazy_covariance_matrix
+        self._posterior_class = (full_output.__class__, tuple(full_output.event_shape[1:]))
         n = self.prediction_strategy.num_train
         test_mean = full_mean[..., n:]
         test_test_covar = full_covar[n:, n:].evaluate_kernel()

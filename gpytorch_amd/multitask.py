@@ -1,0 +1,460 @@
+"""Multitask exact GPs on the fused path (BASELINE config 5).
+
+Mirrors ``gpytorch/kernels/index_kernel.py:91-112`` (K_TT = B B^T + diag(v)),
+``gpytorch/kernels/multitask_kernel.py:46-61`` (K = K_XX (x) K_TT as a Kronecker operator),
+``gpytorch/means/multitask_mean.py:41-45``, ``gpytorch/distributions/multitask_multivariate_normal.py:34-71``
+(interleaved layout: row = i*T + tau) and ``gpytorch/likelihoods/multitask_gaussian_likelihood.py:76-154``
+(noise I_n (x) (D_T + s2 I_T)).
+
+The reference solves K_XX (x) K_TT + noise through per-factor eigendecompositions of K_XX -- O(n^3), infeasible
+at n = 2e5.  Here, as BASELINE config 5 prescribes, the system is solved by batched CG with the Kronecker MVM
+    vec^-1(V) -> K_XX . V_mat . K_TT^T
+whose n^2 part is ONE fused K*V launch with T*t columns (columns = (task, probe) pairs); the T x T factor and the
+(de)interleaving are O(n T t) glue.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import backend as B
+from . import settings
+from .bbmm import slq_logdet
+from .distributions import MultivariateNormal
+from .functions import KernelSpec, hyper_grads
+from .kernels import Kernel
+from .lanczos import root_inv_decomposition
+from .likelihoods import _GaussianLikelihoodBase
+from .linear_cg import linear_cg
+from .means import Mean
+from .module import GreaterThan, Module, Positive
+from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator
+
+
+# ------------------------------------------------------------------------------------------------ layout helpers
+def _deinterleave(vt: torch.Tensor, n: int, T: int) -> torch.Tensor:
+    """[t, >= n*T] interleaved (i*T + tau)  ->  probe-major [(t*T), ld_n] with row (c, tau)."""
+    t = vt.shape[0]
+    out = torch.zeros(t * T, B.round_up(n, 4), device=vt.device, dtype=torch.float32)
+    out[:, :n] = vt[:, : n * T].reshape(t, n, T).permute(0, 2, 1).reshape(t * T, n)
+    return out
+
+
+def _interleave(q: torch.Tensor, t: int, n: int, T: int) -> torch.Tensor:
+    """[(t*T), >= n] rows (c, tau)  ->  [t, ld_{nT}] interleaved."""
+    out = torch.zeros(t, B.round_up(n * T, 4), device=q.device, dtype=torch.float32)
+    out[:, : n * T] = q[:, :n].reshape(t, T, n).permute(0, 2, 1).reshape(t, n * T)
+    return out
+
+
+def kron_matvec(p1: B.PreparedPoints, p2: B.PreparedPoints, ktt: torch.Tensor, vt: torch.Tensor, scale=None) -> torch.Tensor:
+    """(scale * K(x1,x2) (x) K_TT) @ V for V = vt [t, >= n2*T] interleaved; returns [t, ld_{n1 T}] interleaved."""
+    T = ktt.shape[-1]
+    t = vt.shape[0]
+    w = _deinterleave(vt, p2.n, T)
+    q = B.kv(p1, p2, w, scale=scale)  # [(t*T), ld_n1]: K_XX @ V_mat, one fused launch with T*t columns
+    q3 = torch.einsum("ab,cbn->can", ktt.to(torch.float32), q[:, : p1.n].reshape(t, T, p1.n))
+    return _interleave(q3.reshape(t * T, p1.n), t, p1.n, T)
+
+
+# ------------------------------------------------------------------------------------------------ operators
+class KroneckerFusedLinearOperator(LinearOperator):
+    """K_XX (x) K_TT with K_XX a :class:`FusedKernelLinearOperator` and K_TT a dense T x T tensor."""
+
+    def __init__(self, kx: FusedKernelLinearOperator, ktt: torch.Tensor):
+        self.kx, self.ktt = kx, ktt
+        self.T = ktt.shape[-1]
+
+    dtype = property(lambda self: self.kx.dtype)
+    device = property(lambda self: self.kx.device)
+
+    def _size(self):
+        s = self.kx.shape
+        return torch.Size([s[0] * self.T, s[1] * self.T])
+
+    def _matmul(self, rhs):
+        p1, p2 = self.kx.prepared()
+        out_t = kron_matvec(p1, p2, self.ktt.detach(), B.to_probe_major(rhs), self.kx._os())
+        return B.from_probe_major(out_t, self.shape[0]).to(rhs.dtype)
+
+    def _transpose_nonbatch(self):
+        return KroneckerFusedLinearOperator(self.kx._transpose_nonbatch(), self.ktt.mT)
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return (self.kx.diagonal().unsqueeze(-1) * self.ktt.diagonal().unsqueeze(0)).reshape(-1)
+
+    def to_dense(self):
+        return torch.kron(self.kx.to_dense(), self.ktt.to(self.dtype))
+
+    def __getitem__(self, index):
+        r, c = index if isinstance(index, tuple) else (index, slice(None))
+        T = self.T
+
+        def data_slice(sl, n):
+            a, b, step = sl.indices(n * T)
+            if step != 1 or a % T or b % T:
+                raise NotImplementedError("Kronecker operator slices must be aligned to whole data points")
+            return slice(a // T, b // T)
+
+        if isinstance(r, slice) and isinstance(c, slice):
+            return KroneckerFusedLinearOperator(self.kx[data_slice(r, self.kx.shape[0]), data_slice(c, self.kx.shape[1])], self.ktt)
+        return self.to_dense()[index]
+
+    def __add__(self, other):
+        if isinstance(other, TaskNoiseDiagLinearOperator) and self.is_square:
+            return KroneckerFusedAddedDiagLinearOperator(self, other.task_noise)
+        return super().__add__(other)
+
+    def detach(self):
+        return KroneckerFusedLinearOperator(self.kx.detach(), self.ktt.detach())
+
+
+class TaskNoiseDiagLinearOperator(DiagLinearOperator):
+    """I_n (x) diag(task_noise): the noise covariance of MultitaskGaussianLikelihood (rank 0)."""
+
+    def __init__(self, task_noise: torch.Tensor, n: int):
+        self.task_noise, self.n = task_noise, n
+
+    @property
+    def _diag(self):
+        return self.task_noise.repeat(self.n)
+
+
+class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
+    """K_XX (x) K_TT + I_n (x) diag(task_noise): solved by mBCG over the Kronecker MVM."""
+
+    def __init__(self, kron: KroneckerFusedLinearOperator, task_noise: torch.Tensor, bbmm_opts=None):
+        self.kron, self.task_noise = kron, task_noise
+        self.bbmm_opts = {} if bbmm_opts is None else bbmm_opts
+        self._cache = {}
+
+    dtype = property(lambda self: self.kron.dtype)
+    device = property(lambda self: self.kron.device)
+
+    def _size(self):
+        return self.kron._size()
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def _dvec(self):
+        n, T = self.kron.kx.shape[0], self.kron.T
+        dv = torch.zeros(B.round_up(n * T, 4), device=self.device, dtype=torch.float32)
+        dv[: n * T] = self.task_noise.detach().to(torch.float32).repeat(n)
+        return dv
+
+    def _matmul(self, rhs):
+        return self.kron._matmul(rhs) + self.task_noise.detach().repeat(self.kron.kx.shape[0]).unsqueeze(-1) * rhs
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return self.kron.diagonal() + self.task_noise.repeat(self.kron.kx.shape[0])
+
+    def to_dense(self):
+        return self.kron.to_dense() + torch.diag(self.task_noise.repeat(self.kron.kx.shape[0]).to(self.dtype))
+
+    def detach(self):
+        return KroneckerFusedAddedDiagLinearOperator(self.kron.detach(), self.task_noise.detach(), self.bbmm_opts)
+
+    def __add__(self, other):
+        if isinstance(other, TaskNoiseDiagLinearOperator):
+            return KroneckerFusedAddedDiagLinearOperator(self.kron, self.task_noise + other.task_noise, self.bbmm_opts)
+        return super().__add__(other)
+
+    def _use_cholesky(self, flag):
+        return flag.off() or self.shape[-1] <= settings.max_cholesky_size.value()
+
+    def _cg(self, rhs_t, n_tridiag=0, tolerance=None):
+        p1, _ = self.kron.kx.prepared()
+        ktt, os_ = self.kron.ktt.detach(), self.kron.kx._os()
+        N = self.shape[-1]
+
+        def partials(dt):
+            out = kron_matvec(p1, p1, ktt, dt, os_)
+            return out, 1, out.stride(0)
+
+        return linear_cg(None, None, None, rhs_t, n_tridiag=n_tridiag, tolerance=tolerance, kv_partials=partials,
+                         dvec=self._dvec(), nvec=N, group=self.bbmm_opts.get("group"))
+
+    def solve(self, rhs, lhs=None):
+        squeeze = rhs.dim() == 1
+        r = rhs.unsqueeze(-1) if squeeze else rhs
+        if self._use_cholesky(settings.fast_computations.solves):
+            sol = torch.cholesky_solve(r.detach().double(), torch.linalg.cholesky(self.to_dense().detach().double())).to(rhs.dtype)
+        else:
+            sol_t, info = self._cg(B.to_probe_major(r.detach()), tolerance=settings.cg_tolerance.value())
+            self._cache["last_cg_info"] = info
+            sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
+        if lhs is not None:
+            sol = lhs @ sol
+        return sol.squeeze(-1) if squeeze else sol
+
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        kx = self.kron.kx
+        N = self.shape[-1]
+        rhs = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
+        if self._use_cholesky(settings.fast_computations.log_prob):
+            K = self.to_dense_differentiable()
+            Lc = torch.linalg.cholesky(K.double())
+            sol = torch.cholesky_solve(rhs.double(), Lc)
+            iq = (sol * rhs.double()).sum(-2).to(rhs.dtype)
+            ld = (2.0 * Lc.diagonal().log().sum()).to(rhs.dtype)
+        else:
+            iq, ld = KroneckerInvQuadLogdetFn.apply(kx.x1, kx.lengthscale, kx.outputscale, self.kron.ktt, self.task_noise, rhs,
+                                                    kx.spec, self.bbmm_opts)
+        if reduce_inv_quad:
+            iq = iq.sum(-1)
+        _ = N
+        return iq, (ld if logdet else None)
+
+    def to_dense_differentiable(self):
+        """Small-n Cholesky branch: dense K_hat built with autograd-visible torch ops on the device."""
+        kx = self.kron.kx
+        z1 = (kx.x1 - kx.spec.shift) / kx.lengthscale
+        d2 = (z1.unsqueeze(-2) - z1.unsqueeze(-3)).pow(2).sum(-1)
+        if kx.spec.kind == "rbf":
+            kmat = torch.exp(-0.5 * d2)
+        else:
+            nu = {"matern12": 0.5, "matern32": 1.5, "matern52": 2.5}[kx.spec.kind]
+            r = (d2 + 1e-20).sqrt() * (2 * nu) ** 0.5
+            e = torch.exp(-r)
+            kmat = e if nu == 0.5 else ((1 + r) * e if nu == 1.5 else (1 + r + r * r / 3) * e)
+        if kx.outputscale is not None:
+            kmat = kmat * kx.outputscale.reshape(())
+        return torch.kron(kmat, self.kron.ktt) + torch.diag(self.task_noise.repeat(kx.shape[0]))
+
+    def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
+        if self._use_cholesky(settings.fast_computations.covar_root_decomposition):
+            return super().root_inv_decomposition()
+        p1, _ = self.kron.kx.prepared()
+        ktt, os_, dv = self.kron.ktt.detach(), self.kron.kx._os(), self._dvec()
+        N = self.shape[-1]
+
+        def mv(q_row):
+            return kron_matvec(p1, p1, ktt, q_row, os_) + dv.unsqueeze(0) * q_row
+
+        rt = root_inv_decomposition(None, None, None, matvec=mv, nvec=N, device=self.device)
+        return RootLinearOperator(B.from_probe_major(rt, N).to(self.dtype))
+
+
+class KroneckerInvQuadLogdetFn(torch.autograd.Function):
+    """inv_quad / log-det of K_XX (x) K_TT + I (x) diag(task_noise) by mBCG + SLQ, with the A.6 backward
+    specialised to the Kronecker structure (one fused bilinear-derivative launch + one fused K*V launch)."""
+
+    @staticmethod
+    def forward(ctx, x, lengthscale, outputscale, ktt, task_noise, rhs, spec: KernelSpec, opts: dict):
+        n, T = x.shape[-2], ktt.shape[-1]
+        N = n * T
+        dev = x.device
+        xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        ktt_d = ktt.detach().to(torch.float32)
+        t = opts.get("num_probes") or settings.num_trace_samples.value()
+        ld = B.round_up(N, 4)
+        zt = torch.zeros(t, ld, device=dev, dtype=torch.float32)
+        probes = opts.get("probes")
+        if probes is None and settings.deterministic_probes.on() and settings.deterministic_probes.probe_vectors is not None:
+            probes = settings.deterministic_probes.probe_vectors
+        if probes is not None:
+            t = probes.shape[-1]
+            zt = torch.zeros(t, ld, device=dev, dtype=torch.float32)
+            zt[:, :N] = probes.to(device=dev, dtype=torch.float32).t()
+        else:
+            zt[:, :N] = torch.randint(0, 2, (t, N), device=dev, generator=opts.get("generator"), dtype=torch.int8).float() * 2 - 1
+        znorm = B.coldot(zt, zt, N).sqrt()
+        zt.div_(znorm.unsqueeze(-1))
+        rhs_t = B.to_probe_major(rhs)
+        dv = torch.zeros(ld, device=dev, dtype=torch.float32)
+        dv[:N] = task_noise.detach().to(torch.float32).repeat(n)
+
+        def partials(dt):
+            out = kron_matvec(xp, xp, ktt_d, dt, os_)
+            return out, 1, out.stride(0)
+
+        solves_t, info = linear_cg(None, None, None, torch.cat([zt, rhs_t], 0).contiguous(), n_tridiag=t, tolerance=opts.get("tolerance"),
+                                   kv_partials=partials, dvec=dv, nvec=N)
+        logdet = slq_logdet(info.t_mats, N).to(device=dev, dtype=torch.float32)
+        c = rhs_t.shape[0]
+        inv_quad = B.coldot(solves_t[t : t + c], rhs_t, N)
+        ctx.xp, ctx.n, ctx.T, ctx.t = xp, n, T, t
+        ctx.solves_t, ctx.zt, ctx.znorm = solves_t, zt, znorm
+        ctx.has_os = outputscale is not None
+        ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0), ktt, task_noise, rhs)
+        opts["_last_info"] = info
+        return inv_quad.to(rhs.dtype), logdet.to(rhs.dtype)
+
+    @staticmethod
+    def backward(ctx, g_iq, g_ld):
+        lengthscale, outputscale, ktt, task_noise, rhs = ctx.saved_tensors
+        outputscale = outputscale if ctx.has_os else None
+        xp, n, T, t = ctx.xp, ctx.n, ctx.T, ctx.t
+        N = n * T
+        c = ctx.solves_t.shape[0] - t
+        g_iq = g_iq.to(torch.float32).reshape(c, 1)
+        g_ld = g_ld.to(torch.float32).reshape(())
+        s_z = ctx.solves_t[:t] * ctx.znorm.unsqueeze(-1)
+        s_y = ctx.solves_t[t:]
+        zr = ctx.zt * ctx.znorm.unsqueeze(-1)
+        left = torch.cat([s_z * (g_ld / t), -s_y * g_iq], 0)
+        right = torch.cat([zr, s_y], 0)
+        tc = t + c
+        l3 = left[:, :N].reshape(tc, n, T).permute(0, 2, 1).contiguous()   # [tc, T, n]
+        r3 = right[:, :N].reshape(tc, n, T).permute(0, 2, 1).contiguous()
+        ktt32 = ktt.detach().to(torch.float32)
+        r3k = torch.einsum("ab,cbn->can", ktt32, r3)
+        ld_n = B.round_up(n, 4)
+
+        def pad(v3):
+            out = torch.zeros(tc * T, ld_n, device=v3.device, dtype=torch.float32)
+            out[:, :n] = v3.reshape(tc * T, n)
+            return out
+
+        lp = pad(l3)
+        d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, lp, pad(r3k))
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        m3 = B.kv(xp, xp, pad(r3), scale=os_)[:, :n].reshape(tc, T, n)
+        d_ktt = torch.einsum("ctn,csn->ts", l3, m3).to(ktt.dtype)
+        d_noise = (l3 * r3).sum(dim=(0, 2)).to(task_noise.dtype)
+        d_rhs = (2.0 * B.from_probe_major(s_y, N) * g_iq.reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[5] else None
+        return None, d_ls, d_os, d_ktt, d_noise, d_rhs, None, None
+
+
+# ------------------------------------------------------------------------------------------------ modules
+class IndexKernel(Kernel):
+    """``gpytorch/kernels/index_kernel.py``: K_TT = B B^T + diag(v)."""
+
+    def __init__(self, num_tasks: int, rank: int = 1, prior=None, var_constraint=None, **kwargs):
+        if rank > num_tasks:
+            raise RuntimeError("Cannot create a task covariance matrix larger than the number of tasks")
+        super().__init__(**kwargs)
+        self.register_parameter("covar_factor", torch.nn.Parameter(torch.randn(num_tasks, rank)))
+        self.register_parameter("raw_var", torch.nn.Parameter(torch.randn(num_tasks)))
+        self.register_constraint("raw_var", Positive() if var_constraint is None else var_constraint)
+
+    @property
+    def var(self):
+        return self._get_transformed("raw_var")
+
+    @var.setter
+    def var(self, value):
+        self._set_transformed("raw_var", value)
+
+    @property
+    def covar_matrix(self):
+        return self.covar_factor @ self.covar_factor.mT + torch.diag(self.var)  # index_kernel.py:91-99
+
+
+class MultitaskKernel(Kernel):
+    """``gpytorch/kernels/multitask_kernel.py:46-61``."""
+
+    def __init__(self, data_covar_module, num_tasks: int, rank: int = 1, task_covar_prior=None, **kwargs):
+        super().__init__(**kwargs)
+        self.task_covar_module = IndexKernel(num_tasks=num_tasks, rank=rank, prior=task_covar_prior)
+        self.data_covar_module = data_covar_module
+        self.num_tasks = num_tasks
+
+    def __call__(self, x1, x2=None, diag=False, **params):
+        return self.forward(x1, x2, diag=diag, **params)
+
+    def forward(self, x1, x2, diag=False, **params):
+        covar_x = self.data_covar_module(x1, x2, **params)
+        res = KroneckerFusedLinearOperator(covar_x, self.task_covar_module.covar_matrix)
+        return res.diagonal() if diag else res
+
+    def num_outputs_per_input(self, x1, x2):
+        return self.num_tasks
+
+
+class MultitaskMean(Mean):
+    """``gpytorch/means/multitask_mean.py:41-45``: one base mean per task, stacked on the last dimension."""
+
+    def __init__(self, base_means, num_tasks: int):
+        super().__init__()
+        if isinstance(base_means, Mean):
+            base_means = [base_means]
+        if len(base_means) == 1:
+            import copy
+
+            base_means = base_means + [copy.deepcopy(base_means[0]) for _ in range(num_tasks - 1)]
+        if len(base_means) != num_tasks:
+            raise RuntimeError("base_means should be a list of means of length either 1 or num_tasks")
+        self.base_means = torch.nn.ModuleList(base_means)
+        self.num_tasks = num_tasks
+
+    def forward(self, x):
+        return torch.cat([m(x).unsqueeze(-1) for m in self.base_means], dim=-1)
+
+
+class MultitaskMultivariateNormal(MultivariateNormal):
+    """n x T event, interleaved flattening row = i*T + tau (multitask_multivariate_normal.py:34-71)."""
+
+    def __init__(self, mean: torch.Tensor, covariance_matrix, validate_args=False, interleaved=True):
+        if not interleaved:
+            raise NotImplementedError("only the interleaved (data-major, task-minor) layout is implemented")
+        self._output_shape = mean.shape
+        super().__init__(mean.reshape(-1), covariance_matrix)
+
+    @property
+    def event_shape(self):
+        return self._output_shape[-2:]
+
+    @property
+    def num_tasks(self):
+        return self._output_shape[-1]
+
+    @property
+    def mean(self):
+        return self.loc.view(self._output_shape)
+
+    @property
+    def variance(self):
+        return super().variance.view(self._output_shape)
+
+    def log_prob(self, value):
+        return super().log_prob(value.reshape(-1))
+
+
+class MultitaskGaussianLikelihood(_GaussianLikelihoodBase):
+    """``gpytorch/likelihoods/multitask_gaussian_likelihood.py`` with rank = 0: noise I_n (x) (diag(task_noises) + noise I_T)."""
+
+    def __init__(self, num_tasks: int, rank: int = 0, noise_constraint=None, has_global_noise=True, has_task_noise=True, **kwargs):
+        if rank != 0:
+            raise NotImplementedError("inter-task noise correlations (rank > 0) are not implemented")
+        Module.__init__(self)
+        self.num_tasks = num_tasks
+        self.has_global_noise, self.has_task_noise = has_global_noise, has_task_noise
+        if has_task_noise:
+            self.register_parameter("raw_task_noises", torch.nn.Parameter(torch.zeros(num_tasks)))
+            self.register_constraint("raw_task_noises", GreaterThan(1e-4) if noise_constraint is None else noise_constraint)
+        if has_global_noise:
+            self.register_parameter("raw_noise", torch.nn.Parameter(torch.zeros(1)))
+            self.register_constraint("raw_noise", GreaterThan(1e-4) if noise_constraint is None else noise_constraint)
+
+    @property
+    def task_noises(self):
+        return self._get_transformed("raw_task_noises")
+
+    @task_noises.setter
+    def task_noises(self, value):
+        self._set_transformed("raw_task_noises", value)
+
+    @property
+    def noise(self):
+        return self._get_transformed("raw_noise")
+
+    @noise.setter
+    def noise(self, value):
+        self._set_transformed("raw_noise", value)
+
+    def _task_noise_vector(self):
+        dev = (self.raw_task_noises if self.has_task_noise else self.raw_noise).device
+        out = torch.zeros(self.num_tasks, device=dev)
+        if self.has_task_noise:
+            out = out + self.task_noises
+        if self.has_global_noise:
+            out = out + self.noise
+        return out
+
+    def marginal(self, function_dist, *params, **kwargs):
+        mean, covar = function_dist.mean, function_dist.lazy_covariance_matrix
+        n = covar.shape[-1] // self.num_tasks
+        covar = covar + TaskNoiseDiagLinearOperator(self._task_noise_vector(), n)
+        return function_dist.__class__(mean, covar)

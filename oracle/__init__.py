@@ -26,4 +26,4 @@ Pinning status
   results against dense Cholesky (solve, log-det given probes, predictive
   mean/variance) within the tolerances the reference's own tests use.
 """
-from . import kernels, linear_cg, pivoted_cholesky, lanczos, slq, exact_gp  # noqa: F401
+from . import kernels, linear_cg, pivoted_cholesky, lanczos, slq, exact_gp, multitask  # noqa: F401

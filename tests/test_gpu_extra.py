@@ -72,7 +72,9 @@ def test_fixed_heteroskedastic_noise(dev):
     mu_ref = Ksx @ torch.linalg.solve(Kh, y)
     var_ref = 1.1 - (Ksx * torch.linalg.solve(Kh, Ksx.t()).t()).sum(-1)
     assert rel_err(pred.mean, mu_ref) < 1e-3
-    assert ((pred.variance.double().cpu() - var_ref).abs() / var_ref).max() < 5e-3
+    # latent (noise-free) variances are as small as 5e-3 here: the eval-CG tolerance (1e-4 relative to the prior
+    # variance 1.1) bounds the ABSOLUTE error
+    assert (pred.variance.double().cpu() - var_ref).abs().max() < 5e-4
 
 
 def test_training_loop_with_cg_forced(dev):
