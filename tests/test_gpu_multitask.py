@@ -65,13 +65,15 @@ def test_kronecker_matmul_and_diag(dev):
 
 @pytest.mark.parametrize("branch", ["cholesky", "bbmm"])
 def test_multitask_mll_and_grads(branch, dev):
-    n = 200 if branch == "cholesky" else 900
+    n = 200 if branch == "cholesky" else 160
     X, Y = _data(n, 2)
     g, m, lik = _model(X, Y, dev, **PARAMS)
     mll = g.ExactMarginalLogLikelihood(lik, m)
     m.train(); lik.train()
     S = g.settings
-    Z = torch.randn(n * T, 64, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
+    # bbmm branch: a COMPLETE probe basis sqrt(N) e_k makes the Hutchinson trace exact, so the A.6 backward on the
+    # Kronecker operator can be compared with the dense autograd gradient deterministically
+    Z = math.sqrt(n * T) * torch.eye(n * T, dtype=torch.float64)
     S.deterministic_probes.probe_vectors = Z
     try:
         with S.max_cholesky_size(10_000 if branch == "cholesky" else 0), S.cg_tolerance(1e-4), S.deterministic_probes(True):
@@ -80,7 +82,7 @@ def test_multitask_mll_and_grads(branch, dev):
     finally:
         S.deterministic_probes.probe_vectors = None
     ref, gref = OM.dense_mll_and_grads("rbf", X, Y, 0.35, 1.0, PARAMS["Bf"], PARAMS["v"], PARAMS["tn"])
-    tol_v, tol_g = (2e-4, 2e-3) if branch == "cholesky" else (0.02, 0.25)  # bbmm: 64-probe SLQ / trace estimates
+    tol_v, tol_g = (2e-4, 2e-3) if branch == "cholesky" else (5e-3, 2e-2)  # bbmm: 20-step SLQ value, exact-trace gradient
     assert abs(float(val) - float(ref)) < tol_v * max(1.0, abs(float(ref)))
     sg = lambda a: 1.0 - torch.exp(-a)  # noqa: E731  d softplus / d raw at the given actual value
     got_ls = float(m.covar_module.data_covar_module.raw_lengthscale.grad.sum())
