@@ -46,7 +46,7 @@ SIGNATURES = {
     "gpamd_cg_finish_f32": (_i, [_p, _p]),
     "gpamd_pivoted_cholesky_f32": (_i, [_i, _p, _i, _i, _p, _i, _f, _p, _i64, _p, _p, _p, _p]),
     "gpamd_kv_grad_workspace_doubles": (_i64, [_i, _i, _i, _i]),
-    "gpamd_kv_grad_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p]),
+    "gpamd_kv_grad_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p]),
 }
 
 

@@ -226,7 +226,7 @@ def pivoted_cholesky(xp: PreparedPoints, scale, rank: int, tol: float):
     return L[:m, :n], piv[:m], m
 
 
-def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor) -> torch.Tensor:
+def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor, iso: bool = False) -> torch.Tensor:
     """Fused bilinear derivative with W = lt^T rt (lt: [t, ld_n] over x1, rt: [t, ld_m] over x2).
 
     Returns float32 [1 + dp]:  g[0] = sum_ij W_ij k_ij;  g[1+q] = sum_ij W_ij dk/ds_ij (z_iq - z_jq)^2
@@ -241,7 +241,7 @@ def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.
     check(
         lib().gpamd_kv_grad_f32(
             KIND_IDS[x1.kind], _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.dp, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0),
-            t, _ptr(out), _ptr(ws), nd, _stream(dev),
+            t, 1 if iso else 0, _ptr(out), _ptr(ws), nd, _stream(dev),
         ),
         "kv_grad",
     )

@@ -45,11 +45,11 @@ void grad_plan(int n, int m, int* S, int* jchunk, int* nrb) {
   *S = (m + jc - 1) / jc;
 }
 
-template <int KIND>
+template <int KIND, int ISO>
 int launch_grad(int dp, const GradArgs& a, unsigned grid, size_t lds, hipStream_t st) {
 #define L(DPV)                                                                                                  \
   case DPV: {                                                                                                   \
-    auto kfn = kv_grad_kernel<KIND, DPV>;                                                                       \
+    auto kfn = kv_grad_kernel<KIND, DPV, ISO>;                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);                                                 \
     return 0;                                                                                                   \
@@ -71,8 +71,8 @@ int64_t gpamd_kv_grad_workspace_doubles(int n, int m, int t, int dp) {
 }
 
 int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Lt, int64_t ldl,
-                      const float* Rt, int64_t ldr, int t, float* out, double* workspace, int64_t workspace_doubles,
-                      void* stream) {
+                      const float* Rt, int64_t ldr, int t, int iso, float* out, double* workspace,
+                      int64_t workspace_doubles, void* stream) {
   if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m) {
     snprintf(g_err2, sizeof(g_err2), "kv_grad: bad arguments");
     return GPAMD_EINVAL;
@@ -99,10 +99,10 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
     const size_t lds = ((size_t)4 * 2 * th * 32 + (size_t)4 * 64 * dp) * sizeof(float);
     int rc = -2;
     switch (kind) {
-      case GPAMD_RBF: rc = launch_grad<KIND_RBF>(dp, a, (unsigned)units, lds, st); break;
-      case GPAMD_MATERN12: rc = launch_grad<KIND_MATERN12>(dp, a, (unsigned)units, lds, st); break;
-      case GPAMD_MATERN32: rc = launch_grad<KIND_MATERN32>(dp, a, (unsigned)units, lds, st); break;
-      case GPAMD_MATERN52: rc = launch_grad<KIND_MATERN52>(dp, a, (unsigned)units, lds, st); break;
+      case GPAMD_RBF: rc = iso ? launch_grad<KIND_RBF, 1>(dp, a, (unsigned)units, lds, st) : launch_grad<KIND_RBF, 0>(dp, a, (unsigned)units, lds, st); break;
+      case GPAMD_MATERN12: rc = iso ? launch_grad<KIND_MATERN12, 1>(dp, a, (unsigned)units, lds, st) : launch_grad<KIND_MATERN12, 0>(dp, a, (unsigned)units, lds, st); break;
+      case GPAMD_MATERN32: rc = iso ? launch_grad<KIND_MATERN32, 1>(dp, a, (unsigned)units, lds, st) : launch_grad<KIND_MATERN32, 0>(dp, a, (unsigned)units, lds, st); break;
+      case GPAMD_MATERN52: rc = iso ? launch_grad<KIND_MATERN52, 1>(dp, a, (unsigned)units, lds, st) : launch_grad<KIND_MATERN52, 0>(dp, a, (unsigned)units, lds, st); break;
     }
     if (rc) return GPAMD_EUNSUPPORTED;
   }

@@ -31,7 +31,7 @@ struct GradArgs {
   double* part;        // [nrb*S][1 + DP]
 };
 
-template <int KIND, int DP>
+template <int KIND, int DP, int ISO>
 __global__ __launch_bounds__(256) void kv_grad_kernel(GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   constexpr int DQ = DP / 4;
@@ -111,16 +111,25 @@ __global__ __launch_bounds__(256) void kv_grad_kernel(GradArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float df = xi[4 * q + e] - v[e];
-            df2[4 * q + e] = df * df;
-            sq += df2[4 * q + e];
+            if constexpr (ISO) {
+              sq = __builtin_fmaf(df, df, sq);
+            } else {
+              df2[4 * q + e] = df * df;
+              sq += df2[4 * q + e];
+            }
           }
         }
         const float kv = cov_from_sq<KIND>(sq);
         const float dk = dcov_dsq<KIND>(sq);
         f[0] = __builtin_fmaf(w, kv, f[0]);
         const float wd = w * dk;
+        if constexpr (ISO) {
+          // single lengthscale: sum_q (z_iq - z_jq)^2 = s, one fma instead of DP multiplies + DP fmas
+          f[1] = __builtin_fmaf(wd, sq, f[1]);
+        } else {
 #pragma unroll
-        for (int q = 0; q < DP; ++q) f[1 + q] = __builtin_fmaf(wd, df2[q], f[1 + q]);
+          for (int q = 0; q < DP; ++q) f[1 + q] = __builtin_fmaf(wd, df2[q], f[1 + q]);
+        }
       }
     }
 #pragma unroll

@@ -32,10 +32,10 @@ class KernelSpec:
 
 def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t):
     """d/d(lengthscale), d/d(outputscale) of sum_c left[c]^T (outputscale * k(x1, x2)) right[c]."""
-    g = B.kv_grad(xp1, xp2, left_t, right_t)
+    ls = lengthscale.detach().to(torch.float32).reshape(-1)
+    g = B.kv_grad(xp1, xp2, left_t, right_t, iso=ls.numel() == 1)
     d = xp1.d
     theta = 1.0 if outputscale is None else outputscale.detach().reshape(()).to(torch.float32)
-    ls = lengthscale.detach().to(torch.float32).reshape(-1)
     gq = g[1 : 1 + d]
     if ls.numel() == 1:
         d_ls = (theta * (-2.0) / ls * gq.sum()).reshape(lengthscale.shape)

@@ -131,11 +131,12 @@ int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const f
 /* ---- fused bilinear derivative: out[0] = sum_ij W_ij k_ij, out[1+q] = sum_ij W_ij dk/ds_ij (z_iq - z_jq)^2,
  * W = Lt^T Rt (never formed).  Replaces LinearOperator._bilinear_derivative on the kernel operator and the
  * dense backward of gpytorch/functions/rbf_covariance.py:26-29 / matern_covariance.py:53-56 (chunked variant:
- * gpytorch/lazy/lazy_evaluated_kernel_tensor.py:69-104).  out: float[1 + dp]; workspace: double[>= the query]. ---- */
+ * gpytorch/lazy/lazy_evaluated_kernel_tensor.py:69-104).  out: float[1 + dp]; workspace: double[>= the query].
+ * iso != 0 (single lengthscale): out[1] = sum_ij W_ij dk/ds_ij s_ij and out[2..] = 0 (cheaper epilogue). ---- */
 int64_t gpamd_kv_grad_workspace_doubles(int n, int m, int t, int dp);
 int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Lt, int64_t ldl,
-                      const float* Rt, int64_t ldr, int t, float* out, double* workspace, int64_t workspace_doubles,
-                      void* stream);
+                      const float* Rt, int64_t ldr, int t, int iso, float* out, double* workspace,
+                      int64_t workspace_doubles, void* stream);
 
 #ifdef __cplusplus
 }
