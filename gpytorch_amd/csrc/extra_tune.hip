@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kv_mfma_tune.hpp"
+#include "kv_gram.hpp"
 
 using namespace gpamd;
 
@@ -45,7 +46,7 @@ struct VariantDesc {
 
 extern "C" {
 
-int gpamd_kv_variant_count(void) { return 26; }
+int gpamd_kv_variant_count(void) { return 28; }
 
 int gpamd_kv_variant_info(int variant, int* bm_host, int* bn_host) {
   switch (variant) {
@@ -56,6 +57,11 @@ int gpamd_kv_variant_info(int variant, int* bm_host, int* bn_host) {
     return 0;
     VARIANTS(X)
 #undef X
+    case 26:
+    case 27:
+      *bm_host = 256;
+      *bn_host = 128;
+      return 0;
   }
   return GPAMD_EINVAL;
 }
@@ -77,6 +83,14 @@ int gpamd_kv_partials_variant_f32(int variant, const float* X1p, int n, const fl
   }
     VARIANTS(X)
 #undef X
+    case 26:  // Gram-form generation (product kernel), two distance tiles live
+      a.nrb = (n + 255) / 256;
+      hipLaunchKernelGGL((kv_gram_kernel<KIND_RBF, 3, 2, 2, 1, 0>), dim3((unsigned)a.nrb * S), dim3(256), 0, (hipStream_t)stream, a);
+      break;
+    case 27:  // Gram-form, row tiles sequential, forced to three waves per SIMD
+      a.nrb = (n + 255) / 256;
+      hipLaunchKernelGGL((kv_gram_kernel<KIND_RBF, 3, 2, 2, 1, 1>), dim3((unsigned)a.nrb * S), dim3(256), 0, (hipStream_t)stream, a);
+      break;
     default:
       return GPAMD_EINVAL;
   }

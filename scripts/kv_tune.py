@@ -26,7 +26,7 @@ h.gpamd_kv_partials_variant_f32.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_vo
                                             C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
 torch.manual_seed(0)
 X = torch.rand(n, d, device=dev)
-xp = B.prep_points("rbf", X, torch.tensor(0.25))
+xp = B.prep_points("rbf", X, torch.tensor(0.25), X.mean(0))
 ld = B.round_up(n, 4)
 V = torch.randn(t, ld, device=dev)
 V[:, n:] = 0
@@ -34,11 +34,12 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 nv = h.gpamd_kv_variant_count()
 ref = None
 rows = []
-for v in range(nv):
+only = [int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else list(range(nv))
+for v in only:
     bm, bn = C.c_int(0), C.c_int(0)
     h.gpamd_kv_variant_info(v, C.byref(bm), C.byref(bn))
     best = None
-    for S in (2, 3, 4, 5, 6, 7, 8, 10, 12):
+    for S in (7, 10, 12, 13, 17, 19, 23):
         jc = ((n + S - 1) // S + bn.value - 1) // bn.value * bn.value
         Se = (n + jc - 1) // jc
         P = torch.zeros(Se, t, ld, device=dev)
