@@ -46,7 +46,7 @@ struct VariantDesc {
 
 extern "C" {
 
-int gpamd_kv_variant_count(void) { return 28; }
+int gpamd_kv_variant_count(void) { return 27; }
 
 int gpamd_kv_variant_info(int variant, int* bm_host, int* bn_host) {
   switch (variant) {
@@ -58,7 +58,6 @@ int gpamd_kv_variant_info(int variant, int* bm_host, int* bn_host) {
     VARIANTS(X)
 #undef X
     case 26:
-    case 27:
       *bm_host = 256;
       *bn_host = 128;
       return 0;
@@ -85,11 +84,7 @@ int gpamd_kv_partials_variant_f32(int variant, const float* X1p, int n, const fl
 #undef X
     case 26:  // Gram-form generation (product kernel), two distance tiles live
       a.nrb = (n + 255) / 256;
-      hipLaunchKernelGGL((kv_gram_kernel<KIND_RBF, 3, 2, 2, 1, 0>), dim3((unsigned)a.nrb * S), dim3(256), 0, (hipStream_t)stream, a);
-      break;
-    case 27:  // Gram-form, row tiles sequential, forced to three waves per SIMD
-      a.nrb = (n + 255) / 256;
-      hipLaunchKernelGGL((kv_gram_kernel<KIND_RBF, 3, 2, 2, 1, 1>), dim3((unsigned)a.nrb * S), dim3(256), 0, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((kv_gram_kernel<KIND_RBF, 3, 2, 2, 1>), dim3((unsigned)a.nrb * S), dim3(256), 0, (hipStream_t)stream, a);
       break;
     default:
       return GPAMD_EINVAL;

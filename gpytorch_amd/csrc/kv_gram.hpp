@@ -15,13 +15,18 @@
 // fp32 (the reference's fp32 path has the same error; it mean-centres for this reason).  The host only
 // selects this kernel when max |z|^2 (after centring) <= 32, i.e. a relative error <= 1e-5 in K, and never
 // for Matern nu = 1/2 (k = exp(-sqrt(s)) is not Lipschitz in s at 0).  Otherwise kv_mfma.hpp is used.
+//
+// Tried and measured without gain on MI355X (profiles/r01_s13_kv_tune_gram_seq_prefetch.jsonl): row tiles one after
+// the other with occupancy forced to three waves/SIMD (+1 %, needs spills), register prefetch of the next tile
+// across the MFMA phase (0 %), both together (-4 %).  The structure sits at ~122 TFLOP/s; the same loop without
+// any generation reaches 140 (profiles/r01_s4_kv_tune_variants.jsonl).
 #pragma once
 #include "kv_mfma.hpp"
 
 namespace gpamd {
 
-template <int KIND, int D, int CT, int NI, int EX, int SEQ = 0>
-__global__ __launch_bounds__(256, (SEQ ? 3 : 1)) void kv_gram_kernel(KvArgs a) {
+template <int KIND, int D, int CT, int NI, int EX>
+__global__ __launch_bounds__(256) void kv_gram_kernel(KvArgs a) {
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KA = (D + 2 + 1) / 2;   // MFMA k-steps (2 augmented coordinates each)
   constexpr int LDA = 2 * KA + 1;       // odd LDS row stride of the augmented x_j tile -> conflict-free b32 reads
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256, (SEQ ? 3 : 1)) void kv_gram_kernel(KvArgs a) {
   }
 
   constexpr int VQ = TC * (BN / 4) / 256;
-  constexpr int VCH = SEQ ? (VQ < 4 ? VQ : 4) : (VQ < 8 ? VQ : 8);
+  constexpr int VCH = VQ < 8 ? VQ : 8;
 
   auto stage_tile = [&](int j0) {
 #pragma unroll
@@ -151,48 +156,6 @@ __global__ __launch_bounds__(256, (SEQ ? 3 : 1)) void kv_gram_kernel(KvArgs a) {
     stage_tile(j0);
     __syncthreads();
 
-    if constexpr (SEQ) {
-      // row tiles one after the other: only ONE 32x32 distance tile is live (16 registers instead of NI*16),
-      // which brings the kernel under 168 registers -> three resident waves per SIMD
-#pragma unroll 1
-      for (int jb = 0; jb < BN; jb += 32) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          f32x16 kk;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) kk[r] = 0.f;
-#pragma unroll
-          for (int q = 0; q < KA; ++q) {
-            const float aq = Xa[(jb + l31) * LDA + 2 * q + h];
-            kk = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, bq[ni][q], kk, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float sv = kk[r];
-            if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-            kk[r] = cov_from_sq<KIND>(sv);
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int jl = jb + 8 * g + 4 * h;
-            f32x4 av[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(&Vs[(ct * 32 + l31) * LDT + jl]);
-            f32x4 ev;
-            if constexpr (EX) ev = *reinterpret_cast<const f32x4*>(&Es[jl]);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-#pragma unroll
-              for (int ct = 0; ct < CT; ++ct)
-                acc[ni][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct][st], kk[4 * g + st], acc[ni][ct], 0, 0, 0);
-              if constexpr (EX) eacc[ni] = __builtin_fmaf(kk[4 * g + st], ev[st], eacc[ni]);
-            }
-            __builtin_amdgcn_s_setprio(0);
-          }
-        }
-      }
-    } else {
 #pragma unroll 1
     for (int jb = 0; jb < BN; jb += 32) {
       // ---- squared distances of the 32 x (NI*32) block on the matrix pipe, then k = f(S) in place ----
@@ -240,7 +203,6 @@ __global__ __launch_bounds__(256, (SEQ ? 3 : 1)) void kv_gram_kernel(KvArgs a) {
         }
         __builtin_amdgcn_s_setprio(0);
       }
-    }
     }
   }
 

@@ -31,7 +31,8 @@ for name in ("mfma", "insts", "fetch", "write"):
 if out:
     doc = {
         "kernel": kname,
-        "workload": "fused K*V, RBF, n=100000, d=3, t=65 (scripts/kv_only.py)",
+        "workload": f"fused K*V, RBF, n={os.environ.get('KV_ONLY_N', '500000')}, d=3, t=65 (scripts/kv_only.py)",
+        "shape": [int(os.environ.get("KV_ONLY_N", "500000")), 3, 65],
         "counters": out,
         "notes": "separate rocprofv3 --pmc passes (scripts/gpu_session.sh); GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_* over all "
                  "SIMDs; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles; FETCH_SIZE / WRITE_SIZE are in KiB and FETCH_SIZE "
