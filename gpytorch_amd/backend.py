@@ -68,7 +68,7 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
     """Select the Gram-form generation kernel when it is both applicable and accurate (see kv_gram.hpp)."""
     if FORCE_KV_FLAGS is not None:
         return FORCE_KV_FLAGS
-    if x1.kind == "matern12":
+    if t <= 8 or x1.kind == "matern12":
         return 0
     return KV_GRAM if max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) <= GRAM_MAX_SQNORM else 0
 

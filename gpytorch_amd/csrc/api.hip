@@ -10,7 +10,6 @@
 #include "cg_kernels.hpp"
 #include "kv_dispatch.hpp"
 #include "kv_valu.hpp"
-#include "kv_gramv.hpp"
 #include "misc_kernels.hpp"
 
 using namespace gpamd;
@@ -112,17 +111,8 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex) {
 }
 
 int kv_mode(int kind, int flags, const KvVariant& v) {
-  const bool gram = (flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12;
-  if (v.valu) return (gram && v.tpad <= 4) ? KV_MODE_GRAMV : KV_MODE_VALU;
-  return gram ? KV_MODE_GRAM : KV_MODE_MFMA;
-}
-
-// tile geometry of the selected kernel (the small-t Gram variant uses its own row block / j tile)
-void variant_geometry(int mode, KvVariant* v) {
-  if (mode == KV_MODE_GRAMV) {
-    v->bm = KGV_BM;
-    v->bn = KGV_BN;
-  }
+  if (v.valu) return KV_MODE_VALU;
+  return ((flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12) ? KV_MODE_GRAM : KV_MODE_MFMA;
 }
 
 // resident workgroups per CU of the selected kernel (runtime occupancy query; static table without a device)
@@ -143,7 +133,6 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
   KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t);
   const int mode = kv_mode(kind, flags, v);
-  variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
   const long slots = (long)num_cus() * wg_per_cu(kind, mode, kernel_dims(d), v);
   const int min_chunk = 16 * v.bn;
@@ -225,8 +214,6 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0);
     KvVariant v = pick_variant(tg);
-    const int mode = kv_mode(kind, flags, v);
-    variant_geometry(mode, &v);
     KvArgs a;
     a.X1 = X1p; a.X2 = X2p;
     a.Vt = Vt + (int64_t)g0 * ldv;
@@ -237,7 +224,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
-    const void* fn = family_ptr(kind, mode, dk, v.valu ? v.tpad : v.ct, v.ex);
+    const void* fn = family_ptr(kind, kv_mode(kind, flags, v), dk, v.valu ? v.tpad : v.ct, v.ex);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
     void* kargs[] = {(void*)&a};
     (void)hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, 0, st);

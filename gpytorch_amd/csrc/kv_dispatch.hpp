@@ -4,7 +4,7 @@
 
 namespace gpamd {
 
-enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3 };
+enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2 };
 
 // MFMA / Gram variants: CT 32-column tiles (1..4) + EX extra VALU column; NI row tiles per wave by CT.
 // NI*CT*16 accumulator registers: 64 (CT <= 2) .. 128 (CT = 4)
