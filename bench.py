@@ -5,7 +5,7 @@ One "step" = one ExactGP marginal-log-likelihood evaluation on synthetic data of
 BASELINE.json's `metric` is quoted on -- n = 500 000, d = 3, RBF -- in the single-GPU shape of configs[1]
 (64 probe vectors + the y column per GPU, fused K*V HIP kernel, no preconditioner, reference-default
 cg_tolerance = 1): probe draw, fused K*V (MFMA) x CG iterations, device-resident CG vector updates, SLQ
-log-det, inverse quadratic form.  It fits one GPU (K is never formed: ~1.5 GB of HBM).  `--n 100000` runs
+log-det, inverse quadratic form.  It fits one GPU (K is never formed: ~1.5 GB of HBM).  `--size 100000` runs
 configs[1] itself.  Inputs are resident in HBM before the timed region.
 
   value      = algorithmic K*V flops of the step (2 n^2 (t+1) x CG iterations, summed over ranks)
@@ -136,8 +136,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=500_000)
-    ap.add_argument("--d", type=int, default=3)
+    ap.add_argument("--size", type=int, default=500_000, help="number of training points n (not --n: torch.distributed.run's parser treats that as an ambiguous prefix)")
+    ap.add_argument("--dims", type=int, default=3)
     ap.add_argument("--probes", type=int, default=64)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="skip the untimed API-level MLL fwd+bwd / posterior timings")
@@ -146,13 +146,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (one-GPU boxes): GPAMD_BENCH_BACKEND=gloo GPAMD_BENCH_SHARE_DEVICE=1 runs N ranks on cuda:0 with the
+    # stopping-rule / SLQ all-reduces carried by gloo -- same code path as RCCL apart from the transport
+    backend = os.environ.get("GPAMD_BENCH_BACKEND", "nccl")
+    if os.environ.get("GPAMD_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
         group = torch.distributed.group.WORLD
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -160,7 +168,7 @@ def main():
     from gpytorch_amd import linear_cg as LCG
     from gpytorch_amd.bbmm import LOG_2PI, inv_quad_logdet_forward
 
-    n, d, t = args.n, args.d, args.probes
+    n, d, t = args.size, args.dims, args.probes
     ls = {3: 0.25, 10: 0.8, 6: 0.5}.get(d, 0.25)
     X, y = synth(n, d)
     Xd, yd = X.to(dev), y.to(dev)
@@ -198,7 +206,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if group is not None:
-        et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        et = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(et, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(et.item())
 
@@ -246,7 +254,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"ExactGP MLL evaluation (mBCG + SLQ), RBF, n={n}, d={d}, {t} probes/GPU + y column, fused K*V HIP kernel, "
-                            "no preconditioner, cg_tolerance=1.0 (BASELINE metric config n=500k d=3 RBF; --n 100000 = configs[1])",
+                            "no preconditioner, cg_tolerance=1.0 (BASELINE metric config n=500k d=3 RBF; --size 100000 = configs[1])",
                 "n": n, "d": d, "probes_per_gpu": t, "rhs_columns": cols, "cg_iterations_per_step": iters_total / args.steps,
                 "parallelism": f"probe-sharded x{world}",
             },
