@@ -46,6 +46,24 @@ SIGNATURES = {
     "gpamd_cg_finish_f32": (_i, [_p, _p]),
     "gpamd_pivoted_cholesky_f32": (_i, [_i, _p, _i, _i, _p, _i, _f, _p, _i64, _p, _p, _p, _p]),
     "gpamd_kv_grad_workspace_doubles": (_i64, [_i, _i, _i, _i]),
+    # ---- float64 section
+    "gpamd_prep_points_f64": (_i, [_i, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
+    "gpamd_kernel_rows_f64": (_i, [_i, _p, _p, _i64, _i, _p, _i, _i, _p, _p, _i64, _p]),
+    "gpamd_kernel_diag_f64": (_i, [_i, _p, _p, _i, _i, _p, _p, _p]),
+    "gpamd_kernel_grad_block_f32": (_i, [_i, _p, _i64, _i, _p, _i, _i, _p, _i64, _p, _p]),
+    "gpamd_kernel_grad_block_f64": (_i, [_i, _p, _i64, _i, _p, _i, _i, _p, _i64, _p, _p]),
+    "gpamd_coldot_f64": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
+    "gpamd_kv_reduce_f64": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
+    "gpamd_cg64_fscratch_elems": (_i64, [_i, _i]),
+    "gpamd_cg64_create": (_p, [_i, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _i, C.c_double, C.c_double]),
+    "gpamd_cg64_destroy": (None, [_p]),
+    "gpamd_cg64_init": (_i, [_p, _p, _i64, _i, _p]),
+    "gpamd_cg64_begin": (_i, [_p, _p]),
+    "gpamd_cg64_reduce_q": (_i, [_p, _p, _i, _i64, _p, _p, _p, _p]),
+    "gpamd_cg64_update_xr": (_i, [_p, _i, _p]),
+    "gpamd_cg64_update_d": (_i, [_p, _i, _p]),
+    "gpamd_cg64_stop": (_i, [_p, _i, _i, _i, C.c_double, _p]),
+    "gpamd_cg64_finish": (_i, [_p, _p]),
     "gpamd_kv_grad_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p]),
 }
 

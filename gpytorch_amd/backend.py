@@ -37,13 +37,17 @@ def round_up(x: int, m: int) -> int:
 
 
 def padded_dim(d: int) -> int:
-    if d > MAX_INPUT_DIM:
-        raise NotImplementedError(f"gpytorch_amd fused kernels support input dimension <= {MAX_INPUT_DIM} (got {d})")
     return round_up(d, 4)
+
+
+def work_dtype(t: torch.Tensor) -> torch.dtype:
+    """float64 tensors are computed in float64 (generic path), everything else in float32 (fused path)."""
+    return torch.float64 if t.dtype == torch.float64 else torch.float32
 
 
 KV_GRAM = 1              # flag of gpamd_kv_partials_f32 (include/gpamd.h)
 GRAM_MAX_SQNORM = 32.0   # max |z|^2 for which the quadratic expansion keeps K within 1e-5 (kv_gram.hpp)
+FORCE_GENERIC = False    # tests: send float32 / d <= 16 problems down the generic (row-block + GEMM) path too
 FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or KV_GRAM regardless of |z|
 
 
@@ -57,6 +61,16 @@ class PreparedPoints:
         self._zmax2 = None
 
     @property
+    def dtype(self):
+        return self.xp.dtype
+
+    @property
+    def fused(self) -> bool:
+        """True when the fused float32 MFMA / VALU kernels apply (float32, d <= 16); otherwise products go through
+        the generic path: HIP-generated dense row blocks of K times V with a library GEMM (``kv_chunked``)."""
+        return self.xp.dtype == torch.float32 and self.d <= MAX_INPUT_DIM and not FORCE_GENERIC
+
+    @property
     def zmax2(self) -> float:
         """max_i |z_i|^2 of the prepared (scaled, centred) points; one device reduction + sync, cached."""
         if self._zmax2 is None:
@@ -66,6 +80,8 @@ class PreparedPoints:
 
 def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
     """Select the Gram-form generation kernel when it is both applicable and accurate (see kv_gram.hpp)."""
+    if not (x1.fused and x2.fused):
+        return 0
     if FORCE_KV_FLAGS is not None:
         return FORCE_KV_FLAGS
     if t <= 8 or x1.kind == "matern12":
@@ -78,32 +94,30 @@ def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: to
     _require_gpu(x, "x")
     n, d = x.shape[-2], x.shape[-1]
     dp = padded_dim(d)
-    x = x.detach().to(torch.float32).contiguous()
-    ls = lengthscale.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+    wd = work_dtype(x)
+    x = x.detach().to(wd).contiguous()
+    ls = lengthscale.detach().to(device=x.device, dtype=wd).reshape(-1).contiguous()
     if ls.numel() not in (1, d):
         raise ValueError(f"lengthscale must have 1 or {d} elements, got {ls.numel()}")
-    sh = None if shift is None else shift.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
-    xp = torch.empty(n, dp, device=x.device, dtype=torch.float32)
-    check(
-        lib().gpamd_prep_points_f32(
-            KIND_IDS[kind], _ptr(x), n, d, x.stride(0), _ptr(ls), ls.numel(), _ptr(sh), _ptr(xp), dp, _stream(x.device)
-        ),
-        "prep_points",
-    )
+    sh = None if shift is None else shift.detach().to(device=x.device, dtype=wd).reshape(-1).contiguous()
+    xp = torch.empty(n, dp, device=x.device, dtype=wd)
+    fn = lib().gpamd_prep_points_f64 if wd == torch.float64 else lib().gpamd_prep_points_f32
+    check(fn(KIND_IDS[kind], _ptr(x), n, d, x.stride(0), _ptr(ls), ls.numel(), _ptr(sh), _ptr(xp), dp, _stream(x.device)), "prep_points")
     return PreparedPoints(xp, n, d, dp, kind)
 
 
-def to_probe_major(rhs: torch.Tensor) -> torch.Tensor:
-    """[n, t] (any strides/dtype) -> float32 [t, ld] with ld = round_up(n, 4), zero padded."""
+def to_probe_major(rhs: torch.Tensor, dtype: torch.dtype | None = None) -> torch.Tensor:
+    """[n, t] (any strides) -> [t, ld] with ld = round_up(n, 4), zero padded; float32 unless ``dtype`` says otherwise
+    (callers on the generic path pass the dtype of their prepared points)."""
     n, t = rhs.shape[-2], rhs.shape[-1]
     ld = round_up(n, 4)
-    out = torch.zeros(t, ld, device=rhs.device, dtype=torch.float32)
+    out = torch.zeros(t, ld, device=rhs.device, dtype=torch.float32 if dtype is None else dtype)
     out[:, :n] = rhs.detach().t()
     return out
 
 
 def from_probe_major(vt: torch.Tensor, n: int) -> torch.Tensor:
-    """float32 [t, ld] -> [n, t] contiguous."""
+    """[t, ld] -> [n, t] contiguous."""
     return vt[:, :n].t().contiguous()
 
 
@@ -131,7 +145,14 @@ def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dsc
 
     vt: [t, ldv] with ldv >= m; scale/dscale: 1-element device tensors or None; dvec: float32 [>= n] or None."""
     _require_gpu(vt, "vt")
-    assert x1.kind == x2.kind and x1.dp == x2.dp
+    assert x1.kind == x2.kind and x1.dp == x2.dp and x1.dtype == x2.dtype
+    wd = x1.dtype
+    vd_is_vt = vd is vt
+    vt = vt if vt.dtype == wd else vt.to(wd)
+    vd = vt if vd_is_vt else (vd if vd is None or vd.dtype == wd else vd.to(wd))
+    scale, dscale, dvec = (a if a is None or a.dtype == wd else a.to(wd) for a in (scale, dscale, dvec))
+    if not (x1.fused and x2.fused):
+        return kv_chunked(x1, x2, vt, scale, dscale, vd, out, dvec)
     t, ldv = vt.shape
     n, m = x1.n, x2.n
     ldo = round_up(n, 4)
@@ -159,7 +180,52 @@ def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dsc
     return out
 
 
+def kernel_row_block(x1: PreparedPoints, r0: int, nrows: int, x2: PreparedPoints, scale=None) -> torch.Tensor:
+    """Dense rows [r0, r0 + nrows) of scale * k(x1, x2) (HIP generation kernels, float32 or float64)."""
+    out = torch.empty(nrows, x2.n, device=x1.xp.device, dtype=x1.dtype)
+    st = _stream(out.device)
+    if x1.dtype == torch.float64:
+        sc = None if scale is None else scale.to(torch.float64)
+        check(lib().gpamd_kernel_rows_f64(KIND_IDS[x1.kind], _ptr(x1.xp), None, r0, nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(sc),
+                                          _ptr(out), out.stride(0), st), "kernel_rows_f64")
+    else:
+        blk = x1.xp[r0 : r0 + nrows]
+        check(lib().gpamd_kernel_dense_f32(KIND_IDS[x1.kind], _ptr(blk), nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
+                                           out.stride(0), st), "kernel_dense")
+    return out
+
+
+def kv_chunked(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dscale=None, vd=None, out=None, dvec=None):
+    """Generic-path product (float64, or d > 16): K is generated in dense row blocks by the HIP kernels and
+    multiplied with a library GEMM -- the reference's chunked strategy (lazy_evaluated_kernel_tensor.py:245-275)
+    on the device.  HBM-bound: itemsize * n * m bytes written and read per product."""
+    n, m = x1.n, x2.n
+    t = vt.shape[0]
+    dt = x1.dtype
+    ldo = round_up(n, 4)
+    if out is None:
+        out = torch.zeros(t, ldo, device=vt.device, dtype=dt)
+    v = vt[:, :m].to(dt)
+    rows = int(max(1, min(n, 65535, (1 << 27) // max(m, 1))))
+    for r0 in range(0, n, rows):
+        nr = min(rows, n - r0)
+        kc = kernel_row_block(x1, r0, nr, x2)
+        torch.matmul(v, kc.t(), out=out[:, r0 : r0 + nr])
+    if scale is not None:
+        out[:, :n].mul_(scale.to(dt).reshape(()))
+    if vd is not None:
+        coef = torch.zeros((), device=out.device, dtype=dt) if dscale is None else dscale.to(dt).reshape(())
+        if dvec is not None:
+            out[:, :n].add_((coef + dvec[:n].to(dt)) * vd[:, :n].to(dt))
+        else:
+            out[:, :n].add_(coef * vd[:, :n].to(dt))
+    return out
+
+
 def kernel_dense(x1: PreparedPoints, x2: PreparedPoints, scale=None) -> torch.Tensor:
+    if x1.dtype == torch.float64:
+        outs = [kernel_row_block(x1, r0, min(65535, x1.n - r0), x2, scale) for r0 in range(0, x1.n, 65535)]
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
     out = torch.empty(x1.n, x2.n, device=x1.xp.device, dtype=torch.float32)
     check(
         lib().gpamd_kernel_dense_f32(
@@ -173,6 +239,12 @@ def kernel_dense(x1: PreparedPoints, x2: PreparedPoints, scale=None) -> torch.Te
 
 def kernel_rows(x1: PreparedPoints, rows: torch.Tensor, x2: PreparedPoints, scale=None) -> torch.Tensor:
     rows = rows.to(device=x1.xp.device, dtype=torch.int64).contiguous()
+    if x1.dtype == torch.float64:
+        out = torch.empty(rows.numel(), x2.n, device=x1.xp.device, dtype=torch.float64)
+        sc = None if scale is None else scale.to(torch.float64)
+        check(lib().gpamd_kernel_rows_f64(KIND_IDS[x1.kind], _ptr(x1.xp), _ptr(rows), 0, rows.numel(), _ptr(x2.xp), x2.n, x1.dp,
+                                          _ptr(sc), _ptr(out), out.stride(0), _stream(out.device)), "kernel_rows_f64")
+        return out
     out = torch.empty(rows.numel(), x2.n, device=x1.xp.device, dtype=torch.float32)
     check(
         lib().gpamd_kernel_rows_f32(
@@ -186,6 +258,12 @@ def kernel_rows(x1: PreparedPoints, rows: torch.Tensor, x2: PreparedPoints, scal
 
 def kernel_diag(x1: PreparedPoints, x2: PreparedPoints, scale=None) -> torch.Tensor:
     assert x1.n == x2.n
+    if x1.dtype == torch.float64:
+        out = torch.empty(x1.n, device=x1.xp.device, dtype=torch.float64)
+        sc = None if scale is None else scale.to(torch.float64)
+        check(lib().gpamd_kernel_diag_f64(KIND_IDS[x1.kind], _ptr(x1.xp), _ptr(x2.xp), x1.n, x1.dp, _ptr(sc), _ptr(out),
+                                          _stream(out.device)), "kernel_diag_f64")
+        return out
     out = torch.empty(x1.n, device=x1.xp.device, dtype=torch.float32)
     check(
         lib().gpamd_kernel_diag_f32(
@@ -199,9 +277,12 @@ def kernel_diag(x1: PreparedPoints, x2: PreparedPoints, scale=None) -> torch.Ten
 def coldot(a: torch.Tensor, b: torch.Tensor, n: int) -> torch.Tensor:
     """Per-row (probe-major) inner products over the first n entries: out[c] = <a[c,:n], b[c,:n]>."""
     t = a.shape[0]
-    out = torch.empty(t, device=a.device, dtype=torch.float32)
-    scratch = torch.empty(t * 256, device=a.device, dtype=torch.float32)
-    check(lib().gpamd_coldot_f32(_ptr(a), _ptr(b), a.stride(0), n, t, _ptr(out), _ptr(scratch), _stream(a.device)), "coldot")
+    if a.dtype != b.dtype:
+        b = b.to(a.dtype)
+    out = torch.empty(t, device=a.device, dtype=a.dtype)
+    scratch = torch.empty(t * 256, device=a.device, dtype=a.dtype)
+    fn = lib().gpamd_coldot_f64 if a.dtype == torch.float64 else lib().gpamd_coldot_f32
+    check(fn(_ptr(a), _ptr(b), a.stride(0), n, t, _ptr(out), _ptr(scratch), _stream(a.device)), "coldot")
     return out
 
 
@@ -210,6 +291,13 @@ def pivoted_cholesky(xp: PreparedPoints, scale, rank: int, tol: float):
     n = xp.n
     rank = min(rank, n)
     dev = xp.xp.device
+    if xp.dtype != torch.float32:
+        # float64 models: the greedy factor is built from a float32 copy of the prepared points.  Any SPD
+        # P = L L^T + s2 I is a valid preconditioner; everything derived from this L (Q1, log|P|, the probe
+        # covariance) is then computed in float64 by the caller, so the float64 solve loses nothing.
+        xp32 = PreparedPoints(xp.xp.to(torch.float32), n, xp.d, xp.dp, xp.kind)
+        L32, piv, m = pivoted_cholesky(xp32, None if scale is None else scale.to(torch.float32), rank, tol)
+        return L32.to(xp.dtype), piv, m
     ldl = round_up(n, 4)
     L = torch.zeros(rank, ldl, device=dev, dtype=torch.float32)
     piv = torch.zeros(rank, device=dev, dtype=torch.int64)
@@ -232,7 +320,9 @@ def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.
     Returns float32 [1 + dp]:  g[0] = sum_ij W_ij k_ij;  g[1+q] = sum_ij W_ij dk/ds_ij (z_iq - z_jq)^2
     where z are the PREPARED coordinates and s the squared prepared distance."""
     _require_gpu(lt, "left")
-    assert x1.kind == x2.kind and x1.dp == x2.dp and lt.shape[0] == rt.shape[0]
+    assert x1.kind == x2.kind and x1.dp == x2.dp and lt.shape[0] == rt.shape[0] and x1.fused and x2.fused
+    lt = lt if lt.dtype == torch.float32 else lt.to(torch.float32)
+    rt = rt if rt.dtype == torch.float32 else rt.to(torch.float32)
     t = lt.shape[0]
     dev = lt.device
     nd = int(lib().gpamd_kv_grad_workspace_doubles(x1.n, x2.n, t, x1.dp))
@@ -246,6 +336,36 @@ def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.
         "kv_grad",
     )
     return out
+
+
+def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor) -> torch.Tensor:
+    """Generic-path (float64, or d > 16) twin of :func:`kv_grad`; same return convention, float64 [1 + dp].
+
+    Per row block: W = left^T right (library GEMM) -> HIP ``gpamd_kernel_grad_block`` turns it into A = W * dk/ds and
+    accumulates sum W*k -> the per-dimension sums  sum_ij A_ij (z_iq - z_jq)^2  expand into row sums, column sums and
+    one A @ z2 product, accumulated in float64."""
+    _require_gpu(lt, "left")
+    assert x1.kind == x2.kind and x1.dp == x2.dp and x1.dtype == x2.dtype and lt.shape[0] == rt.shape[0]
+    n, m, dp, dt = x1.n, x2.n, x1.dp, x1.dtype
+    dev = lt.device
+    fn = lib().gpamd_kernel_grad_block_f64 if dt == torch.float64 else lib().gpamd_kernel_grad_block_f32
+    acc = torch.zeros(1, device=dev, dtype=torch.float64)
+    gq = torch.zeros(dp, device=dev, dtype=torch.float64)
+    cs = torch.zeros(m, device=dev, dtype=torch.float64)
+    z1, z2 = x1.xp.to(torch.float64), x2.xp.to(torch.float64)
+    r_all = rt[:, :m].to(dt)
+    rows = int(max(1, min(n, 65535, (1 << 26) // max(m, 1))))
+    st = _stream(dev)
+    for r0 in range(0, n, rows):
+        nr = min(rows, n - r0)
+        w = (lt[:, r0 : r0 + nr].to(dt).t() @ r_all).contiguous()
+        check(fn(KIND_IDS[x1.kind], _ptr(x1.xp), r0, nr, _ptr(x2.xp), m, dp, _ptr(w), w.stride(0), _ptr(acc), st), "kernel_grad_block")
+        a = w.to(torch.float64)
+        zb = z1[r0 : r0 + nr]
+        gq += (zb.pow(2) * a.sum(1, keepdim=True)).sum(0) - 2.0 * (zb * (a @ z2)).sum(0)
+        cs += a.sum(0)
+    gq += (z2.pow(2) * cs.unsqueeze(-1)).sum(0)
+    return torch.cat([acc, gq])
 
 
 # d s / d l factors: s = sum_q z_q^2-differences with z = coef * x / l  =>  ds_q/dl_q = -2 s_q / l_q

@@ -46,6 +46,7 @@ def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=
         warnings.warn("NaNs encountered in preconditioner computation. Attempting to continue without preconditioning.", NumericalWarning)
         return None
     dev = lt.device
+    wd = x.dtype
     ld = B.round_up(n, 4)
     s2 = sigma2.detach().reshape(()).to(torch.float64)
     eye = torch.eye(k, device=dev, dtype=torch.float64)
@@ -54,40 +55,40 @@ def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=
     g1 = (ltd @ ltd.t()) if ltd is not None else (lt @ lt.t()).to(torch.float64)
     r1 = torch.linalg.cholesky(g1 + s2 * eye, upper=True)
     r1inv = torch.linalg.solve_triangular(r1, eye, upper=True)
-    q1t = (r1inv.t().to(torch.float32) @ lt)  # [k, n] = (L R1^-1)^T
+    q1t = (r1inv.t().to(wd) @ lt)  # [k, n] = (L R1^-1)^T
     # round 2 (re-orthogonalise): G2 = Q'^T Q' over all n + k rows
     g2 = (q1t @ q1t.t()).to(torch.float64) + s2 * (r1inv.t() @ r1inv)
     r2 = torch.linalg.cholesky(g2, upper=True)
     r2inv = torch.linalg.solve_triangular(r2, eye, upper=True)
-    q1t = r2inv.t().to(torch.float32) @ q1t
+    q1t = r2inv.t().to(wd) @ q1t
     rdiag = (r2 @ r1).diagonal()
     logdet = 2.0 * rdiag.abs().log().sum() + (n - k) * torch.log(s2)
-    q1t_pad = torch.zeros(k, ld, device=dev, dtype=torch.float32)
+    q1t_pad = torch.zeros(k, ld, device=dev, dtype=wd)
     q1t_pad[:, :n] = q1t
-    lt_pad = torch.zeros(k, ld, device=dev, dtype=torch.float32)
+    lt_pad = torch.zeros(k, ld, device=dev, dtype=wd)
     lt_pad[:, :n] = lt
-    return Preconditioner(q1t_pad, sigma2.detach().reshape(()).to(torch.float32), logdet.to(torch.float32), lt_pad)
+    return Preconditioner(q1t_pad, sigma2.detach().reshape(()).to(wd), logdet.to(wd), lt_pad)
 
 
-def probe_vectors(n: int, t: int, precond: Preconditioner | None, device, generator=None, probes=None):
+def probe_vectors(n: int, t: int, precond: Preconditioner | None, device, generator=None, probes=None, dtype=torch.float32):
     """A.5.  Returns (Zt [t, ld] column-normalised, norms [t]).
 
     ``probes``: optional user-supplied UN-normalised (n, t) matrix (``deterministic_probes``-style
     injection; lets CPU and GPU runs share Z)."""
     ld = B.round_up(n, 4)
-    zt = torch.zeros(t, ld, device=device, dtype=torch.float32)
+    zt = torch.zeros(t, ld, device=device, dtype=dtype)
     if probes is None and settings.deterministic_probes.on() and settings.deterministic_probes.probe_vectors is not None:
         probes = settings.deterministic_probes.probe_vectors
     if probes is not None:
-        zt[:, :n] = probes.to(device=device, dtype=torch.float32).t()
+        zt[:, :n] = probes.to(device=device, dtype=dtype).t()
     elif precond is None:
         r = torch.randint(0, 2, (t, n), device=device, generator=generator, dtype=torch.int8)
-        zt[:, :n] = r.to(torch.float32) * 2 - 1
+        zt[:, :n] = r.to(dtype) * 2 - 1
     else:
         k = precond.lt.shape[0]
-        e1 = torch.randn(t, k, device=device, generator=generator, dtype=torch.float32)
-        e2 = torch.randn(t, n, device=device, generator=generator, dtype=torch.float32)
-        zt[:, :n] = (e1 @ precond.lt)[:, :n] + precond.sigma2.sqrt() * e2
+        e1 = torch.randn(t, k, device=device, generator=generator, dtype=dtype)
+        e2 = torch.randn(t, n, device=device, generator=generator, dtype=dtype)
+        zt[:, :n] = (e1 @ precond.lt.to(dtype))[:, :n] + precond.sigma2.to(dtype).sqrt() * e2
     norms = B.coldot(zt, zt, n).sqrt()
     zt.div_(norms.unsqueeze(-1))
     return zt, norms
@@ -143,6 +144,7 @@ def inv_quad_logdet_forward(
     2-float stopping-rule all-reduce per CG iteration and one scalar all-reduce of the SLQ sums."""
     n = x.n
     dev = rhs_t.device
+    wd = x.dtype
     t = settings.num_trace_samples.value() if num_probes is None else num_probes
     if dvec is not None:
         precond = None  # the pivoted-Cholesky preconditioner is built for the constant-diagonal branch only (A.4)
@@ -150,14 +152,14 @@ def inv_quad_logdet_forward(
         precond = build_preconditioner(x, scale, sigma2)
     if probes is not None:
         t = probes.shape[-1]
-    zt, znorm = probe_vectors(n, t, precond, dev, generator, probes)
+    zt, znorm = probe_vectors(n, t, precond, dev, generator, probes, dtype=wd)
     if t_total is None:
         t_total = t
         if group is not None:
-            tt = torch.tensor([float(t)], device=dev)
+            tt = torch.tensor([float(t)], device=dev, dtype=torch.float32)
             allreduce_sum_(tt, group)
             t_total = int(tt.item())
-    full = torch.cat([zt, rhs_t.to(torch.float32)], dim=0).contiguous()
+    full = torch.cat([zt, rhs_t.to(wd)], dim=0).contiguous()
     solves_t, info = linear_cg(
         x, scale, sigma2, full, n_tridiag=t, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, group=group,
         dvec=dvec,
@@ -167,12 +169,12 @@ def inv_quad_logdet_forward(
     else:
         # (n / t_total) * sum over THIS rank's probes
         ld_slq = slq_logdet(info.t_mats, n) * (t / t_total)
-    ld_slq = ld_slq.to(device=dev, dtype=torch.float32)
+    ld_slq = ld_slq.to(device=dev, dtype=wd)
     if group is not None:
         allreduce_sum_(ld_slq, group)
     logdet = ld_slq + (precond.logdet if precond is not None else 0.0)
     c = rhs_t.shape[0]
-    inv_quad = B.coldot(solves_t[t : t + c], rhs_t.to(torch.float32), n)
+    inv_quad = B.coldot(solves_t[t : t + c], rhs_t.to(wd), n)
     return InvQuadLogdetResult(inv_quad, logdet, solves_t, zt, znorm, precond, info, ld_slq)
 
 

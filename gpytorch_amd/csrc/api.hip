@@ -14,9 +14,11 @@
 
 using namespace gpamd;
 
-namespace {
+namespace gpamd {
+thread_local char g_err[512] = "";  // shared by every translation unit of the library (gpamd_last_error)
+}
 
-thread_local char g_err[512] = "";
+namespace {
 
 int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);

@@ -66,6 +66,25 @@ __device__ __forceinline__ double cov_from_sq_f64(double s) {
   }
 }
 
+template <int KIND>
+__device__ __forceinline__ double dcov_dsq_f64(double s) {
+  if constexpr (KIND == KIND_RBF) {
+    return -0.6931471805599453 * exp2(-s);
+  } else {
+    double r = sqrt(s);
+    double e = exp(-r);
+    if constexpr (KIND == KIND_MATERN12) return r > 1e-150 ? -0.5 * e / r : 0.0;
+    if constexpr (KIND == KIND_MATERN32) return -0.5 * e;
+    return -(1.0 + r) * e * (1.0 / 6.0);
+  }
+}
+
+// scalar-type dispatch for the kernels templated on T (generic path)
+template <int KIND> __device__ __forceinline__ float cov_any(float s) { return cov_from_sq<KIND>(s); }
+template <int KIND> __device__ __forceinline__ double cov_any(double s) { return cov_from_sq_f64<KIND>(s); }
+template <int KIND> __device__ __forceinline__ float dcov_any(float s) { return dcov_dsq<KIND>(s); }
+template <int KIND> __device__ __forceinline__ double dcov_any(double s) { return dcov_dsq_f64<KIND>(s); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -7,9 +7,11 @@
 #include "kv_grad.hpp"
 
 using namespace gpamd;
+namespace gpamd {
+extern thread_local char g_err[512];
+}
 
 namespace {
-thread_local char g_err2[256] = "";
 constexpr int GRAD_TGROUP = 128;  // probe columns per launch
 
 int grad_num_cus() {
@@ -74,7 +76,7 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
                       const float* Rt, int64_t ldr, int t, int iso, float* out, double* workspace,
                       int64_t workspace_doubles, void* stream) {
   if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m) {
-    snprintf(g_err2, sizeof(g_err2), "kv_grad: bad arguments");
+    snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad: bad arguments");
     return GPAMD_EINVAL;
   }
   if (dp != 4 && dp != 8 && dp != 12 && dp != 16) return GPAMD_EUNSUPPORTED;
@@ -109,7 +111,7 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
   hipLaunchKernelGGL(grad_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, (int)(groups * units), 1 + dp, out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
-    snprintf(g_err2, sizeof(g_err2), "kv_grad: %s", hipGetErrorString(e));
+    snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad: %s", hipGetErrorString(e));
     return (int)e;
   }
   return 0;

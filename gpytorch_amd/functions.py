@@ -32,10 +32,14 @@ class KernelSpec:
 
 def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t):
     """d/d(lengthscale), d/d(outputscale) of sum_c left[c]^T (outputscale * k(x1, x2)) right[c]."""
-    ls = lengthscale.detach().to(torch.float32).reshape(-1)
-    g = B.kv_grad(xp1, xp2, left_t, right_t, iso=ls.numel() == 1)
+    wd = xp1.dtype
+    ls = lengthscale.detach().to(wd).reshape(-1)
+    if xp1.fused and xp2.fused:
+        g = B.kv_grad(xp1, xp2, left_t, right_t, iso=ls.numel() == 1)
+    else:
+        g = B.kv_grad_generic(xp1, xp2, left_t, right_t).to(wd)
     d = xp1.d
-    theta = 1.0 if outputscale is None else outputscale.detach().reshape(()).to(torch.float32)
+    theta = 1.0 if outputscale is None else outputscale.detach().reshape(()).to(wd)
     gq = g[1 : 1 + d]
     if ls.numel() == 1:
         d_ls = (theta * (-2.0) / ls * gq.sum()).reshape(lengthscale.shape)
@@ -52,9 +56,9 @@ class InvQuadLogdetFn(torch.autograd.Function):
     def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec, opts: dict):
         n = x.shape[-2]
         xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
-        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
-        nz = noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
-        rhs_t = B.to_probe_major(rhs)
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
+        nz = noise.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
+        rhs_t = B.to_probe_major(rhs, xp.dtype)
         res = inv_quad_logdet_forward(
             xp, os_, nz, rhs_t,
             num_probes=opts.get("num_probes"), precond=opts.get("precond", "auto"), probes=opts.get("probes"),
@@ -76,8 +80,8 @@ class InvQuadLogdetFn(torch.autograd.Function):
         res, xp, n = ctx.res, ctx.xp, ctx.n
         t = res.zt.shape[0]
         c = res.solves_t.shape[0] - t
-        g_iq = g_iq.to(torch.float32).reshape(c, 1)
-        g_ld = g_ld.to(torch.float32).reshape(())
+        g_iq = g_iq.to(xp.dtype).reshape(c, 1)
+        g_ld = g_ld.to(xp.dtype).reshape(())
         world = 1 if ctx.group is None else torch.distributed.get_world_size(ctx.group)
         s_z = res.solves_t[:t] * res.znorm.unsqueeze(-1)
         s_y = res.solves_t[t:]
@@ -90,7 +94,7 @@ class InvQuadLogdetFn(torch.autograd.Function):
         d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, left, right)
         d_noise = B.coldot(left, right, n).sum().reshape(noise.shape).to(noise.dtype)
         if ctx.group is not None:
-            pack = torch.cat([d_ls.reshape(-1).float(), d_noise.reshape(-1).float()] + ([d_os.reshape(-1).float()] if d_os is not None else []))
+            pack = torch.cat([d_ls.reshape(-1).to(xp.dtype), d_noise.reshape(-1).to(xp.dtype)] + ([d_os.reshape(-1).to(xp.dtype)] if d_os is not None else []))
             allreduce_sum_(pack, ctx.group)
             k = d_ls.numel()
             d_ls = pack[:k].reshape(d_ls.shape).to(d_ls.dtype)
@@ -111,7 +115,7 @@ class CholeskyInvQuadLogdetFn(torch.autograd.Function):
     def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec):
         n = x.shape[-2]
         xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
-        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
         K = B.kernel_dense(xp, xp, os_).to(torch.float64)
         K.diagonal().add_(noise.detach().reshape(()).to(torch.float64))
         if spec.dvec is not None:
@@ -136,8 +140,8 @@ class CholeskyInvQuadLogdetFn(torch.autograd.Function):
         left = torch.cat([kinv * g_ld.to(torch.float64), -(sol * g_iq.to(torch.float64).reshape(1, c)).t()], dim=0)
         right = torch.cat([torch.eye(n, device=sol.device, dtype=torch.float64), sol.t()], dim=0)
         ld = B.round_up(n, 4)
-        lt = torch.zeros(n + c, ld, device=sol.device, dtype=torch.float32)
-        rt = torch.zeros(n + c, ld, device=sol.device, dtype=torch.float32)
+        lt = torch.zeros(n + c, ld, device=sol.device, dtype=xp.dtype)
+        rt = torch.zeros(n + c, ld, device=sol.device, dtype=xp.dtype)
         lt[:, :n] = left
         rt[:, :n] = right
         d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, lt, rt)
@@ -152,10 +156,10 @@ class KernelMatmulFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, lengthscale, outputscale, noise, rhs, spec: KernelSpec):
         xp1 = B.prep_points(spec.kind, x1, lengthscale, spec.shift)
-        xp2 = xp1 if x2 is x1 else B.prep_points(spec.kind, x2, lengthscale, spec.shift)
-        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
-        nz = None if noise is None else noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
-        vt = B.to_probe_major(rhs)
+        xp2 = xp1 if x2 is x1 else B.prep_points(spec.kind, x2.to(x1.dtype), lengthscale, spec.shift)
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp1.dtype).contiguous()
+        nz = None if noise is None else noise.detach().reshape(-1)[:1].to(xp1.dtype).contiguous()
+        vt = B.to_probe_major(rhs, xp1.dtype)
         out_t = B.kv(xp1, xp2, vt, scale=os_, dscale=nz, vd=vt if nz is not None else None,
                      dvec=spec.dvec if nz is not None else None)
         ctx.xp1, ctx.xp2, ctx.dvec = xp1, xp2, (spec.dvec if nz is not None else None)
@@ -169,16 +173,17 @@ class KernelMatmulFn(torch.autograd.Function):
         lengthscale, outputscale, noise, rhs = ctx.saved_tensors
         outputscale = outputscale if ctx.has_os else None
         noise = noise if ctx.has_noise else None
-        gt = B.to_probe_major(g)
-        rt = B.to_probe_major(rhs)
+        wd = ctx.xp1.dtype
+        gt = B.to_probe_major(g, wd)
+        rt = B.to_probe_major(rhs, wd)
         d_ls = d_os = d_noise = d_rhs = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             d_ls, d_os = hyper_grads(ctx.xp1, ctx.xp2, lengthscale, outputscale, gt, rt)
         if noise is not None and ctx.needs_input_grad[4]:
             d_noise = (g * rhs).sum().reshape(noise.shape).to(noise.dtype)
         if ctx.needs_input_grad[5]:
-            os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
-            nz = None if noise is None else noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+            os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(wd).contiguous()
+            nz = None if noise is None else noise.detach().reshape(-1)[:1].to(wd).contiguous()
             out_t = B.kv(ctx.xp2, ctx.xp1, gt, scale=os_, dscale=nz, vd=gt if nz is not None else None, dvec=ctx.dvec)
             d_rhs = B.from_probe_major(out_t, ctx.xp2.n).to(rhs.dtype)
         return None, None, d_ls, d_os, d_noise, d_rhs, None

@@ -102,8 +102,7 @@ class _StationaryFused(Kernel):
         return x1.detach().mean(dim=-2)
 
     def forward(self, x1, x2, diag=False, **params):
-        if x1.shape[-1] > B.MAX_INPUT_DIM:
-            raise NotImplementedError(f"fused kernels support d <= {B.MAX_INPUT_DIM}")
+        # float32 with d <= 16: fused MFMA / VALU kernels; float64 or d > 16: generic path (backend.kv_chunked)
         op = FusedKernelLinearOperator(x1, x2, KernelSpec(self.kind, self._shift(x1)), self.lengthscale)
         return op.diagonal() if diag else op
 

@@ -17,7 +17,7 @@ from . import settings
 
 def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_t: torch.Tensor | None = None,
                     tol: float = 1e-5, generator=None, dvec=None, matvec=None, nvec=None, device=None):
-    """Returns (Qt [m, ld] with orthonormal rows, T [m, m] float32 on device).
+    """Returns (Qt [m, ld] with orthonormal rows, T [m, m] on device, in the dtype of the prepared points).
 
     ``matvec(q_row [1, ld]) -> [1, ld]``: optional operator override (multitask Kronecker); then ``x`` may be
     None and ``nvec`` / ``device`` give the vector length and device."""
@@ -25,11 +25,12 @@ def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_
     dev = x.xp.device if device is None else device
     ld = B.round_up(n, 4)
     num_iter = min(max_iter, n)
+    wd = init_vec_t.dtype if init_vec_t is not None else (x.dtype if x is not None else torch.float32)
     if init_vec_t is None:
-        init_vec_t = torch.zeros(1, ld, device=dev, dtype=torch.float32)
-        init_vec_t[:, :n] = torch.randn(1, n, device=dev, generator=generator, dtype=torch.float32)
-    Q = torch.zeros(num_iter, ld, device=dev, dtype=torch.float32)
-    T = torch.zeros(num_iter, num_iter, device=dev, dtype=torch.float32)
+        init_vec_t = torch.zeros(1, ld, device=dev, dtype=wd)
+        init_vec_t[:, :n] = torch.randn(1, n, device=dev, generator=generator, dtype=wd)
+    Q = torch.zeros(num_iter, ld, device=dev, dtype=wd)
+    T = torch.zeros(num_iter, num_iter, device=dev, dtype=wd)
 
     def mv(q_row):  # K_hat q, q_row: [1, ld]
         if matvec is not None:
@@ -98,5 +99,5 @@ def root_inv_decomposition(x: B.PreparedPoints, scale, dscale, max_iter=None, in
     jitter = settings.tridiagonal_jitter.value()
     Tj = T + jitter * torch.eye(T.shape[0], device=T.device, dtype=T.dtype)
     evals, evecs = tridiag_to_diag(Tj)
-    w = (evecs / evals.sqrt().unsqueeze(-2)).to(device=Q.device, dtype=torch.float32)  # V Lambda^-1/2
+    w = (evecs / evals.sqrt().unsqueeze(-2)).to(device=Q.device, dtype=Q.dtype)  # V Lambda^-1/2
     return w.t() @ Q  # [m, ld]: rows = columns of Q V Lambda^-1/2

@@ -87,9 +87,10 @@ class Preconditioner:
 
     def apply_(self, rt: torch.Tensor, out: torch.Tensor):
         # out = (R - (R Q1) Q1^T) / s2   in probe-major form: rows are vectors
-        w = rt @ self.q1t.t()
-        torch.addmm(rt, w, self.q1t, alpha=-1.0, out=out)
-        out.div_(self.sigma2)
+        q1t = self.q1t if self.q1t.dtype == rt.dtype else self.q1t.to(rt.dtype)
+        w = rt @ q1t.t()
+        torch.addmm(rt, w, q1t, alpha=-1.0, out=out)
+        out.div_(self.sigma2.to(rt.dtype))
         return out
 
 
@@ -119,6 +120,10 @@ def linear_cg(
     B._require_gpu(rhs_t, "rhs")
     L = lib()
     n = x.n if nvec is None else nvec
+    if x is not None and rhs_t.dtype != x.dtype:
+        rhs_t = rhs_t.to(x.dtype)  # the solve runs in the dtype of the prepared points
+    elif rhs_t.dtype not in (torch.float32, torch.float64):
+        rhs_t = rhs_t.to(torch.float32)
     t, ld = rhs_t.shape
     dev = rhs_t.device
     if tolerance is None:
@@ -131,30 +136,42 @@ def linear_cg(
     hist = min(n_tri_iter, max_iter) if n_tridiag else 0
 
     st = B._stream(dev)
-    Xt = torch.zeros(t, ld, device=dev, dtype=torch.float32)
+    # the vector kernels are templated on the scalar type
+    f64 = rhs_t.dtype == torch.float64
+    wd = torch.float64 if f64 else torch.float32
+    F = {k: getattr(L, (f"gpamd_cg64_{k}" if f64 else f"gpamd_cg_{k}_f32"))
+         for k in ("init", "begin", "reduce_q", "update_xr", "update_d", "stop", "finish")}
+    Xt = torch.zeros(t, ld, device=dev, dtype=wd)
     Rt = torch.zeros_like(Xt)
     Dt = torch.zeros_like(Xt)
     Qt = torch.zeros_like(Xt)
     Zt = torch.zeros_like(Xt) if preconditioner is not None else Rt
-    fs = torch.zeros(int(L.gpamd_cg_fscratch_elems(t, hist)), device=dev, dtype=torch.float32)
+    fs = torch.zeros(int(L.gpamd_cg_fscratch_elems(t, hist)), device=dev, dtype=wd)
     isc = torch.zeros(int(L.gpamd_cg_iscratch_elems(t)), device=dev, dtype=torch.int32)
     offs = (C.c_int64 * 5)()
     check(L.gpamd_cg_layout(t, hist, offs), "cg_layout")
-    h = L.gpamd_cg_create_f32(
-        n, t, ld, B._ptr(Xt), B._ptr(Rt), B._ptr(Dt), B._ptr(Qt), B._ptr(Zt), B._ptr(fs), B._ptr(isc), hist,
-        float(eps), float(stop_updating_after),
-    )
+    create = L.gpamd_cg64_create if f64 else L.gpamd_cg_create_f32
+    h = create(n, t, ld, B._ptr(Xt), B._ptr(Rt), B._ptr(Dt), B._ptr(Qt), B._ptr(Zt), B._ptr(fs), B._ptr(isc), hist,
+               float(eps), float(stop_updating_after))
     if not h:
         check(-1, "cg_create")
     done_t = isc[2 * t : 2 * t + 2]
-    done_ptr = C.c_void_p(L.gpamd_cg_done_ptr(h))
+    done_ptr = C.c_void_p(isc.data_ptr() + 2 * t * 4)
     stats = fs[offs[4] : offs[4] + 2]
+    scale = None if scale is None else scale.to(wd)
+    dscale = None if dscale is None else dscale.to(wd)
+    dvec = None if dvec is None else dvec.to(wd)
+    if kv_partials is None and not x.fused:
+        # generic path (float64, or d > 16): dense row blocks of K (HIP) x library GEMM, one "partial" slab
+        def kv_partials(dt_, _x=x):
+            out = B.kv_chunked(_x, _x, dt_)
+            return out, 1, out.stride(0)
     try:
-        check(L.gpamd_cg_init_f32(h, B._ptr(rhs_t), rhs_t.stride(0), 1 if preconditioner is not None else 0, st), "cg_init")
+        check(F["init"](h, B._ptr(rhs_t), rhs_t.stride(0), 1 if preconditioner is not None else 0, st), "cg_init")
         if preconditioner is not None:
             preconditioner.apply_(Rt, Zt)
             Dt.copy_(Zt)
-            check(L.gpamd_cg_begin_f32(h, st), "cg_begin")
+            check(F["begin"](h, st), "cg_begin")
 
         if kv_partials is None:
             flags = B.kv_flags(x, x, t)
@@ -186,14 +203,14 @@ def linear_cg(
             if ev is not None:
                 ev[1].record(torch.cuda.current_stream(dev))
                 KV_EVENT_LOG.append((ev[0], ev[1], n, t, k))
-            check(L.gpamd_cg_reduce_q_f32(h, B._ptr(P), S, ldp, B._ptr(scale), B._ptr(dscale), B._ptr(dvec), st), "cg_reduce_q")
-            check(L.gpamd_cg_update_xr_f32(h, k, st), "cg_update_xr")
+            check(F["reduce_q"](h, B._ptr(P), S, ldp, B._ptr(scale), B._ptr(dscale), B._ptr(dvec), st), "cg_reduce_q")
+            check(F["update_xr"](h, k, st), "cg_update_xr")
             if preconditioner is not None:
                 preconditioner.apply_(Rt, Zt)
-            check(L.gpamd_cg_update_d_f32(h, k, st), "cg_update_d")
+            check(F["update_d"](h, k, st), "cg_update_d")
             if group is not None:
                 allreduce_sum_(stats, group)
-            check(L.gpamd_cg_stop_f32(h, k, min_iter, tri_floor, float(tolerance), st), "cg_stop")
+            check(F["stop"](h, k, min_iter, tri_floor, float(tolerance), st), "cg_stop")
             iters = k + 1
             if k >= first_poll and ((k - first_poll) % poll_every == 0 or k == max_iter - 1):
                 flag, iters_dev = (int(v) for v in done_t.tolist())
@@ -205,7 +222,7 @@ def linear_cg(
             iters = iters_dev if flag else max_iter
         if flag == 2:
             raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
-        check(L.gpamd_cg_finish_f32(h, st), "cg_finish")
+        check(F["finish"](h, st), "cg_finish")
         rnorm = fs[offs[1] : offs[1] + t].clone()
         tolerance_reached = flag == 1
         if not tolerance_reached and max_iter > 0:
@@ -223,5 +240,5 @@ def linear_cg(
             b_h = fs[offs[3] : offs[3] + hist * t].view(hist, t)[:, :n_tridiag].cpu()
             t_mats = build_tridiag(a_h, b_h, iters, tolerance_reached, n_tri_iter)
     finally:
-        L.gpamd_cg_destroy(h)
+        (L.gpamd_cg64_destroy if f64 else L.gpamd_cg_destroy)(h)
     return Xt, CGInfo(iters, tolerance_reached, rnorm, t_mats)

@@ -34,14 +34,14 @@ from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOper
 def _deinterleave(vt: torch.Tensor, n: int, T: int) -> torch.Tensor:
     """[t, >= n*T] interleaved (i*T + tau)  ->  probe-major [(t*T), ld_n] with row (c, tau)."""
     t = vt.shape[0]
-    out = torch.zeros(t * T, B.round_up(n, 4), device=vt.device, dtype=torch.float32)
+    out = torch.zeros(t * T, B.round_up(n, 4), device=vt.device, dtype=vt.dtype)
     out[:, :n] = vt[:, : n * T].reshape(t, n, T).permute(0, 2, 1).reshape(t * T, n)
     return out
 
 
 def _interleave(q: torch.Tensor, t: int, n: int, T: int) -> torch.Tensor:
     """[(t*T), >= n] rows (c, tau)  ->  [t, ld_{nT}] interleaved."""
-    out = torch.zeros(t, B.round_up(n * T, 4), device=q.device, dtype=torch.float32)
+    out = torch.zeros(t, B.round_up(n * T, 4), device=q.device, dtype=q.dtype)
     out[:, : n * T] = q[:, :n].reshape(t, T, n).permute(0, 2, 1).reshape(t, n * T)
     return out
 
@@ -50,9 +50,9 @@ def kron_matvec(p1: B.PreparedPoints, p2: B.PreparedPoints, ktt: torch.Tensor, v
     """(scale * K(x1,x2) (x) K_TT) @ V for V = vt [t, >= n2*T] interleaved; returns [t, ld_{n1 T}] interleaved."""
     T = ktt.shape[-1]
     t = vt.shape[0]
-    w = _deinterleave(vt, p2.n, T)
+    w = _deinterleave(vt.to(p1.dtype), p2.n, T)
     q = B.kv(p1, p2, w, scale=scale)  # [(t*T), ld_n1]: K_XX @ V_mat, one fused launch with T*t columns
-    q3 = torch.einsum("ab,cbn->can", ktt.to(torch.float32), q[:, : p1.n].reshape(t, T, p1.n))
+    q3 = torch.einsum("ab,cbn->can", ktt.to(q.dtype), q[:, : p1.n].reshape(t, T, p1.n))
     return _interleave(q3.reshape(t * T, p1.n), t, p1.n, T)
 
 
@@ -73,7 +73,7 @@ class KroneckerFusedLinearOperator(LinearOperator):
 
     def _matmul(self, rhs):
         p1, p2 = self.kx.prepared()
-        out_t = kron_matvec(p1, p2, self.ktt.detach(), B.to_probe_major(rhs), self.kx._os())
+        out_t = kron_matvec(p1, p2, self.ktt.detach(), B.to_probe_major(rhs, p1.dtype), self.kx._os())
         return B.from_probe_major(out_t, self.shape[0]).to(rhs.dtype)
 
     def _transpose_nonbatch(self):
@@ -138,8 +138,9 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
 
     def _dvec(self):
         n, T = self.kron.kx.shape[0], self.kron.T
-        dv = torch.zeros(B.round_up(n * T, 4), device=self.device, dtype=torch.float32)
-        dv[: n * T] = self.task_noise.detach().to(torch.float32).repeat(n)
+        wd = B.work_dtype(self.kron.kx.x1)
+        dv = torch.zeros(B.round_up(n * T, 4), device=self.device, dtype=wd)
+        dv[: n * T] = self.task_noise.detach().to(wd).repeat(n)
         return dv
 
     def _matmul(self, rhs):
@@ -180,7 +181,7 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
         if self._use_cholesky(settings.fast_computations.solves):
             sol = torch.cholesky_solve(r.detach().double(), torch.linalg.cholesky(self.to_dense().detach().double())).to(rhs.dtype)
         else:
-            sol_t, info = self._cg(B.to_probe_major(r.detach()), tolerance=settings.cg_tolerance.value())
+            sol_t, info = self._cg(B.to_probe_major(r.detach(), B.work_dtype(self.kron.kx.x1)), tolerance=settings.cg_tolerance.value())
             self._cache["last_cg_info"] = info
             sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
         if lhs is not None:
@@ -245,25 +246,26 @@ class KroneckerInvQuadLogdetFn(torch.autograd.Function):
         N = n * T
         dev = x.device
         xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
-        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
-        ktt_d = ktt.detach().to(torch.float32)
+        wd = xp.dtype
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(wd).contiguous()
+        ktt_d = ktt.detach().to(wd)
         t = opts.get("num_probes") or settings.num_trace_samples.value()
         ld = B.round_up(N, 4)
-        zt = torch.zeros(t, ld, device=dev, dtype=torch.float32)
+        zt = torch.zeros(t, ld, device=dev, dtype=wd)
         probes = opts.get("probes")
         if probes is None and settings.deterministic_probes.on() and settings.deterministic_probes.probe_vectors is not None:
             probes = settings.deterministic_probes.probe_vectors
         if probes is not None:
             t = probes.shape[-1]
-            zt = torch.zeros(t, ld, device=dev, dtype=torch.float32)
-            zt[:, :N] = probes.to(device=dev, dtype=torch.float32).t()
+            zt = torch.zeros(t, ld, device=dev, dtype=wd)
+            zt[:, :N] = probes.to(device=dev, dtype=wd).t()
         else:
-            zt[:, :N] = torch.randint(0, 2, (t, N), device=dev, generator=opts.get("generator"), dtype=torch.int8).float() * 2 - 1
+            zt[:, :N] = torch.randint(0, 2, (t, N), device=dev, generator=opts.get("generator"), dtype=torch.int8).to(wd) * 2 - 1
         znorm = B.coldot(zt, zt, N).sqrt()
         zt.div_(znorm.unsqueeze(-1))
-        rhs_t = B.to_probe_major(rhs)
-        dv = torch.zeros(ld, device=dev, dtype=torch.float32)
-        dv[:N] = task_noise.detach().to(torch.float32).repeat(n)
+        rhs_t = B.to_probe_major(rhs, wd)
+        dv = torch.zeros(ld, device=dev, dtype=wd)
+        dv[:N] = task_noise.detach().to(wd).repeat(n)
 
         def partials(dt):
             out = kron_matvec(xp, xp, ktt_d, dt, os_)
@@ -271,7 +273,7 @@ class KroneckerInvQuadLogdetFn(torch.autograd.Function):
 
         solves_t, info = linear_cg(None, None, None, torch.cat([zt, rhs_t], 0).contiguous(), n_tridiag=t, tolerance=opts.get("tolerance"),
                                    kv_partials=partials, dvec=dv, nvec=N)
-        logdet = slq_logdet(info.t_mats, N).to(device=dev, dtype=torch.float32)
+        logdet = slq_logdet(info.t_mats, N).to(device=dev, dtype=wd)
         c = rhs_t.shape[0]
         inv_quad = B.coldot(solves_t[t : t + c], rhs_t, N)
         ctx.xp, ctx.n, ctx.T, ctx.t = xp, n, T, t
@@ -288,8 +290,9 @@ class KroneckerInvQuadLogdetFn(torch.autograd.Function):
         xp, n, T, t = ctx.xp, ctx.n, ctx.T, ctx.t
         N = n * T
         c = ctx.solves_t.shape[0] - t
-        g_iq = g_iq.to(torch.float32).reshape(c, 1)
-        g_ld = g_ld.to(torch.float32).reshape(())
+        wd = xp.dtype
+        g_iq = g_iq.to(wd).reshape(c, 1)
+        g_ld = g_ld.to(wd).reshape(())
         s_z = ctx.solves_t[:t] * ctx.znorm.unsqueeze(-1)
         s_y = ctx.solves_t[t:]
         zr = ctx.zt * ctx.znorm.unsqueeze(-1)
@@ -298,18 +301,18 @@ class KroneckerInvQuadLogdetFn(torch.autograd.Function):
         tc = t + c
         l3 = left[:, :N].reshape(tc, n, T).permute(0, 2, 1).contiguous()   # [tc, T, n]
         r3 = right[:, :N].reshape(tc, n, T).permute(0, 2, 1).contiguous()
-        ktt32 = ktt.detach().to(torch.float32)
+        ktt32 = ktt.detach().to(wd)
         r3k = torch.einsum("ab,cbn->can", ktt32, r3)
         ld_n = B.round_up(n, 4)
 
         def pad(v3):
-            out = torch.zeros(tc * T, ld_n, device=v3.device, dtype=torch.float32)
+            out = torch.zeros(tc * T, ld_n, device=v3.device, dtype=wd)
             out[:, :n] = v3.reshape(tc * T, n)
             return out
 
         lp = pad(l3)
         d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, lp, pad(r3k))
-        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(wd).contiguous()
         m3 = B.kv(xp, xp, pad(r3), scale=os_)[:, :n].reshape(tc, T, n)
         d_ktt = torch.einsum("ctn,csn->ts", l3, m3).to(ktt.dtype)
         d_noise = (l3 * r3).sum(dim=(0, 2)).to(task_noise.dtype)

@@ -376,12 +376,12 @@ class FusedKernelLinearOperator(LinearOperator):
         return torch.Size([self.x1.shape[-2], self.x2.shape[-2]])
 
     def _os(self):
-        return None if self.outputscale is None else self.outputscale.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        return None if self.outputscale is None else self.outputscale.detach().reshape(-1)[:1].to(B.work_dtype(self.x1)).contiguous()
 
     def prepared(self):
         if self._prep is None:
             p1 = B.prep_points(self.spec.kind, self.x1, self.lengthscale, self.spec.shift)
-            p2 = p1 if self.square_same_inputs else B.prep_points(self.spec.kind, self.x2, self.lengthscale, self.spec.shift)
+            p2 = p1 if self.square_same_inputs else B.prep_points(self.spec.kind, self.x2.to(self.x1.dtype), self.lengthscale, self.spec.shift)
             self._prep = (p1, p2)
         return self._prep
 
@@ -469,8 +469,9 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             return None
         if "dvec" not in self._cache:
             n = self.shape[-1]
-            dv = torch.zeros(B.round_up(n, 4), device=self.device, dtype=torch.float32)
-            dv[:n] = self.noise_vec.detach().to(torch.float32)
+            wd = B.work_dtype(self.kernel_op.x1)
+            dv = torch.zeros(B.round_up(n, 4), device=self.device, dtype=wd)
+            dv[:n] = self.noise_vec.detach().to(wd)
             self._cache["dvec"] = dv
         return self._cache["dvec"]
 
@@ -520,7 +521,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         return flag.off() or self.shape[-1] <= settings.max_cholesky_size.value()
 
     def _nz(self):
-        return self.noise.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+        return self.noise.detach().reshape(-1)[:1].to(B.work_dtype(self.kernel_op.x1)).contiguous()
 
     # ---- A.1 dispatch ----
     def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
@@ -556,7 +557,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             return None, None, None
 
         def closure(v):
-            vt = B.to_probe_major(v)
+            vt = B.to_probe_major(v, B.work_dtype(self.kernel_op.x1))
             return B.from_probe_major(pre.apply_(vt, torch.zeros_like(vt)), v.shape[-2]).to(v.dtype)
 
         return closure, None, pre.logdet
@@ -576,7 +577,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             if "precond" not in self._cache:
                 self._cache["precond"] = None if self.noise_vec is not None else build_preconditioner(p1, self.kernel_op._os(), self._nz())
             sol_t, info = linear_cg(
-                p1, self.kernel_op._os(), self._nz(), B.to_probe_major(r.detach()), n_tridiag=0,
+                p1, self.kernel_op._os(), self._nz(), B.to_probe_major(r.detach(), p1.dtype), n_tridiag=0,
                 tolerance=settings.cg_tolerance.value(), preconditioner=self._cache["precond"], dvec=self._dvec(),
             )
             self._cache["last_cg_info"] = info
@@ -592,7 +593,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         if self._use_cholesky(settings.fast_computations.covar_root_decomposition):
             return super().root_inv_decomposition()
         p1, _ = self.kernel_op.prepared()
-        init_t = None if initial_vectors is None else B.to_probe_major(initial_vectors.reshape(self.shape[-1], -1)[:, :1])
+        init_t = None if initial_vectors is None else B.to_probe_major(initial_vectors.reshape(self.shape[-1], -1)[:, :1], B.work_dtype(self.kernel_op.x1))
         rt = root_inv_decomposition(p1, self.kernel_op._os(), self._nz(), init_vec_t=init_t,
                                     generator=self.bbmm_opts.get("generator"), dvec=self._dvec())
         return RootLinearOperator(B.from_probe_major(rt, self.shape[-1]).to(self.dtype))

@@ -138,6 +138,42 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
                       const float* Rt, int64_t ldr, int t, int iso, float* out, double* workspace,
                       int64_t workspace_doubles, void* stream);
 
+/* ---- float64 (the reference honours float64 inputs).  Same conventions with double buffers.  The fused MFMA K*V
+ * kernels are float32-only; in float64 K @ V is formed from dense row blocks of K generated by
+ * gpamd_kernel_rows_f64 (rows == NULL: the block [row0, row0 + nrows)) times V with a library DGEMM by the caller,
+ * then fed to the same device-resident mBCG through gpamd_cg64_reduce_q (S = 1). ---- */
+int gpamd_prep_points_f64(int kind, const double* X, int n, int d, int64_t ldx, const double* ls, int nls,
+                          const double* shift, double* Xp, int dp, void* stream);
+int gpamd_kernel_rows_f64(int kind, const double* X1p, const int64_t* rows, int64_t row0, int nrows, const double* X2p, int m,
+                          int dp, const double* scale, double* out, int64_t ldo, void* stream);
+int gpamd_kernel_diag_f64(int kind, const double* X1p, const double* X2p, int n, int dp, const double* scale, double* out,
+                          void* stream);
+/* Generic-path bilinear derivative, one row block (any dp; replaces, for float64 / d > 16, what gpamd_kv_grad_f32 does
+ * fused; reference: the kernel backward, gpytorch/functions/rbf_covariance.py:26-29, matern_covariance.py:53-56).
+ * W [nrows, ldw]: left^T right on entry, W * dk/ds on exit (s = squared prepared distance);
+ * acc[0] += sum W * k  (acc: one device double, zeroed by the caller). */
+int gpamd_kernel_grad_block_f32(int kind, const float* X1p, int64_t row0, int nrows, const float* X2p, int m, int dp, float* W,
+                                int64_t ldw, double* acc, void* stream);
+int gpamd_kernel_grad_block_f64(int kind, const double* X1p, int64_t row0, int nrows, const double* X2p, int m, int dp, double* W,
+                                int64_t ldw, double* acc, void* stream);
+int gpamd_coldot_f64(const double* A, const double* B, int64_t ld, int n, int t, double* out, double* scratch, void* stream);
+int gpamd_kv_reduce_f64(const double* P, int S, int64_t ldp, int t, int n, const double* scale, const double* dscale,
+                        const double* dvec, const double* Vd, int64_t ldd, double* Out, int64_t ldo, const int* done,
+                        void* stream);
+typedef struct gpamd_cg64 gpamd_cg64_t;
+int64_t gpamd_cg64_fscratch_elems(int t, int hist_len); /* layout / iscratch: as the float32 solver */
+gpamd_cg64_t* gpamd_cg64_create(int n, int t, int64_t ld, double* X, double* R, double* D, double* Q, double* Z,
+                                double* fscratch, int* iscratch, int hist_len, double eps, double stop_updating_after);
+void gpamd_cg64_destroy(gpamd_cg64_t* h);
+int gpamd_cg64_init(gpamd_cg64_t* h, const double* B, int64_t ldb, int have_precond, void* stream);
+int gpamd_cg64_begin(gpamd_cg64_t* h, void* stream);
+int gpamd_cg64_reduce_q(gpamd_cg64_t* h, const double* P, int S, int64_t ldp, const double* scale, const double* dscale,
+                        const double* dvec, void* stream);
+int gpamd_cg64_update_xr(gpamd_cg64_t* h, int k, void* stream);
+int gpamd_cg64_update_d(gpamd_cg64_t* h, int k, void* stream);
+int gpamd_cg64_stop(gpamd_cg64_t* h, int k, int min_iter, int tridiag_floor, double tol, void* stream);
+int gpamd_cg64_finish(gpamd_cg64_t* h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

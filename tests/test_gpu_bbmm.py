@@ -25,7 +25,7 @@ def _setup(kind, n, d, ls, dev, seed=0):
 
     X, y = make_data(n, d, seed)
     shift = None if kind == "rbf" else X.mean(0).to(dev)
-    xp = B.prep_points(kind, X.to(dev), torch.tensor(ls), shift)
+    xp = B.prep_points(kind, X.float().to(dev), torch.tensor(ls), shift)
     return X, y, xp
 
 

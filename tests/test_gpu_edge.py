@@ -25,7 +25,7 @@ def test_duplicate_points_and_extreme_lengthscales(dev):
     rhs = torch.randn(n, 4, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
     for ls in (0.3, 25.0, 0.004):
-        xp = B.prep_points("rbf", X.to(dev), torch.tensor(ls), X.mean(0).to(dev))
+        xp = B.prep_points("rbf", X.float().to(dev), torch.tensor(ls), X.mean(0).to(dev))
         K = OK.rbf(X, X, ls, direct=True)
         out = B.from_probe_major(B.kv(xp, xp, B.to_probe_major(rhs.to(dev))), n)
         assert rel_err(out, K @ rhs) < 5e-5, ls
@@ -42,7 +42,7 @@ def test_nan_rhs_raises_and_nonconvergence_warns(dev):
 
     n = 900
     X, y = make_data(n, 3)
-    xp = B.prep_points("rbf", X.to(dev), torch.tensor(0.25))
+    xp = B.prep_points("rbf", X.float().to(dev), torch.tensor(0.25))
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
     bad = y.clone()
     bad[17] = float("nan")

@@ -130,7 +130,7 @@ def _rank_worker(rank, world, port, q):
     X, y = make_data(n, 3)
     Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
     a, b = D.probe_shard(t_total, world, rank)
-    xp = B.prep_points("rbf", X.to(dev), torch.tensor(0.25), X.mean(0).to(dev))
+    xp = B.prep_points("rbf", X.float().to(dev), torch.tensor(0.25), X.mean(0).to(dev))
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
     res = inv_quad_logdet_forward(xp, sc, s2, B.to_probe_major(y.unsqueeze(-1).to(dev)), precond=None, probes=Z[:, a:b],
                                   tolerance=0.5, group=dist.group.WORLD, t_total=t_total)
@@ -158,7 +158,7 @@ def test_two_rank_probe_sharding_on_device(dev):
     n, t_total = 3000, 16
     X, y = make_data(n, 3)
     Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
-    xp = B.prep_points("rbf", X.to(dev), torch.tensor(0.25), X.mean(0).to(dev))
+    xp = B.prep_points("rbf", X.float().to(dev), torch.tensor(0.25), X.mean(0).to(dev))
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
     rhs = B.to_probe_major(y.unsqueeze(-1).repeat(1, world).to(dev))
     ref = inv_quad_logdet_forward(xp, sc, s2, rhs, precond=None, probes=Z, tolerance=0.5)

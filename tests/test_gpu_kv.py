@@ -26,7 +26,7 @@ KINDS = ["rbf", "matern12", "matern32", "matern52"]
 def _prep(kind, X, ls, dev, shift=None):
     from gpytorch_amd import backend as B
 
-    return B.prep_points(kind, X.to(dev), torch.as_tensor(ls), shift)
+    return B.prep_points(kind, X.float().to(dev), torch.as_tensor(ls), shift)
 
 
 def _oracle_K(kind, X1, X2, ls):

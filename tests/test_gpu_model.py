@@ -98,8 +98,8 @@ def test_kv_grad_kernel_ard_rectangular(dev):
         gl, go = torch.autograd.grad(val, [ls, os_])
         shift = None if kind == "rbf" else X1.mean(0).float().to(dev)
         lsd = ls.detach().float().to(dev)
-        p1 = B.prep_points(kind, X1.to(dev), lsd, shift)
-        p2 = B.prep_points(kind, X2.to(dev), lsd, shift)
+        p1 = B.prep_points(kind, X1.float().to(dev), lsd, shift)
+        p2 = B.prep_points(kind, X2.float().to(dev), lsd, shift)
         d_ls, d_os = hyper_grads(p1, p2, lsd, os_.detach().float().reshape(1).to(dev), B.to_probe_major(Lm.to(dev)), B.to_probe_major(Rm.to(dev)))
         assert rel_err(d_ls, gl) < 1e-3, kind
         assert abs(float(d_os) - float(go)) < 1e-3 * abs(float(go)), kind
