@@ -76,9 +76,11 @@ def probe_vectors(n: int, t: int, precond: Preconditioner | None, device, genera
     ``probes``: optional user-supplied UN-normalised (n, t) matrix (``deterministic_probes``-style
     injection; lets CPU and GPU runs share Z)."""
     ld = B.round_up(n, 4)
-    zt = torch.zeros(t, ld, device=device, dtype=dtype)
     if probes is None and settings.deterministic_probes.on() and settings.deterministic_probes.probe_vectors is not None:
         probes = settings.deterministic_probes.probe_vectors
+    if probes is not None:
+        t = probes.shape[-1]
+    zt = torch.zeros(t, ld, device=device, dtype=dtype)
     if probes is not None:
         zt[:, :n] = probes.to(device=device, dtype=dtype).t()
     elif precond is None:
@@ -150,6 +152,8 @@ def inv_quad_logdet_forward(
         precond = None  # the pivoted-Cholesky preconditioner is built for the constant-diagonal branch only (A.4)
     if precond == "auto":
         precond = build_preconditioner(x, scale, sigma2)
+    if probes is None and settings.deterministic_probes.on() and settings.deterministic_probes.probe_vectors is not None:
+        probes = settings.deterministic_probes.probe_vectors
     if probes is not None:
         t = probes.shape[-1]
     zt, znorm = probe_vectors(n, t, precond, dev, generator, probes, dtype=wd)
