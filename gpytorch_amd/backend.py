@@ -84,7 +84,7 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
         return 0
     if FORCE_KV_FLAGS is not None:
         return FORCE_KV_FLAGS
-    if t <= 8 or x1.kind == "matern12":
+    if x1.kind == "matern12":
         return 0
     return KV_GRAM if max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) <= GRAM_MAX_SQNORM else 0
 

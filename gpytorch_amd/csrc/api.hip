@@ -10,6 +10,7 @@
 #include "cg_kernels.hpp"
 #include "kv_dispatch.hpp"
 #include "kv_valu.hpp"
+#include "kv_gramv.hpp"
 #include "misc_kernels.hpp"
 
 using namespace gpamd;
@@ -103,6 +104,14 @@ int kernel_dims(int d) {  // kernels exist for these valid-dimension counts; oth
 }
 
 const void* family_ptr(int kind, int mode, int d, int v, int ex) {
+  if (mode == KV_MODE_GRAMV) {
+    switch (kind) {
+      case GPAMD_RBF: return kvs_kernel_ptr_rbf(d, v);
+      case GPAMD_MATERN32: return kvs_kernel_ptr_matern32(d, v);
+      case GPAMD_MATERN52: return kvs_kernel_ptr_matern52(d, v);
+    }
+    return nullptr;
+  }
   switch (kind) {
     case GPAMD_RBF: return kv_kernel_ptr_rbf(mode, d, v, ex);
     case GPAMD_MATERN12: return kv_kernel_ptr_matern12(mode, d, v, ex);
@@ -113,8 +122,17 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex) {
 }
 
 int kv_mode(int kind, int flags, const KvVariant& v) {
-  if (v.valu) return KV_MODE_VALU;
-  return ((flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12) ? KV_MODE_GRAM : KV_MODE_MFMA;
+  const bool gram = (flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12;
+  if (v.valu) return gram ? KV_MODE_GRAMV : KV_MODE_VALU;
+  return gram ? KV_MODE_GRAM : KV_MODE_MFMA;
+}
+
+// tile geometry of the selected kernel (the small-t Gram variant uses its own row block / j tile)
+void variant_geometry(int mode, KvVariant* v) {
+  if (mode == KV_MODE_GRAMV) {
+    v->bm = KGV_BM;
+    v->bn = KGV_BN;
+  }
 }
 
 // resident workgroups per CU of the selected kernel (runtime occupancy query; static table without a device)
@@ -135,6 +153,7 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
   KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t);
   const int mode = kv_mode(kind, flags, v);
+  variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
   const long slots = (long)num_cus() * wg_per_cu(kind, mode, kernel_dims(d), v);
   const int min_chunk = 16 * v.bn;
@@ -216,6 +235,8 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0);
     KvVariant v = pick_variant(tg);
+    const int mode = kv_mode(kind, flags, v);
+    variant_geometry(mode, &v);
     KvArgs a;
     a.X1 = X1p; a.X2 = X2p;
     a.Vt = Vt + (int64_t)g0 * ldv;
@@ -226,7 +247,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
-    const void* fn = family_ptr(kind, kv_mode(kind, flags, v), dk, v.valu ? v.tpad : v.ct, v.ex);
+    const void* fn = family_ptr(kind, mode, dk, v.valu ? v.tpad : v.ct, v.ex);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
     void* kargs[] = {(void*)&a};
     (void)hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, 0, st);

@@ -1,0 +1,102 @@
+// Squared distances on the matrix pipe at the f16 rate, at f32 accuracy: hi/lo-split augmented coordinates.
+//
+// kv_gram.hpp's first form fed the quadratic expansion  S_ji = |z_j|^2 + |z_i|^2 - 2 z_j.z_i  to
+// v_mfma_f32_32x32x2_f32: ceil((D+2)/2) instructions of 64 cycles per 32x32 block -- 9 % (D = 3) to 19 % (D = 10) of
+// the matrix-pipe time of a 64-column product.  Here every f32 operand x is split exactly as  x = hi + lo,
+// hi = f16(x), lo = f16(x - hi)  (22 significant bits), and the expansion becomes a sum of f16 x f16 products
+//     z_j.(-2 z_i) = sum_q  ah bh + ah bl + al bh (+ al bl)          (a = z_j, b = -2 z_i)
+//     |z_j|^2 * 1 + 1 * |z_i|^2  with both norms split the same way
+// i.e. NS = NT*D + 4 "slots" (NT = 4 product terms per dimension, 3 for D >= 12 where al*bl is dropped), which ONE
+// v_mfma_f32_32x32x16_f16 (16 slots, 32 cycles, products exact, f32 accumulate) evaluates for D <= 3, two for D <= 7,
+// three for D <= 11: 1/6 to 1/4 of the f32 form's matrix-pipe time.  The C/D layout of the 32x32 MFMAs does not depend
+// on the input type, so the result registers are still exactly this lane's B operands of the contraction steps.
+//
+// Accuracy (scripts/micro/gram_f16.hip, checked against float64 on the device): max |S - S_exact| = 6.8e-6 at
+// max |z|^2 = 32 (relative error 4.7e-6 in K = 2^-S), 6e-8 absolute floor near S = 0 (f16 subnormal spacing of the split
+// norms) -- inside the 1e-5 bound the host's |z|^2 <= 32 selection rule already assumes.
+#pragma once
+#include "common.hpp"
+
+namespace gpamd {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int D>
+struct GramF16 {
+  static constexpr int NT = (D <= 11) ? 4 : 3;   // product terms per dimension
+  static constexpr int NS = NT * D + 4;          // slots: products + |z_j|^2 (hi, lo) + |z_i|^2 (hi, lo)
+  static constexpr int KH = (NS + 15) / 16;      // 32x32x16 MFMAs per 32x32 block
+};
+
+__device__ __forceinline__ void f16_split(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+
+// A side (contracted points x_j): slot s of a row with coordinates split into zh/zl and |z|^2 into nh/nl
+template <int D>
+__device__ __forceinline__ _Float16 gram_slot_a(int s, const _Float16* zh, const _Float16* zl, _Float16 nh, _Float16 nl,
+                                                _Float16 valid) {
+  constexpr int NT = GramF16<D>::NT;
+  if (s < NT * D) return (s % NT) < 2 ? zh[s / NT] : zl[s / NT];
+  const int u = s - NT * D;
+  return u == 0 ? nh : (u == 1 ? nl : (u < 4 ? valid : (_Float16)0.f));
+}
+
+// B side (output points x_i): coordinates are those of -2 z_i
+template <int D>
+__device__ __forceinline__ _Float16 gram_slot_b(int s, const _Float16* bh, const _Float16* bl, _Float16 nh, _Float16 nl) {
+  constexpr int NT = GramF16<D>::NT;
+  if (s < NT * D) return ((s % NT) & 1) == 0 ? bh[s / NT] : bl[s / NT];
+  const int u = s - NT * D;
+  return u < 2 ? (_Float16)1.f : (u == 2 ? nh : (u == 3 ? nl : (_Float16)0.f));
+}
+
+// B operands of one output row for this lane's k-group h (elements 8h .. 8h+7 of every 16-slot group)
+template <int D>
+__device__ __forceinline__ void gram_pack_b(const float* z, int h, f16x8* out /* [KH] */) {
+  constexpr int KH = GramF16<D>::KH;
+  _Float16 bh[D], bl[D], nh, nl;
+  float nn = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    nn = __builtin_fmaf(z[k], z[k], nn);
+    f16_split(-2.f * z[k], bh[k], bl[k]);
+  }
+  f16_split(nn, nh, nl);
+#pragma unroll
+  for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 v0 = gram_slot_b<D>(kh * 16 + e, bh, bl, nh, nl);
+      const _Float16 v1 = gram_slot_b<D>(kh * 16 + 8 + e, bh, bl, nh, nl);
+      out[kh][e] = h ? v1 : v0;
+    }
+}
+
+// A operands of one contracted row, written to LDS planes Xh[kh][row][16]  (row stride 32 B: the 64 lanes of a wave
+// read 1 KB contiguous -> conflict-free ds_read_b128)
+template <int D>
+__device__ __forceinline__ void gram_pack_a(const float* z, bool valid, _Float16* Xh, int row, int BN) {
+  constexpr int KH = GramF16<D>::KH;
+  _Float16 zh[D], zl[D], nh, nl;
+  float nn = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    nn = __builtin_fmaf(z[k], z[k], nn);
+    f16_split(z[k], zh[k], zl[k]);
+  }
+  f16_split(nn, nh, nl);
+  const _Float16 one = valid ? (_Float16)1.f : (_Float16)0.f;
+#pragma unroll
+  for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      f16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gram_slot_a<D>(kh * 16 + 8 * hh + e, zh, zl, nh, nl, one);
+      *reinterpret_cast<f16x8*>(&Xh[((kh * BN) + row) * 16 + 8 * hh]) = v;
+    }
+}
+
+}  // namespace gpamd

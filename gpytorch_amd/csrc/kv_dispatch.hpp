@@ -4,7 +4,7 @@
 
 namespace gpamd {
 
-enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2 };
+enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3 };
 
 // MFMA / Gram variants: CT 32-column tiles (1..4) + EX extra VALU column; NI row tiles per wave by CT.
 // NI*CT*16 accumulator registers: 64 (CT <= 2) .. 128 (CT = 4)
@@ -15,5 +15,10 @@ const void* kv_kernel_ptr_rbf(int mode, int d, int v, int ex);
 const void* kv_kernel_ptr_matern12(int mode, int d, int v, int ex);
 const void* kv_kernel_ptr_matern32(int mode, int d, int v, int ex);
 const void* kv_kernel_ptr_matern52(int mode, int d, int v, int ex);
+
+// small-t Gram-form kernels (kvs_<family>.hip; none for Matern nu = 1/2)
+const void* kvs_kernel_ptr_rbf(int d, int tpad);
+const void* kvs_kernel_ptr_matern32(int d, int tpad);
+const void* kvs_kernel_ptr_matern52(int d, int tpad);
 
 }  // namespace gpamd

@@ -20,21 +20,27 @@
 // the other with occupancy forced to three waves/SIMD (+1 %, needs spills), register prefetch of the next tile
 // across the MFMA phase (0 %), both together (-4 %).  The structure sits at ~122 TFLOP/s; the same loop without
 // any generation reaches 140 (profiles/r01_s4_kv_tune_variants.jsonl).
+// Since session s17 the Gram block itself runs at the f16 MFMA rate on hi/lo-split coordinates (gram_f16.hpp):
+// GramF16<D>::KH instructions of 32 cycles instead of KA of 64.
 #pragma once
+#include "gram_f16.hpp"
 #include "kv_mfma.hpp"
 
 namespace gpamd {
 
+// Register budget: 64 accumulators (CT <= 2) fit three waves per SIMD (<= 168 unified registers) only if the
+// allocator is told to: left alone it parks the 16 distance registers in AGPRs (v_accvgpr_read before every v_exp)
+// and lands at 180.
 template <int KIND, int D, int CT, int NI, int EX>
-__global__ __launch_bounds__(256) void kv_gram_kernel(KvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT <= 2 ? 3 : 2, CT <= 2 ? 3 : 2)))
+void kv_gram_kernel(KvArgs a) {
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
-  constexpr int KA = (D + 2 + 1) / 2;   // MFMA k-steps (2 augmented coordinates each)
-  constexpr int LDA = 2 * KA + 1;       // odd LDS row stride of the augmented x_j tile -> conflict-free b32 reads
+  constexpr int KH = GramF16<D>::KH;    // 32x32x16 f16 MFMAs per 32x32 block of squared distances
   constexpr int BN = KV_BN, LDT = KV_LDT, TC = 32 * CT;
-  __shared__ __attribute__((aligned(16))) float smem[TC * LDT + BN * LDA + BN + 3];
+  __shared__ __attribute__((aligned(16))) float smem[TC * LDT + BN + KH * BN * 8];
   float* Vs = smem;
   float* Es = smem + TC * LDT;          // 16-B aligned (TC*LDT*4 is a multiple of 16)
-  float* Xa = Es + BN;
+  _Float16* Xh = reinterpret_cast<_Float16*>(Es + BN);   // [KH][BN][16] split augmented x_j rows
 
   if (a.done && *a.done) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,8 +51,8 @@ __global__ __launch_bounds__(256) void kv_gram_kernel(KvArgs a) {
   const int jend = min(a.m, jbeg + a.jchunk);
   const int ibase = rb * (4 * NI * 32) + wave * (NI * 32);
 
-  // B operand of the Gram MFMAs: Baug[k = 2q + h][i]
-  float bq[NI][KA];
+  // B operands of the Gram MFMAs (this lane's output row, k-group h), kept in registers for the whole kernel
+  f16x8 bq[NI][KH];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int i = min(ibase + ni * 32 + l31, a.n - 1);
@@ -56,19 +62,7 @@ __global__ __launch_bounds__(256) void kv_gram_kernel(KvArgs a) {
       f32x4 v = *reinterpret_cast<const f32x4*>(a.X1 + (int64_t)i * DP + 4 * q);
       z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
     }
-    float nn = 0.f;
-#pragma unroll
-    for (int k = 0; k < D; ++k) nn = __builtin_fmaf(z[k], z[k], nn);
-#pragma unroll
-    for (int q = 0; q < KA; ++q) {
-      float v0, v1;  // rows 2q, 2q+1 of Baug
-      {
-        const int k0 = 2 * q, k1 = 2 * q + 1;
-        v0 = (k0 < D) ? -2.f * z[k0 < D ? k0 : 0] : (k0 == D ? 1.f : (k0 == D + 1 ? nn : 0.f));
-        v1 = (k1 < D) ? -2.f * z[k1 < D ? k1 : 0] : (k1 == D ? 1.f : (k1 == D + 1 ? nn : 0.f));
-      }
-      bq[ni][q] = h ? v1 : v0;
-    }
+    gram_pack_b<D>(z, h, bq[ni]);
   }
 
   f32x16 acc[NI][CT];
@@ -114,8 +108,8 @@ __global__ __launch_bounds__(256) void kv_gram_kernel(KvArgs a) {
         if (r0 + rr < VQ) *reinterpret_cast<f32x4*>(&Vs[c * LDT + 4 * q]) = vreg[rr];
       }
     }
-    // augmented x_j rows: [z_j (D), |z_j|^2, 1, 0-pad]   (rows beyond jend: all zero -> S = |z_i|^2, k finite;
-    // their V entries are zero so they contribute nothing)
+    // split augmented x_j rows (rows beyond jend: all zero -> S = 0, k = 1; their V entries are zero so they
+    // contribute nothing)
     if (tid < BN) {
       const int j = j0 + tid;
       float z[DP];
@@ -125,14 +119,7 @@ __global__ __launch_bounds__(256) void kv_gram_kernel(KvArgs a) {
         if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP + 4 * q);
         z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
       }
-      float nn = 0.f;
-#pragma unroll
-      for (int k = 0; k < D; ++k) nn = __builtin_fmaf(z[k], z[k], nn);
-#pragma unroll
-      for (int k = 0; k < 2 * KA; ++k) {
-        float v = (k < D) ? z[k < D ? k : 0] : (k == D ? nn : (k == D + 1 ? (j < jend ? 1.f : 0.f) : 0.f));
-        Xa[tid * LDA + k] = v;
-      }
+      gram_pack_a<D>(z, j < jend, Xh, tid, BN);
     }
     if constexpr (EX) {
       if (tid < BN / 4) {
@@ -165,10 +152,10 @@ __global__ __launch_bounds__(256) void kv_gram_kernel(KvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) kk[ni][r] = 0.f;
 #pragma unroll
-      for (int q = 0; q < KA; ++q) {
-        const float aq = Xa[(jb + l31) * LDA + 2 * q + h];
+      for (int kh = 0; kh < KH; ++kh) {
+        const f16x8 aq = *reinterpret_cast<const f16x8*>(&Xh[(kh * BN + jb + l31) * 16 + 8 * h]);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) kk[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, bq[ni][q], kk[ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) kk[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq[ni][kh], kk[ni], 0, 0, 0);
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)

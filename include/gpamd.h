@@ -34,7 +34,7 @@ enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 /* kv flags.  GPAMD_KV_GRAM: the caller asserts max |z|^2 <= 32 over both prepared clouds (after centring), so
  * the squared distances may be formed by the quadratic expansion on the matrix pipe (kv_gram.hpp; the expansion
  * the reference itself uses, gpytorch/kernels/kernel.py:26-49) with <= 1e-5 relative error in K.  Ignored for
- * Matern nu = 1/2 and for t <= 8. */
+ * Matern nu = 1/2. */
 enum { GPAMD_KV_GRAM = 1 };
 
 int gpamd_abi_version(void);
