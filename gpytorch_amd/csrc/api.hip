@@ -104,6 +104,14 @@ int kernel_dims(int d) {  // kernels exist for these valid-dimension counts; oth
 }
 
 const void* family_ptr(int kind, int mode, int d, int v, int ex) {
+  if (mode == KV_MODE_GRAM2) {
+    switch (kind) {
+      case GPAMD_RBF: return kvs2_kernel_ptr_rbf(d, v, ex);
+      case GPAMD_MATERN32: return kvs2_kernel_ptr_matern32(d, v, ex);
+      case GPAMD_MATERN52: return kvs2_kernel_ptr_matern52(d, v, ex);
+    }
+    return nullptr;
+  }
   if (mode == KV_MODE_GRAMV) {
     switch (kind) {
       case GPAMD_RBF: return kvs_kernel_ptr_rbf(d, v);
@@ -121,9 +129,10 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex) {
   return nullptr;
 }
 
-int kv_mode(int kind, int flags, const KvVariant& v) {
+int kv_mode(int kind, int flags, int d, const KvVariant& v) {
   const bool gram = (flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12;
   if (v.valu) return gram ? KV_MODE_GRAMV : KV_MODE_VALU;
+  if (gram && (flags & GPAMD_KV_ASYNC) && v.ct == 2 && d <= 4) return KV_MODE_GRAM2;
   return gram ? KV_MODE_GRAM : KV_MODE_MFMA;
 }
 
@@ -142,7 +151,8 @@ int wg_per_cu(int kind, int mode, int dk, const KvVariant& v) {
   if (fn && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) return nb;
   (void)hipGetLastError();
   if (v.valu) return 4;
-  if (mode == KV_MODE_GRAM) return 2;
+  if (mode == KV_MODE_GRAM) return 3;
+  if (mode == KV_MODE_GRAM2) return 2;
   return v.ct <= 2 ? 3 : 2;
 }
 
@@ -152,7 +162,7 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // full (efficiency = units / (rounds * slots)), keeping every chunk >= 16 LDS tiles (per-unit prologue
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
   KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t);
-  const int mode = kv_mode(kind, flags, v);
+  const int mode = kv_mode(kind, flags, d, v);
   variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
   const long slots = (long)num_cus() * wg_per_cu(kind, mode, kernel_dims(d), v);
@@ -235,7 +245,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0);
     KvVariant v = pick_variant(tg);
-    const int mode = kv_mode(kind, flags, v);
+    const int mode = kv_mode(kind, flags, d, v);
     variant_geometry(mode, &v);
     KvArgs a;
     a.X1 = X1p; a.X2 = X2p;

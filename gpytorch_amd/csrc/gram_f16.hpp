@@ -28,9 +28,15 @@ struct GramF16 {
   static constexpr int KH = (NS + 15) / 16;      // 32x32x16 MFMAs per 32x32 block
 };
 
+// hi + lo == v to 22 bits REQUIRES lo to be computed from the very hi that is stored.  The optimiser is free to
+// re-derive "(_Float16)v" from a recomputed v (e.g. |z|^2 contracted differently in two places, 1 ulp apart): when v
+// sits on an f16 rounding tie the two copies land on different neighbours and hi + lo is off by a whole f16 ulp
+// (found by scripts/micro/pack_check.hip: one point in 1300, 2e-3 error in S).  The empty asm pins hi's float image.
 __device__ __forceinline__ void f16_split(float v, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)v;
-  lo = (_Float16)(v - (float)hi);
+  float hf = (float)(_Float16)v;
+  asm volatile("" : "+v"(hf));
+  hi = (_Float16)hf;  // exact: hf is an f16 value
+  lo = (_Float16)(v - hf);
 }
 
 // A side (contracted points x_j): slot s of a row with coordinates split into zh/zl and |z|^2 into nh/nl
@@ -70,6 +76,29 @@ __device__ __forceinline__ void gram_pack_b(const float* z, int h, f16x8* out /*
     for (int e = 0; e < 8; ++e) {
       const _Float16 v0 = gram_slot_b<D>(kh * 16 + e, bh, bl, nh, nl);
       const _Float16 v1 = gram_slot_b<D>(kh * 16 + 8 + e, bh, bl, nh, nl);
+      out[kh][e] = h ? v1 : v0;
+    }
+}
+
+// A operands of one contracted row for this lane's k-group h, in registers (kv_gram2.hpp: every wave splits its own rows)
+template <int D>
+__device__ __forceinline__ void gram_pack_a_lane(const float* z, bool valid, int h, f16x8* out /* [KH] */) {
+  constexpr int KH = GramF16<D>::KH;
+  _Float16 zh[D], zl[D], nh, nl;
+  float nn = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    nn = __builtin_fmaf(z[k], z[k], nn);
+    f16_split(z[k], zh[k], zl[k]);
+  }
+  f16_split(nn, nh, nl);
+  const _Float16 one = valid ? (_Float16)1.f : (_Float16)0.f;
+#pragma unroll
+  for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 v0 = gram_slot_a<D>(kh * 16 + e, zh, zl, nh, nl, one);
+      const _Float16 v1 = gram_slot_a<D>(kh * 16 + 8 + e, zh, zl, nh, nl, one);
       out[kh][e] = h ? v1 : v0;
     }
 }
