@@ -403,6 +403,40 @@ int gpamd_cg_init_f32(gpamd_cg_t* h, const float* B, int64_t ldb, int have_preco
   return check_launch("cg_init");
 }
 
+// ---- row-sharded solves: gpamd_cg_init_f32 split at the points where the host all-reduces the partial sums -------------
+int gpamd_cg_partials_layout(int n, int t, int hist_len, int64_t* offs, int* stride, int* nb) {
+  if (!offs || !stride || !nb || n <= 0 || t <= 0 || hist_len < 0) return fail(GPAMD_EINVAL, "cg_partials_layout: bad arguments");
+  const int64_t base = (int64_t)4 * t + 4 + (int64_t)2 * hist_len * t;
+  offs[0] = base;                               // part_a : d^T q (and ||b||^2 during init)
+  offs[1] = base + (int64_t)t * CG_MAXNB;       // part_rz: r^T z
+  offs[2] = base + (int64_t)2 * t * CG_MAXNB;   // part_rr: r^T r
+  *stride = CG_MAXNB;
+  *nb = (int)col_blocks(n);
+  return 0;
+}
+
+int gpamd_cg_init_norms_f32(gpamd_cg_t* h, const float* B, int64_t ldb, void* stream) {
+  if (!h || ldb % 4) return fail(GPAMD_EINVAL, "cg_init_norms: bad arguments");
+  CgState<float>& s = h->st;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(s.done, 0, 2 * sizeof(int), st);
+  hipLaunchKernelGGL((coldot_kernel<float>), dim3(s.nb, s.t), dim3(256), 0, st, B, B, ldb, s.n, s.part_a, (const int*)nullptr);
+  return check_launch("cg_init_norms");
+}
+
+int gpamd_cg_init_apply_f32(gpamd_cg_t* h, const float* B, int64_t ldb, int copy_d, void* stream) {
+  if (!h || ldb % 4) return fail(GPAMD_EINVAL, "cg_init_apply: bad arguments");
+  CgState<float>& s = h->st;
+  hipLaunchKernelGGL((cg_init_kernel<float>), dim3(s.nb, s.t), dim3(256), 0, (hipStream_t)stream, s, B, ldb, copy_d ? 1 : 0);
+  return check_launch("cg_init_apply");
+}
+
+int gpamd_cg_begin_apply_f32(gpamd_cg_t* h, void* stream) {
+  if (!h) return fail(GPAMD_EINVAL, "cg_begin_apply: null handle");
+  hipLaunchKernelGGL((cg_begin_kernel<float>), dim3(h->st.t), dim3(256), 0, (hipStream_t)stream, h->st);
+  return check_launch("cg_begin_apply");
+}
+
 int gpamd_cg_begin_f32(gpamd_cg_t* h, void* stream) {
   if (!h) return fail(GPAMD_EINVAL, "cg_begin: null handle");
   CgState<float>& s = h->st;

@@ -1,4 +1,5 @@
-"""Multi-GPU host logic: probe-column sharding (design 1).
+"""Multi-GPU host logic: probe-column sharding (design 1) and row sharding for the small-t
+solves (design 2, :class:`RowShard`).
 
 One process per GPU (``torch.distributed``; backend "nccl" == RCCL over xGMI on ROCm, "gloo" in the
 CPU tests).  X is replicated, the probe vectors are partitioned over ranks, and because every mBCG
@@ -63,3 +64,92 @@ def allreduce_sum_(t: torch.Tensor, group=None):
         else:
             dist.all_reduce(t, group=group)
     return t
+
+
+class RowShard:
+    """Row sharding of K_hat for solves with few right-hand sides.
+
+    Rank g owns the contiguous rows ``[g * n_pad, min(n, (g+1) * n_pad))`` of K_hat (``n_pad`` = ceil(n / G) rounded up
+    to 4); X is replicated.  Per product: one all-gather of the t local vector slices (n * t * 4 bytes in total;
+    t = 1 for the predictive-mean CG and Lanczos) followed by a RECTANGULAR fused K*V (local rows x all columns: 1/G of
+    the kernel-generation work, which is what bounds these products).  Per CG iteration: two all-reduces of t partial
+    sums (d^T q; r^T r).  The padded tail ``[n, G * n_pad)`` of the gathered vectors is identically zero, so the rows
+    appended to the replicated cloud for it (copies of the last point) never contribute."""
+
+    def __init__(self, xp_full, group):
+        from . import backend as B
+
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        n = xp_full.n
+        self.n = n
+        self.n_pad = B.round_up((n + self.world - 1) // self.world, 4)
+        self.r0 = self.rank * self.n_pad
+        self.r1 = min(n, self.r0 + self.n_pad)
+        if (self.world - 1) * self.n_pad >= n:
+            raise ValueError(f"row sharding needs at least one row per rank (n = {n}, world = {self.world})")
+        self.n_loc = self.r1 - self.r0
+        self.np_all = self.world * self.n_pad
+        xp = xp_full.xp
+        self.x_loc = B.PreparedPoints(xp[self.r0 : self.r1], self.n_loc, xp_full.d, xp_full.dp, xp_full.kind)
+        if self.np_all > n:
+            xp = torch.cat([xp, xp[-1:].expand(self.np_all - n, xp.shape[1])], dim=0).contiguous()
+        self.x_all = B.PreparedPoints(xp, self.np_all, xp_full.d, xp_full.dp, xp_full.kind)
+        self.x_all._zmax2 = xp_full.zmax2
+        self.x_loc._zmax2 = xp_full.zmax2
+
+    # ---- vectors: probe-major [t, ld] ------------------------------------------------------------------------------
+    def local(self, full_t: torch.Tensor) -> torch.Tensor:
+        """[t, >= n] -> this rank's slice as a fresh probe-major [t, round_up(n_loc, 4)] tensor."""
+        from . import backend as B
+
+        out = torch.zeros(full_t.shape[0], B.round_up(self.n_loc, 4), device=full_t.device, dtype=full_t.dtype)
+        out[:, : self.n_loc] = full_t[:, self.r0 : self.r1]
+        return out
+
+    def gather(self, loc_t: torch.Tensor) -> torch.Tensor:
+        """Local slices [t, >= n_loc] of every rank -> [t, G * n_pad] (zero in the padded tail of every slice)."""
+        t = loc_t.shape[0]
+        send = torch.zeros(t, self.n_pad, device=loc_t.device, dtype=loc_t.dtype)
+        send[:, : self.n_loc] = loc_t[:, : self.n_loc]
+        recv = torch.empty(self.world * t, self.n_pad, device=loc_t.device, dtype=loc_t.dtype)  # rank-major concatenation
+        if loc_t.is_cuda and dist.get_backend(self.group) == "gloo":
+            r = recv.cpu()
+            dist.all_gather_into_tensor(r, send.cpu(), group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        if t == 1:
+            return recv.reshape(1, self.np_all)
+        return recv.view(self.world, t, self.n_pad).permute(1, 0, 2).reshape(t, self.np_all).contiguous()
+
+    def kv_local(self, loc_t: torch.Tensor, scale=None, dscale=None, dvec_loc=None) -> torch.Tensor:
+        """This rank's rows of (scale * K + dscale * I + diag(dvec)) @ V for V given by its local slices."""
+        from . import backend as B
+
+        full = self.gather(loc_t)
+        return B.kv(self.x_loc, self.x_all, full, scale=scale, dscale=dscale, vd=loc_t if dscale is not None else None, dvec=dvec_loc)
+
+    def allreduce_partials(self, fscratch: torch.Tensor, offset: int, t: int, stride: int):
+        """Sum over ranks of one of the solver's per-column partial arrays (include/gpamd.h, gpamd_cg_partials_layout):
+        collapse each column's partials, all-reduce the t sums, store them in entry 0 and clear the rest."""
+        v = fscratch[offset : offset + t * stride].view(t, stride)
+        sums = v.sum(dim=1)
+        allreduce_sum_(sums, self.group)
+        v.zero_()
+        v[:, 0] = sums
+
+    def allreduce(self, x: torch.Tensor) -> torch.Tensor:
+        return allreduce_sum_(x, self.group)
+
+    def broadcast(self, x: torch.Tensor) -> torch.Tensor:
+        """In place, from the first rank of the group."""
+        src = dist.get_global_rank(self.group, 0) if self.group is not dist.group.WORLD else 0
+        if x.is_cuda and dist.get_backend(self.group) == "gloo":
+            tmp = x.detach().cpu()
+            dist.broadcast(tmp, src=src, group=self.group)
+            x.copy_(tmp)
+        else:
+            dist.broadcast(x, src=src, group=self.group)
+        return x

@@ -33,6 +33,7 @@ from ._lib import check, lib
 # When set to a list, every fused K*V launch of the CG loop is bracketed by HIP events on the launch
 # stream and (start, end, n, t) is appended -- bench.py uses it to time the dominant kernel live.
 KV_EVENT_LOG: list | None = None
+LAST_INFO = None  # CGInfo of the most recent solve in this process (diagnostics / tests)
 
 
 class NumericalWarning(RuntimeWarning):
@@ -110,15 +111,27 @@ def linear_cg(
     kv_partials=None,
     dvec: torch.Tensor | None = None,
     nvec: int | None = None,
+    row_shard=None,
 ):
     """Solve (scale*K(x,x) + dscale*I + diag(dvec)) X = rhs for all rows of ``rhs_t`` ([t, ld], probe-major).
 
     ``kv_partials(Dt) -> (P, S, ldp)``: optional override of the noise-free operator product (used by the
     multitask Kronecker operator, whose vectors have length n*T): returns partial slabs ``P[S][t][ldp]`` whose
     sum is ``K_op @ D``; ``x`` may then be ``None`` and the vector length is taken from ``nvec``.
+    ``row_shard`` (:class:`gpytorch_amd.distributed.RowShard`): this rank owns a block of ROWS of the system; ``rhs_t``,
+    ``dvec`` and the returned solves are its local slices, products gather the search directions over ranks, and the
+    solver's inner products are all-reduced (float32, no preconditioner).
     Returns (solves_t [t, ld], CGInfo)."""
     B._require_gpu(rhs_t, "rhs")
     L = lib()
+    if row_shard is not None:
+        if preconditioner is not None or rhs_t.dtype != torch.float32 or kv_partials is not None:
+            raise NotImplementedError("row-sharded solves: float32, no preconditioner, fused kernel operator")
+        x, nvec = None, row_shard.n_loc
+
+        def kv_partials(dt_, _rs=row_shard):
+            out = _rs.kv_local(dt_)  # unscaled K[rows, :] @ D; scale / noise are applied by reduce_q
+            return out, 1, out.stride(0)
     n = x.n if nvec is None else nvec
     if x is not None and rhs_t.dtype != x.dtype:
         rhs_t = rhs_t.to(x.dtype)  # the solve runs in the dtype of the prepared points
@@ -166,8 +179,23 @@ def linear_cg(
         def kv_partials(dt_, _x=x):
             out = B.kv_chunked(_x, _x, dt_)
             return out, 1, out.stride(0)
+    if row_shard is not None:
+        po = (C.c_int64 * 3)()
+        pstride, pnb = C.c_int(), C.c_int()
+        check(L.gpamd_cg_partials_layout(n, t, hist, po, C.byref(pstride), C.byref(pnb)), "cg_partials_layout")
+
+        def ar(which):
+            row_shard.allreduce_partials(fs, int(po[which]), t, pstride.value)
     try:
-        check(F["init"](h, B._ptr(rhs_t), rhs_t.stride(0), 1 if preconditioner is not None else 0, st), "cg_init")
+        if row_shard is not None:
+            check(L.gpamd_cg_init_norms_f32(h, B._ptr(rhs_t), rhs_t.stride(0), st), "cg_init_norms")
+            ar(0)
+            check(L.gpamd_cg_init_apply_f32(h, B._ptr(rhs_t), rhs_t.stride(0), 1, st), "cg_init_apply")
+            ar(2)
+            ar(1)
+            check(L.gpamd_cg_begin_apply_f32(h, st), "cg_begin_apply")
+        else:
+            check(F["init"](h, B._ptr(rhs_t), rhs_t.stride(0), 1 if preconditioner is not None else 0, st), "cg_init")
         if preconditioner is not None:
             preconditioner.apply_(Rt, Zt)
             Dt.copy_(Zt)
@@ -204,7 +232,12 @@ def linear_cg(
                 ev[1].record(torch.cuda.current_stream(dev))
                 KV_EVENT_LOG.append((ev[0], ev[1], n, t, k))
             check(F["reduce_q"](h, B._ptr(P), S, ldp, B._ptr(scale), B._ptr(dscale), B._ptr(dvec), st), "cg_reduce_q")
+            if row_shard is not None:
+                ar(0)
             check(F["update_xr"](h, k, st), "cg_update_xr")
+            if row_shard is not None:
+                ar(2)
+                ar(1)
             if preconditioner is not None:
                 preconditioner.apply_(Rt, Zt)
             check(F["update_d"](h, k, st), "cg_update_d")
@@ -241,4 +274,6 @@ def linear_cg(
             t_mats = build_tridiag(a_h, b_h, iters, tolerance_reached, n_tri_iter)
     finally:
         (L.gpamd_cg64_destroy if f64 else L.gpamd_cg_destroy)(h)
-    return Xt, CGInfo(iters, tolerance_reached, rnorm, t_mats)
+    global LAST_INFO
+    LAST_INFO = CGInfo(iters, tolerance_reached, rnorm, t_mats)
+    return Xt, LAST_INFO

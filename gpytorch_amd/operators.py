@@ -538,12 +538,32 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
                 drop = True
             else:
                 drop = False
-            iq, ld = InvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec(), self.bbmm_opts)
+            iq, ld = InvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec(), self._iql_opts())
             if drop:
                 iq = iq[:0]
         if reduce_inv_quad:
             iq = iq.sum(-1)
         return iq, (ld if logdet else None)
+
+    def _iql_opts(self) -> dict:
+        """Solver options of this evaluation: ``bbmm_opts`` completed with the ``settings.sharding`` probe group
+        (each rank then draws its share of ``num_trace_samples`` from a rank-specific generator)."""
+        opts = self.bbmm_opts
+        group = opts.get("group", settings.sharding.probe_group())
+        if group is None or "group" in opts or torch.distributed.get_world_size(group) == 1:
+            return opts
+        from .distributed import probe_shard
+
+        world, rank = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
+        t_total = settings.num_trace_samples.value()
+        a, b = probe_shard(t_total, world, rank)
+        if b - a < 1:
+            raise ValueError(f"probe sharding needs num_trace_samples >= world size ({t_total} < {world})")
+        opts = dict(opts, group=group, num_probes=b - a, t_total=t_total)
+        if "generator" not in opts and opts.get("probes") is None:
+            opts["generator"] = torch.Generator(device=self.device).manual_seed(torch.initial_seed() % (2**31) + 7919 * (rank + 1))
+        self._shared_opts = opts  # InvQuadLogdetFn stores "_last_info" in the dict it is given
+        return opts
 
     def _preconditioner(self):
         """``AddedDiagLinearOperator._preconditioner``: (closure on [n, c] tensors, None, logdet) or Nones."""
@@ -572,6 +592,8 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         r = rhs.unsqueeze(-1) if squeeze else rhs
         if self._use_cholesky(settings.fast_computations.solves):
             sol = torch.cholesky_solve(r.detach().to(torch.float64), torch.linalg.cholesky(self.to_dense().detach().to(torch.float64))).to(rhs.dtype)
+        elif self._row_shard() is not None:
+            sol = self._solve_row_sharded(r).to(rhs.dtype)
         else:
             p1, _ = self.kernel_op.prepared()
             if "precond" not in self._cache:
@@ -586,12 +608,61 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             sol = lhs @ sol
         return sol.squeeze(-1) if squeeze else sol
 
+    # ---- row-sharded small-t solves (settings.sharding(row_group=...) or bbmm_opts["row_group"]) ----
+    def _row_shard(self):
+        group = self.bbmm_opts.get("row_group", settings.sharding.row_group())
+        if group is None or torch.distributed.get_world_size(group) == 1:
+            return None
+        p1, _ = self.kernel_op.prepared()
+        if not p1.fused:
+            return None  # generic path (float64 / d > 16): replicated solve
+        if "row_shard" not in self._cache:
+            from .distributed import RowShard
+
+            self._cache["row_shard"] = RowShard(p1, group)
+        return self._cache["row_shard"]
+
+    def _dvec_local(self, rs):
+        dv = self._dvec()
+        return None if dv is None else rs.local(dv.unsqueeze(0))[0]
+
+    def _solve_row_sharded(self, r: torch.Tensor) -> torch.Tensor:
+        """K_hat^-1 r with every rank owning a block of rows; returns the FULL solution [n, c] on every rank."""
+        from .linear_cg import linear_cg
+
+        rs = self._row_shard()
+        n = self.shape[-1]
+        rhs_loc = rs.local(B.to_probe_major(r.detach()))
+        sol_loc, info = linear_cg(None, self.kernel_op._os(), self._nz(), rhs_loc, n_tridiag=0, tolerance=settings.cg_tolerance.value(),
+                                  dvec=self._dvec_local(rs), row_shard=rs)
+        self._cache["last_cg_info"] = info
+        return B.from_probe_major(rs.gather(sol_loc), n)
+
+    def _root_inv_row_sharded(self, init_t):
+        from .lanczos import root_inv_decomposition
+
+        rs = self._row_shard()
+        n = self.shape[-1]
+        os_, nz, dvl = self.kernel_op._os(), self._nz(), self._dvec_local(rs)
+        if init_t is None:
+            # the same start vector on every rank: drawn at full length (as the single-process path does), rank 0's wins
+            init_t = torch.zeros(1, B.round_up(n, 4), device=self.device)
+            init_t[:, :n] = torch.randn(1, n, device=self.device, generator=self.bbmm_opts.get("generator"))
+            rs.broadcast(init_t)
+        rt_loc = root_inv_decomposition(None, None, None, init_vec_t=rs.local(init_t), nvec=rs.n_loc, device=self.device,
+                                        matvec=lambda q: rs.kv_local(q, scale=os_, dscale=nz, dvec_loc=dvl), reduce=rs.allreduce)
+        return rs.gather(rt_loc)
+
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
         """Lanczos root-inverse (``exact_prediction_strategies.py:271``) -> RootLinearOperator(n x m)."""
         from .lanczos import root_inv_decomposition
 
         if self._use_cholesky(settings.fast_computations.covar_root_decomposition):
             return super().root_inv_decomposition()
+        if self._row_shard() is not None:
+            init_t = None if initial_vectors is None else B.to_probe_major(initial_vectors.reshape(self.shape[-1], -1)[:, :1])
+            rt = self._root_inv_row_sharded(init_t)
+            return RootLinearOperator(B.from_probe_major(rt, self.shape[-1]).to(self.dtype))
         p1, _ = self.kernel_op.prepared()
         init_t = None if initial_vectors is None else B.to_probe_major(initial_vectors.reshape(self.shape[-1], -1)[:, :1], B.work_dtype(self.kernel_op.x1))
         rt = root_inv_decomposition(p1, self.kernel_op._os(), self._nz(), init_vec_t=init_t,

@@ -246,3 +246,39 @@ class fast_computations:
         for c in self._ctx:
             c.__exit__()
         return False
+
+
+class sharding:
+    """Process-group defaults for the multi-GPU paths (one process per GPU; ``torchrun``), read by the fused operators
+    when their ``bbmm_opts`` do not say otherwise:
+
+      * ``probe_group``: the probe columns of ``inv_quad_logdet`` (MLL forward / backward) are partitioned over the ranks
+        of this group -- each rank draws ``num_trace_samples // world`` (+1 for the first ranks) probes;
+      * ``row_group``: the small-t solves of the predictive posterior (mean-cache CG, LOVE Lanczos) are ROW-sharded over
+        this group -- every rank ends up with the full caches.
+
+    Replaces ``gpytorch.kernels.MultiDeviceKernel`` (``multi_device_kernel.py:49-92``).  Not thread-safe, like every
+    other setting here (``gpytorch/settings.py:84-144`` are process-global class attributes)."""
+
+    _probe_group = None
+    _row_group = None
+
+    def __init__(self, probe_group=None, row_group=None):
+        self._new = (probe_group, row_group)
+
+    @classmethod
+    def probe_group(cls):
+        return cls._probe_group
+
+    @classmethod
+    def row_group(cls):
+        return cls._row_group
+
+    def __enter__(self):
+        self._old = (sharding._probe_group, sharding._row_group)
+        sharding._probe_group, sharding._row_group = self._new
+        return self
+
+    def __exit__(self, *args):
+        sharding._probe_group, sharding._row_group = self._old
+        return False

@@ -108,6 +108,16 @@ const int* gpamd_cg_done_ptr(const gpamd_cg_t* h);
 int gpamd_cg_init_f32(gpamd_cg_t* h, const float* B, int64_t ldb, int have_precond, void* stream);
 /* with a preconditioner: after the caller wrote Z = P^-1 R and D = Z: rho = r.z */
 int gpamd_cg_begin_f32(gpamd_cg_t* h, void* stream);
+/* Row-sharded solves (each rank owns a contiguous block of rows of K_hat; used for the small-t solves
+ * -- predictive-mean CG, Lanczos -- where probe-column sharding has nothing to split).  The solver's inner products
+ * become sums over ranks: the three per-column partial arrays live in fscratch at offs[0..2] (d^T q, r^T z, r^T r), each
+ * [t][stride] with nb used entries per column; between the producing and the consuming call the host sums a column's
+ * partials, all-reduces the t sums (RCCL), writes them to entry 0 and zeroes the rest.  gpamd_cg_init_f32 is split at
+ * those points: init_norms (-> offs[0]) | init_apply (-> offs[2], and offs[1] when copy_d) | begin_apply. */
+int gpamd_cg_partials_layout(int n, int t, int hist_len, int64_t* offs, int* stride, int* nb);
+int gpamd_cg_init_norms_f32(gpamd_cg_t* h, const float* B, int64_t ldb, void* stream);
+int gpamd_cg_init_apply_f32(gpamd_cg_t* h, const float* B, int64_t ldb, int copy_d, void* stream);
+int gpamd_cg_begin_apply_f32(gpamd_cg_t* h, void* stream);
 /* Q = scale * sum_s P[s] + (dscale + dvec) .* D, and d.q partials */
 int gpamd_cg_reduce_q_f32(gpamd_cg_t* h, const float* P, int S, int64_t ldp, const float* scale, const float* dscale,
                           const float* dvec, void* stream);

@@ -91,3 +91,57 @@ def test_probe_shard_partition():
         assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         probe_shard(4, 2, 2)
+
+
+def _row_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from gpytorch_amd import backend as B
+    from gpytorch_amd import distributed as D
+
+    group = D.init_from_env("gloo")
+    n, dp, t = 1001, 4, 3
+    g = torch.Generator().manual_seed(5)
+    xp = B.PreparedPoints(torch.rand(n, dp, generator=g), n, 3, dp, "rbf")
+    rs = D.RowShard(xp, group)
+    full = torch.zeros(t, B.round_up(n, 4))
+    full[:, :n] = torch.randn(t, n, generator=g)
+    loc = rs.local(full)
+    back = rs.gather(loc)
+    ok_gather = bool(torch.equal(back[:, :n], full[:, :n])) and bool((back[:, n:] == 0).all())
+    ok_pad = bool(torch.equal(rs.x_all.xp[:n], xp.xp)) and rs.x_all.n == world * rs.n_pad and rs.x_loc.n == rs.r1 - rs.r0
+    # solver partials: [t][stride] with 5 used entries per column -> entry 0 = global column sum, rest cleared
+    stride = 16
+    fs = torch.zeros(7 + t * stride)
+    v = fs[7:].view(t, stride)
+    v[:, :5] = torch.arange(t * 5, dtype=torch.float32).view(t, 5) + rank
+    expect = sum((torch.arange(t * 5, dtype=torch.float32).view(t, 5) + r).sum(1) for r in range(world))
+    rs.allreduce_partials(fs, 7, t, stride)
+    ok_part = bool(torch.equal(v[:, 0], expect)) and bool((v[:, 1:] == 0).all())
+    bc = torch.full((4,), float(rank))
+    rs.broadcast(bc)
+    q.put((rank, rs.r0, rs.r1, ok_gather, ok_pad, ok_part, bool((bc == 0).all())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_shard_host_logic():
+    """RowShard on CPU tensors over gloo, 3 ranks: the row partition covers [0, n) without overlap,
+    gather(local(v)) reproduces v (zero padded tail), the replicated cloud is padded consistently, the solver's partial
+    arrays are summed over ranks into entry 0, broadcast takes rank 0's value."""
+    world, port = 3, 31000 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=180) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1] == 0 and results[-1][2] == 1001
+    for a, b in zip(results[:-1], results[1:]):
+        assert a[2] == b[1]
+    for r in results:
+        assert all(r[3:]), r

@@ -166,3 +166,167 @@ def test_two_rank_probe_sharding_on_device(dev):
         assert iters == ref.info.iterations
         assert abs(iq - float(ref.inv_quad[0])) < 1e-5 * abs(float(ref.inv_quad[0]))
         assert abs(ld - float(ref.logdet)) < 1e-5 * abs(float(ref.logdet))
+
+
+def _collect(q, procs, world, budget=240.0):
+    """Results of all ranks; fails within seconds when a rank dies instead of waiting out the queue timeout."""
+    import queue
+    import time
+
+    results, t0 = [], time.time()
+    while len(results) < world:
+        try:
+            results.append(q.get(timeout=2.0))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > budget:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError(f"rank process failed (exit codes {dead}) or timed out")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(results, key=lambda r: r[0])
+
+
+def _row_worker(rank, world, port, q, fixed_noise):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import gpytorch_amd as g
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    mu, var, info = _posterior(g, dev, fixed_noise, dist.group.WORLD)
+    q.put((rank, mu.cpu(), var.cpu(), info))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _posterior(g, dev, fixed_noise, row_group):
+    n, ns, d = 2999, 257, 3  # n not divisible by the world size or by 4: ragged last shard
+    X, y = make_data(n, d)
+    Xs = torch.rand(ns, d, generator=torch.Generator().manual_seed(9))
+
+    class GPModel(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ConstantMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.MaternKernel(nu=2.5))
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    if fixed_noise:
+        nv = 0.08 + 0.05 * torch.rand(n, generator=torch.Generator().manual_seed(4))
+        lik = g.likelihoods.FixedNoiseGaussianLikelihood(noise=nv.to(dev))
+    else:
+        lik = g.likelihoods.GaussianLikelihood()
+    m = GPModel(X.float().to(dev), y.float().to(dev), lik).to(dev)
+    m.covar_module.base_kernel.lengthscale = 0.5
+    m.covar_module.outputscale = 1.3
+    if not fixed_noise:
+        lik.noise = 0.1
+    m.eval()
+    lik.eval()
+    S = g.settings
+    torch.manual_seed(77)  # the Lanczos start vector of the LOVE cache comes from the default generator (rank 0's, when sharded)
+    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.fast_pred_var(), S.max_root_decomposition_size(250), \
+            S.max_preconditioner_size(0), S.sharding(row_group=row_group):
+        mu = m(Xs.to(dev)).mean  # mean-cache CG (the most recent solve: LOVE below is Lanczos only)
+        from gpytorch_amd import linear_cg as LCG
+
+        iters = LCG.LAST_INFO.iterations
+        var = m(Xs.to(dev)).variance
+    return mu, var, iters
+
+
+@pytest.mark.parametrize("world,fixed_noise", [(2, False), (3, True)])
+def test_row_sharded_posterior_on_device(world, fixed_noise, dev):
+    """the small-t solves of the predictive posterior (mean-cache CG, LOVE Lanczos) with every rank owning
+    a block of ROWS of K_hat.  `world` processes share cuda:0 (gloo carries the all-gathers of the search directions and the
+    per-iteration all-reduces of the solver's partial sums): same CG iteration count, mean and LOVE variance as the
+    single-process run, on every rank."""
+    import gpytorch_amd as g
+
+    port = 29100 + os.getpid() % 400 + world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, q, fixed_noise)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = _collect(q, procs, world)
+    mu, var, iters = _posterior(g, dev, fixed_noise, None)
+    mu, var = mu.cpu(), var.cpu()
+    assert iters > 10
+    for rank, mu_r, var_r, it_r in results:
+        assert abs(it_r - iters) <= max(2, 0.03 * iters), (rank, it_r, iters)  # float32 summation order, see test_gpu_bbmm
+        assert float((mu_r - mu).abs().max()) < 2e-4 * float(mu.abs().max()), rank
+        # Lanczos coefficients are chaotic in float32 beyond ~30 steps (any two implementations diverge), so the LOVE
+        # caches are compared through what they approximate: both within 3 % of the largest predictive variance
+        assert float((var_r - var).abs().max()) < 3e-2 * float(var.abs().max()), (rank, float((var_r - var).abs().max()), float(var.abs().max()))
+
+
+def _probe_api_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import gpytorch_amd as g
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    n, d = 2500, 3
+    X, y = make_data(n, d)
+
+    class GPModel(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ConstantMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel())
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood()
+    m = GPModel(X.float().to(dev), y.float().to(dev), lik).to(dev)
+    m.covar_module.base_kernel.lengthscale = 0.25
+    m.covar_module.outputscale = 1.0
+    lik.noise = 0.1
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    m.train()
+    lik.train()
+    S = g.settings
+    torch.manual_seed(5)  # same seed on every rank: the rank-specific generators must still give different probes
+    with S.max_cholesky_size(0), S.num_trace_samples(48), S.max_preconditioner_size(0), S.cg_tolerance(1e-3), \
+            S.sharding(probe_group=dist.group.WORLD):
+        val = mll(m(m.train_inputs[0]), m.train_targets)
+        val.backward()
+    grads = [float(p.grad.sum()) for p in (m.covar_module.base_kernel.raw_lengthscale, m.covar_module.raw_outputscale, lik.noise_covar.raw_noise)]
+    q.put((rank, float(val), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_probe_sharding_through_the_model_api(dev):
+    """settings.sharding(probe_group=...): ExactMarginalLogLikelihood through the gpytorch-shaped API on 2 ranks sharing
+    cuda:0; each rank solves 24 of the 48 probes (+ y).  Every rank reports the same value and gradients (all-reduced),
+    and they agree with the dense float64 MLL to the accuracy of a 48-probe trace estimate."""
+    world, port = 2, 29900 + os.getpid() % 300
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_probe_api_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = _collect(q, procs, world)
+    X, y = make_data(2500, 3)
+    ref, gref = OG.dense_mll_and_grads("rbf", X, y, 0.25, 1.0, 0.1)
+    (_, v0, g0), (_, v1, g1) = results
+    assert abs(v0 - v1) < 1e-6 * max(1.0, abs(v0))
+    assert all(abs(a - b) < 1e-5 * max(1e-3, abs(a)) for a, b in zip(g0, g1))
+    assert abs(v0 - float(ref)) < 0.02 * max(1.0, abs(float(ref))), (v0, float(ref))
+    chain = [1.0 - math.exp(-v) for v in (0.25, 1.0, 0.1 - 1e-4)]
+    for gg, rr, cc in zip(g0, gref, chain):
+        assert abs(gg - float(rr) * cc) < 0.15 * abs(float(rr) * cc) + 2e-3, (gg, float(rr) * cc)
