@@ -330,3 +330,69 @@ def test_probe_sharding_through_the_model_api(dev):
     chain = [1.0 - math.exp(-v) for v in (0.25, 1.0, 0.1 - 1e-4)]
     for gg, rr, cc in zip(g0, gref, chain):
         assert abs(gg - float(rr) * cc) < 0.15 * abs(float(rr) * cc) + 2e-3, (gg, float(rr) * cc)
+
+
+def test_mll_with_priors_and_lbfgs_training(dev):
+    """SURVEY.md 8f rank 1 -- the step around the hot path.  (i) ``test/mlls/test_exact_marginal_log_likelihood.py:71-91``:
+    MLL == (log_prob + sum of prior log-probs) / n.  (ii) hyper-parameter training with L-BFGS (strong Wolfe) over the
+    deterministic Cholesky branch and then Adam over the BBMM branch, ARD lengthscales, priors on every parameter: the
+    loss decreases and the fitted model predicts held-out data (MAE < 0.15, the bar of test_keops_gp_regression.py:58-77)."""
+    import gpytorch_amd as g
+    from gpytorch_amd import priors as P
+
+    n, d = 700, 2
+    X, y = make_data(n + 200, d, seed=3)
+    Xt, yt, Xs, ys = X[:n], y[:n], X[n:], y[n:]
+
+    class GPModel(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ConstantMean(constant_prior=P.NormalPrior(0.0, 1.0))
+            base = g.kernels.MaternKernel(nu=2.5, ard_num_dims=d, lengthscale_prior=P.GammaPrior(3.0, 6.0))
+            self.covar_module = g.kernels.ScaleKernel(base, outputscale_prior=P.GammaPrior(2.0, 0.15))
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood(noise_prior=P.GammaPrior(1.1, 0.05))
+    m = GPModel(Xt.float().to(dev), yt.float().to(dev), lik).to(dev)
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    S = g.settings
+    m.train()
+    lik.train()
+    # (i) assembly
+    out = m(m.train_inputs[0])
+    val = mll(out, m.train_targets)
+    lp = lik(out).log_prob(m.train_targets)
+    prior_sum = sum(pr.log_prob(cl(mod)).sum() for _, mod, pr, cl, _ in m.named_priors())
+    assert abs(float(val) - float((lp + prior_sum) / n)) < 1e-5 * max(1.0, abs(float(val)))
+    assert len(list(m.named_priors())) == 4
+    # (ii) L-BFGS on the exact branch
+    opt = torch.optim.LBFGS(m.parameters(), lr=0.5, max_iter=12, line_search_fn="strong_wolfe")
+    losses = []
+
+    def closure():
+        opt.zero_grad()
+        loss = -mll(m(m.train_inputs[0]), m.train_targets)
+        loss.backward()
+        losses.append(float(loss))
+        return loss
+
+    for _ in range(3):
+        opt.step(closure)
+    assert losses[-1] < losses[0] - 0.05 and all(math.isfinite(v) for v in losses)
+    # a few Adam steps on the BBMM branch starting from there (stochastic gradients)
+    opt2 = torch.optim.Adam(m.parameters(), lr=0.02)
+    with S.max_cholesky_size(0), S.num_trace_samples(16):
+        for _ in range(5):
+            opt2.zero_grad()
+            loss = -mll(m(m.train_inputs[0]), m.train_targets)
+            loss.backward()
+            opt2.step()
+            assert math.isfinite(float(loss))
+    m.eval()
+    lik.eval()
+    with torch.no_grad(), S.max_cholesky_size(0), S.fast_pred_var():
+        pred = lik(m(Xs.float().to(dev)))
+    assert float((pred.mean.cpu() - ys).abs().mean()) < 0.15
+    assert bool((pred.variance > 0).all())
