@@ -68,11 +68,15 @@ struct KvVariant {
   int bn;      // j tile
 };
 
-KvVariant pick_variant(int t) {  // t <= 129 handled per launch group
+bool gram_ok(int kind, int flags);
+
+// gram: the Gram-form kernels apply -- then 9..16 columns also stay on the VALU-contraction kernel (kv_gramv, T = 16:
+// exp + 8 packed fmas per pair beats a 32-column MFMA tile that is at most half full)
+KvVariant pick_variant(int t, bool gram) {  // t <= 129 handled per launch group
   KvVariant v{};
-  if (t <= 8) {
+  if (t <= 8 || (gram && t <= 16)) {
     v.valu = true;
-    v.tpad = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : 8));
+    v.tpad = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : (t <= 8 ? 8 : 16)));
     v.bm = KVV_BM;
     v.bn = KVV_BN;
   } else {
@@ -129,8 +133,10 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex) {
   return nullptr;
 }
 
+bool gram_ok(int kind, int flags) { return (flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12; }
+
 int kv_mode(int kind, int flags, int d, const KvVariant& v) {
-  const bool gram = (flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12;
+  const bool gram = gram_ok(kind, flags);
   if (v.valu) return gram ? KV_MODE_GRAMV : KV_MODE_VALU;
   if (gram && (flags & GPAMD_KV_ASYNC) && v.ct == 2 && d <= 4) return KV_MODE_GRAM2;
   return gram ? KV_MODE_GRAM : KV_MODE_MFMA;
@@ -161,7 +167,7 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // runs in ceil(units / slots) rounds of resident workgroups: pick the S whose last round is nearly
   // full (efficiency = units / (rounds * slots)), keeping every chunk >= 16 LDS tiles (per-unit prologue
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
-  KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t);
+  KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t, gram_ok(kind, flags));
   const int mode = kv_mode(kind, flags, d, v);
   variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
@@ -244,7 +250,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
   hipStream_t st = (hipStream_t)stream;
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0);
-    KvVariant v = pick_variant(tg);
+    KvVariant v = pick_variant(tg, gram_ok(kind, flags));
     const int mode = kv_mode(kind, flags, d, v);
     variant_geometry(mode, &v);
     KvArgs a;

@@ -15,7 +15,8 @@ dev = torch.device("cuda:0")
 CASES = [
     ("rbf", 100_000, 3, 65, 0.25), ("rbf", 500_000, 3, 65, 0.25), ("matern52", 200_000, 10, 65, 0.8),
     ("rbf", 200_000, 3, 33, 0.25), ("rbf", 200_000, 3, 129, 0.25), ("matern32", 200_000, 6, 65, 0.5),
-    ("rbf", 200_000, 16, 65, 1.2), ("rbf", 500_000, 3, 1, 0.25), ("rbf", 500_000, 3, 4, 0.25), ("matern52", 500_000, 3, 1, 0.25),
+    ("rbf", 200_000, 16, 65, 1.2), ("rbf", 500_000, 3, 11, 0.25), ("rbf", 500_000, 3, 16, 0.25), ("rbf", 500_000, 3, 17, 0.25),
+    ("matern52", 200_000, 10, 11, 0.8), ("rbf", 500_000, 3, 1, 0.25), ("rbf", 500_000, 3, 4, 0.25), ("matern52", 500_000, 3, 1, 0.25),
 ]
 out = []
 for kind, n, d, t, ls in CASES:

@@ -95,6 +95,8 @@ def test_golden_kernel_values(dev):
         (300, 300, 3, 1),     # VALU T=1
         (513, 700, 3, 3),     # VALU T=4 padded, ragged n/m
         (1000, 900, 10, 8),   # VALU T=8
+        (777, 1000, 3, 11),   # 9..16 columns: small-t Gram kernel T=16 (default num_trace_samples = 10 + y) / MFMA CT=1 when direct
+        (640, 900, 6, 16),    # same, full tile
         (257, 300, 3, 32),    # MFMA CT=1
         (700, 1100, 3, 33),   # MFMA CT=1 + EX
         (1025, 1300, 6, 64),  # MFMA CT=2
@@ -110,7 +112,7 @@ def test_kv_matches_oracle(kind, n, m, d, t, dev):
     on the matrix pipe (kv_gram.hpp, kv_gramv.hpp for t <= 8; tolerance 5e-5: quadratic-expansion cancellation)."""
     from gpytorch_amd import backend as B
 
-    if kind != "rbf" and (t in (3, 8, 70, 128, 129, 140)):
+    if kind != "rbf" and (t in (3, 8, 16, 70, 128, 129, 140)):
         pytest.skip("shape sweep is exhaustive for rbf; other families cover one shape per code path")
     g = torch.Generator().manual_seed(n + 7 * m + 13 * t)
     X1 = torch.rand(n, d, generator=g, dtype=torch.float64)
