@@ -267,7 +267,7 @@ def main():
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
-                "kernel": "kv_gram_kernel<RBF,D=3,CT=2,NI=2,EX=1> (Gram-form generation; kv_mfma_kernel when max|z|^2 > 32)",
+                "kernel": "kv_gram_kernel<RBF,D=3,CT=2,NI=2,EX=1> (Gram-form generation on split-f16 MFMA + fp32 MFMA contraction; kv_mfma_kernel when max|z|^2 > 32)",
                 "kernel_ms": kv_ms,
                 "launches_timed": len(live),
                 "flop_per_launch": flop_per_launch,

@@ -133,7 +133,7 @@ def _rank_worker(rank, world, port, q):
     xp = B.prep_points("rbf", X.float().to(dev), torch.tensor(0.25), X.mean(0).to(dev))
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
     res = inv_quad_logdet_forward(xp, sc, s2, B.to_probe_major(y.unsqueeze(-1).to(dev)), precond=None, probes=Z[:, a:b],
-                                  tolerance=0.5, group=dist.group.WORLD, t_total=t_total)
+                                  tolerance=1e-3, group=dist.group.WORLD, t_total=t_total)
     q.put((rank, res.info.iterations, float(res.inv_quad.sum()), float(res.logdet)))
     dist.barrier()
     dist.destroy_process_group()
@@ -161,11 +161,13 @@ def test_two_rank_probe_sharding_on_device(dev):
     xp = B.prep_points("rbf", X.float().to(dev), torch.tensor(0.25), X.mean(0).to(dev))
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
     rhs = B.to_probe_major(y.unsqueeze(-1).repeat(1, world).to(dev))
-    ref = inv_quad_logdet_forward(xp, sc, s2, rhs, precond=None, probes=Z, tolerance=0.5)
+    ref = inv_quad_logdet_forward(xp, sc, s2, rhs, precond=None, probes=Z, tolerance=1e-3)
     for rank, iters, iq, ld in results:
-        assert iters == ref.info.iterations
-        assert abs(iq - float(ref.inv_quad[0])) < 1e-5 * abs(float(ref.inv_quad[0]))
-        assert abs(ld - float(ref.logdet)) < 1e-5 * abs(float(ref.logdet))
+        # 8 probes + y per rank run on the small-t kernel, the 18-column reference on the MFMA kernel: different float32
+        # summation orders move the stopping iteration by a few steps (see test_gpu_bbmm); the converged values agree
+        assert abs(iters - ref.info.iterations) <= max(2, 0.03 * ref.info.iterations)
+        assert abs(iq - float(ref.inv_quad[0])) < 1e-4 * abs(float(ref.inv_quad[0]))
+        assert abs(ld - float(ref.logdet)) < 1e-4 * abs(float(ref.logdet))
 
 
 def _collect(q, procs, world, budget=240.0):
