@@ -54,6 +54,8 @@ SIGNATURES = {
     "gpamd_prep_points_f64": (_i, [_i, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
     "gpamd_kernel_rows_f64": (_i, [_i, _p, _p, _i64, _i, _p, _i, _i, _p, _p, _i64, _p]),
     "gpamd_kernel_diag_f64": (_i, [_i, _p, _p, _i, _i, _p, _p, _p]),
+    "gpamd_kv_plan_f64": (_i, [_i, _i, _i, _i, _i64, _p, _p, _p]),
+    "gpamd_kv_partials_f64": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _i64, _i, _i, _p, _p]),
     "gpamd_kernel_grad_block_f32": (_i, [_i, _p, _i64, _i, _p, _i, _i, _p, _i64, _p, _p]),
     "gpamd_kernel_grad_block_f64": (_i, [_i, _p, _i64, _i, _p, _i, _i, _p, _i64, _p, _p]),
     "gpamd_coldot_f64": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),

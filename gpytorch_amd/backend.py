@@ -153,7 +153,7 @@ def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dsc
     vd = vt if vd_is_vt else (vd if vd is None or vd.dtype == wd else vd.to(wd))
     scale, dscale, dvec = (a if a is None or a.dtype == wd else a.to(wd) for a in (scale, dscale, dvec))
     if not (x1.fused and x2.fused):
-        return kv_chunked(x1, x2, vt, scale, dscale, vd, out, dvec)
+        return kv_generic(x1, x2, vt, scale, dscale, vd, out, dvec)
     t, ldv = vt.shape
     n, m = x1.n, x2.n
     ldo = round_up(n, 4)
@@ -193,6 +193,49 @@ def kernel_row_block(x1: PreparedPoints, r0: int, nrows: int, x2: PreparedPoints
         blk = x1.xp[r0 : r0 + nrows]
         check(lib().gpamd_kernel_dense_f32(KIND_IDS[x1.kind], _ptr(blk), nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
                                            out.stride(0), st), "kernel_dense")
+    return out
+
+
+FUSED_F64_MAX_DP = 8   # kv_f64.hpp keeps NI * dp doubles of x_i in registers
+FORCE_CHUNKED = False  # tests: keep float64 products on the row-block path
+
+
+def fused_f64(x1: PreparedPoints, x2: PreparedPoints) -> bool:
+    """float64 clouds with d <= 8: fused generation + float64 MFMA contraction (csrc/kv_f64.hpp)."""
+    return (x1.dtype == torch.float64 and x2.dtype == torch.float64 and x1.dp == x2.dp and x1.dp <= FUSED_F64_MAX_DP
+            and not FORCE_CHUNKED)
+
+
+def kv_partials_f64(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, done_ptr=None):
+    """Unscaled partial slabs of k(x1, x2) @ V from the fused float64 kernel: (P [S*t*ldo doubles], S, ldo)."""
+    n, m, t = x1.n, x2.n, vt.shape[0]
+    ldo = round_up(n, 4)
+    S, jc, ws = C.c_int(), C.c_int(), C.c_int64()
+    check(lib().gpamd_kv_plan_f64(n, m, x1.dp, t, ldo, C.byref(S), C.byref(jc), C.byref(ws)), "kv_plan_f64")
+    key = ("f64", vt.device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < ws.value:
+        buf = torch.empty(max(ws.value, 1 << 18), device=vt.device, dtype=torch.float64)
+        _ws_cache[key] = buf
+    check(lib().gpamd_kv_partials_f64(KIND_IDS[x1.kind], _ptr(x1.xp), n, _ptr(x2.xp), m, x1.dp, _ptr(vt), vt.stride(0), t, _ptr(buf),
+                                      ldo, S.value, jc.value, done_ptr, _stream(vt.device)), "kv_partials_f64")
+    return buf, S.value, ldo
+
+
+def kv_generic(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dscale=None, vd=None, out=None, dvec=None):
+    """Products outside the fused float32 kernels: fused float64 (d <= 8) or row blocks x GEMM (kv_chunked)."""
+    if not fused_f64(x1, x2):
+        return kv_chunked(x1, x2, vt, scale, dscale, vd, out, dvec)
+    dt = torch.float64
+    vt = vt if vt.dtype == dt else vt.to(dt)
+    n, t = x1.n, vt.shape[0]
+    P, S, ldo = kv_partials_f64(x1, x2, vt)
+    if out is None:
+        out = torch.empty(t, ldo, device=vt.device, dtype=dt)
+    sc, ds, dv = (None if a is None else a.to(dt) for a in (scale, dscale, dvec))
+    vdd = None if vd is None else (vt if vd is vt else vd.to(dt))
+    check(lib().gpamd_kv_reduce_f64(_ptr(P), S, ldo, t, n, _ptr(sc), _ptr(ds), _ptr(dv), _ptr(vdd), 0 if vdd is None else vdd.stride(0),
+                                    _ptr(out), out.stride(0), None, _stream(vt.device)), "kv_reduce_f64")
     return out
 
 

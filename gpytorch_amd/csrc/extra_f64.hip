@@ -14,6 +14,7 @@
 #include <stdio.h>
 
 #include "cg_kernels.hpp"
+#include "kv_f64.hpp"
 
 using namespace gpamd;
 namespace gpamd {
@@ -143,6 +144,38 @@ int grad_block_launch(int kind, const T* X1p, int64_t row0, int nrows, const T* 
 
 }  // namespace
 
+namespace {
+
+// column tiles of 16: 1 (t <= 16), 4 (t <= 64), 5 (t <= 80); wider right-hand sides go in groups of 80
+int kv64_ct_for(int t) { return t <= 16 ? 1 : (t <= 64 ? 4 : 5); }
+int kv64_group(int t, int g0) { return (t - g0) <= 80 ? (t - g0) : 80; }
+int kv64_bm(int ct) { return 4 * kv64_ni_for_ct(ct) * 16; }
+
+template <int KIND, int DP>
+const void* kv64_ptr_ct(int ct) {
+  switch (ct) {
+    case 1: return reinterpret_cast<const void*>(&kv_f64_kernel<KIND, DP, 1>);
+    case 4: return reinterpret_cast<const void*>(&kv_f64_kernel<KIND, DP, 4>);
+    case 5: return reinterpret_cast<const void*>(&kv_f64_kernel<KIND, DP, 5>);
+  }
+  return nullptr;
+}
+template <int KIND>
+const void* kv64_ptr_dp(int dp, int ct) {
+  return dp == 4 ? kv64_ptr_ct<KIND, 4>(ct) : (dp == 8 ? kv64_ptr_ct<KIND, 8>(ct) : nullptr);
+}
+const void* kv64_ptr(int kind, int dp, int ct) {
+  switch (kind) {
+    case GPAMD_RBF: return kv64_ptr_dp<KIND_RBF>(dp, ct);
+    case GPAMD_MATERN12: return kv64_ptr_dp<KIND_MATERN12>(dp, ct);
+    case GPAMD_MATERN32: return kv64_ptr_dp<KIND_MATERN32>(dp, ct);
+    case GPAMD_MATERN52: return kv64_ptr_dp<KIND_MATERN52>(dp, ct);
+  }
+  return nullptr;
+}
+
+}  // namespace
+
 struct gpamd_cg64 {
   CgState<double> st;
 };
@@ -182,6 +215,48 @@ int gpamd_kernel_grad_block_f32(int kind, const float* X1p, int64_t row0, int nr
 int gpamd_kernel_grad_block_f64(int kind, const double* X1p, int64_t row0, int nrows, const double* X2p, int m, int dp, double* W,
                                 int64_t ldw, double* acc, void* stream) {
   return grad_block_launch<double>(kind, X1p, row0, nrows, X2p, m, dp, W, ldw, acc, stream);
+}
+
+int gpamd_kv_plan_f64(int n, int m, int dp, int t, int64_t ldo, int* S, int* jchunk, int64_t* workspace_doubles) {
+  if (n <= 0 || m <= 0 || t <= 0 || !S || !jchunk || !workspace_doubles || ldo < n) return fail64(GPAMD_EINVAL, "kv_plan_f64: bad arguments");
+  if (dp != 4 && dp != 8) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: fused float64 kernel needs d <= 8 (generic path otherwise)");
+  const int ct = kv64_ct_for(t > 80 ? 80 : t);
+  const int nrb = (n + kv64_bm(ct) - 1) / kv64_bm(ct);
+  int s = (3 * 3 * 256 + nrb - 1) / nrb;  // ~3 rounds of 3 resident workgroups on 256 CUs
+  const int smax = m / (4 * KV64_BN) > 0 ? m / (4 * KV64_BN) : 1;
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  const int jc = ((m + s - 1) / s + KV64_BN - 1) / KV64_BN * KV64_BN;
+  *jchunk = jc;
+  *S = (m + jc - 1) / jc;
+  *workspace_doubles = (int64_t)(*S) * t * ldo;
+  return 0;
+}
+
+int gpamd_kv_partials_f64(int kind, const double* X1p, int n, const double* X2p, int m, int dp, const double* Vt, int64_t ldv,
+                          int t, double* P, int64_t ldo, int S, int jchunk, const int* done, void* stream) {
+  if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || S <= 0 || jchunk <= 0 || jchunk % KV64_BN || ldv < m || ldo < n)
+    return fail64(GPAMD_EINVAL, "kv_partials_f64: bad shape");
+  if (dp != 4 && dp != 8) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: fused float64 kernel needs d <= 8 (generic path otherwise)");
+  for (int g0 = 0; g0 < t;) {
+    const int tg = kv64_group(t, g0);
+    const int ct = kv64_ct_for(tg);
+    KvArgs64 a;
+    a.X1 = X1p; a.X2 = X2p;
+    a.Vt = Vt + (int64_t)g0 * ldv;
+    a.P = P + (int64_t)g0 * ldo;
+    a.ldv = ldv; a.ldo = ldo; a.pstride = (int64_t)t * ldo;
+    a.n = n; a.m = m; a.t = tg;
+    a.S = S; a.jchunk = jchunk;
+    a.nrb = (n + kv64_bm(ct) - 1) / kv64_bm(ct);
+    a.done = done;
+    const void* fn = kv64_ptr(kind, dp, ct);
+    if (!fn) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: no kernel variant");
+    void* kargs[] = {(void*)&a};
+    (void)hipLaunchKernel(fn, dim3((unsigned)a.nrb * (unsigned)S), dim3(256), kargs, 0, (hipStream_t)stream);
+    g0 += tg;
+  }
+  return launch_ok("kv_partials_f64");
 }
 
 int gpamd_coldot_f64(const double* A, const double* B, int64_t ld, int n, int t, double* out, double* scratch, void* stream) {

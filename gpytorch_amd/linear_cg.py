@@ -175,10 +175,14 @@ def linear_cg(
     dscale = None if dscale is None else dscale.to(wd)
     dvec = None if dvec is None else dvec.to(wd)
     if kv_partials is None and not x.fused:
-        # generic path (float64, or d > 16): dense row blocks of K (HIP) x library GEMM, one "partial" slab
-        def kv_partials(dt_, _x=x):
-            out = B.kv_chunked(_x, _x, dt_)
-            return out, 1, out.stride(0)
+        # generic path: fused float64 kernel (d <= 8), else dense row blocks of K (HIP) x library GEMM as one "partial" slab
+        if B.fused_f64(x, x):
+            def kv_partials(dt_, _x=x):
+                return B.kv_partials_f64(_x, _x, dt_, done_ptr)
+        else:
+            def kv_partials(dt_, _x=x):
+                out = B.kv_chunked(_x, _x, dt_)
+                return out, 1, out.stride(0)
     if row_shard is not None:
         po = (C.c_int64 * 3)()
         pstride, pnb = C.c_int(), C.c_int()

@@ -158,6 +158,14 @@ int gpamd_kernel_rows_f64(int kind, const double* X1p, const int64_t* rows, int6
                           int dp, const double* scale, double* out, int64_t ldo, void* stream);
 int gpamd_kernel_diag_f64(int kind, const double* X1p, const double* X2p, int n, int dp, const double* scale, double* out,
                           void* stream);
+/* Fused float64 K*V (kv_f64.hpp: float64 generation on the VALU, contraction on v_mfma_f64_16x16x4_f64; d <= 8, else
+ * GPAMD_EUNSUPPORTED and the caller uses the row-block path).  Same partial-slab convention as gpamd_kv_partials_f32:
+ * P [S][t][ldo], to be summed / scaled by gpamd_kv_reduce_f64 or gpamd_cg64_reduce_q.  Replaces
+ * KernelLinearOperator._matmul / LazyEvaluatedKernelTensor._matmul (lazy_evaluated_kernel_tensor.py:245-275) for
+ * float64 models. */
+int gpamd_kv_plan_f64(int n, int m, int dp, int t, int64_t ldo, int* S, int* jchunk, int64_t* workspace_doubles);
+int gpamd_kv_partials_f64(int kind, const double* X1p, int n, const double* X2p, int m, int dp, const double* Vt, int64_t ldv,
+                          int t, double* P, int64_t ldo, int S, int jchunk, const int* done, void* stream);
 /* Generic-path bilinear derivative, one row block (any dp; replaces, for float64 / d > 16, what gpamd_kv_grad_f32 does
  * fused; reference: the kernel backward, gpytorch/functions/rbf_covariance.py:26-29, matern_covariance.py:53-56).
  * W [nrows, ldw]: left^T right on entry, W * dk/ds on exit (s = squared prepared distance);
