@@ -16,7 +16,7 @@ from . import settings
 
 
 def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_t: torch.Tensor | None = None,
-                    tol: float = 1e-5, generator=None, dvec=None, matvec=None, nvec=None, device=None, reduce=None):
+                    tol: float = 1e-5, generator=None, dvec=None, matvec=None, nvec=None, device=None, reduce=None, n_global=None):
     """Returns (Qt [m, ld] with orthonormal rows, T [m, m] on device, in the dtype of the prepared points).
 
     ``matvec(q_row [1, ld]) -> [1, ld]``: optional operator override (multitask Kronecker); then ``x`` may be
@@ -26,7 +26,7 @@ def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_
     n = x.n if nvec is None else nvec
     dev = x.xp.device if device is None else device
     ld = B.round_up(n, 4)
-    num_iter = min(max_iter, n)
+    num_iter = min(max_iter, n if n_global is None else n_global)  # row-sharded: the same step count on every rank
     wd = init_vec_t.dtype if init_vec_t is not None else (x.dtype if x is not None else torch.float32)
     if init_vec_t is None:
         init_vec_t = torch.zeros(1, ld, device=dev, dtype=wd)
@@ -103,12 +103,12 @@ def tridiag_to_diag(T: torch.Tensor):
 
 
 def root_inv_decomposition(x: B.PreparedPoints, scale, dscale, max_iter=None, init_vec_t=None, generator=None, dvec=None,
-                           matvec=None, nvec=None, device=None, reduce=None):
+                           matvec=None, nvec=None, device=None, reduce=None, n_global=None):
     """Rt [m, ld] with Rt^T Rt ~= K_hat^-1 on the Krylov space (the ``covar_cache`` of
     ``exact_prediction_strategies.py:267-272``)."""
     max_iter = settings.max_root_decomposition_size.value() if max_iter is None else max_iter
     Q, T = lanczos_tridiag(x, scale, dscale, max_iter, init_vec_t, generator=generator, dvec=dvec, matvec=matvec,
-                           nvec=nvec, device=device, reduce=reduce)
+                           nvec=nvec, device=device, reduce=reduce, n_global=n_global)
     jitter = settings.tridiagonal_jitter.value()
     Tj = T + jitter * torch.eye(T.shape[0], device=T.device, dtype=T.dtype)
     evals, evecs = tridiag_to_diag(Tj)

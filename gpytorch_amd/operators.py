@@ -650,7 +650,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             init_t[:, :n] = torch.randn(1, n, device=self.device, generator=self.bbmm_opts.get("generator"))
             rs.broadcast(init_t)
         rt_loc = root_inv_decomposition(None, None, None, init_vec_t=rs.local(init_t), nvec=rs.n_loc, device=self.device,
-                                        matvec=lambda q: rs.kv_local(q, scale=os_, dscale=nz, dvec_loc=dvl), reduce=rs.allreduce)
+                                        matvec=lambda q: rs.kv_local(q, scale=os_, dscale=nz, dvec_loc=dvl), reduce=rs.allreduce, n_global=n)
         return rs.gather(rt_loc)
 
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):

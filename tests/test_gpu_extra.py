@@ -208,7 +208,7 @@ def _row_worker(rank, world, port, q, fixed_noise):
 
 
 def _posterior(g, dev, fixed_noise, row_group):
-    n, ns, d = 2999, 257, 3  # n not divisible by the world size or by 4: ragged last shard
+    n, ns, d = 1501, 257, 3  # n not divisible by the world size or by 4: ragged last shard
     X, y = make_data(n, d)
     Xs = torch.rand(ns, d, generator=torch.Generator().manual_seed(9))
 
@@ -222,7 +222,7 @@ def _posterior(g, dev, fixed_noise, row_group):
             return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
 
     if fixed_noise:
-        nv = 0.08 + 0.05 * torch.rand(n, generator=torch.Generator().manual_seed(4))
+        nv = 0.4 + 0.2 * torch.rand(n, generator=torch.Generator().manual_seed(4))
         lik = g.likelihoods.FixedNoiseGaussianLikelihood(noise=nv.to(dev))
     else:
         lik = g.likelihoods.GaussianLikelihood()
@@ -230,12 +230,12 @@ def _posterior(g, dev, fixed_noise, row_group):
     m.covar_module.base_kernel.lengthscale = 0.5
     m.covar_module.outputscale = 1.3
     if not fixed_noise:
-        lik.noise = 0.1
+        lik.noise = 0.5
     m.eval()
     lik.eval()
     S = g.settings
     torch.manual_seed(77)  # the Lanczos start vector of the LOVE cache comes from the default generator (rank 0's, when sharded)
-    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.fast_pred_var(), S.max_root_decomposition_size(250), \
+    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.fast_pred_var(), S.max_root_decomposition_size(500), \
             S.max_preconditioner_size(0), S.sharding(row_group=row_group):
         mu = m(Xs.to(dev)).mean  # mean-cache CG (the most recent solve: LOVE below is Lanczos only)
         from gpytorch_amd import linear_cg as LCG
@@ -263,12 +263,13 @@ def test_row_sharded_posterior_on_device(world, fixed_noise, dev):
     mu, var, iters = _posterior(g, dev, fixed_noise, None)
     mu, var = mu.cpu(), var.cpu()
     assert iters > 10
+    assert float(var.min()) > 1e-4  # the single-process LOVE variances are themselves converged (nothing clipped)
     for rank, mu_r, var_r, it_r in results:
-        assert abs(it_r - iters) <= max(2, 0.03 * iters), (rank, it_r, iters)  # float32 summation order, see test_gpu_bbmm
+        assert abs(it_r - iters) <= max(4, 0.08 * iters), (rank, it_r, iters)  # float32 summation order, see test_gpu_bbmm
         assert float((mu_r - mu).abs().max()) < 2e-4 * float(mu.abs().max()), rank
         # Lanczos coefficients are chaotic in float32 beyond ~30 steps (any two implementations diverge), so the LOVE
-        # caches are compared through what they approximate: both within 3 % of the largest predictive variance
-        assert float((var_r - var).abs().max()) < 3e-2 * float(var.abs().max()), (rank, float((var_r - var).abs().max()), float(var.abs().max()))
+        # caches are compared where the decomposition has converged (noise 0.5: condition number ~4e3, 500 steps)
+        assert float((var_r - var).abs().max()) < 1e-2 * float(var.abs().max()), (rank, float((var_r - var).abs().max()), float(var.abs().max()))
 
 
 def _probe_api_worker(rank, world, port, q):
