@@ -214,7 +214,12 @@ def linear_cg(
         min_iter = min(10, max_iter - 1)
         tri_floor = min(n_tri_iter, max_iter - 1) if n_tridiag else 0
         first_poll = max(min_iter, tri_floor)
-        poll_every = 1 if float(n) * n * t > 2e11 else 8
+        # (row-sharded: the schedule must not depend on the local row count -- a rank that stops polling-late would issue
+        # collectives its peers never join)
+        n_poll = row_shard.n_pad if row_shard is not None else n
+        poll_every = 1 if float(n_poll) * n_poll * t > 2e11 else 8
+        if group is not None or row_shard is not None:
+            poll_every = 1  # every rank must leave the loop at the same iteration (ranks may hold different column counts)
         flag = 0
         iters = 0
         for k in range(max_iter):
