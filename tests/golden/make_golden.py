@@ -7,6 +7,7 @@ and are what travels to the GPU box (``/root/reference`` does not exist there).
 What is executed from /root/reference (nothing is copied into the repo):
   * ``gpytorch/functions/rbf_covariance.py``     -> RBFCovariance.apply   (imports only torch)
   * ``gpytorch/functions/matern_covariance.py``  -> MaternCovariance.apply (imports only torch, math)
+  * ``gpytorch/utils/transforms.py``             -> inv_softplus, inv_sigmoid (imports only torch)
   * ``gpytorch/kernels/kernel.py`` lines 26-60   -> sq_dist, dist: the two function definitions are
     extracted with ``ast`` and exec'd (the module itself cannot be imported because the third-party
     ``linear_operator`` package is not installed in this image).
@@ -87,6 +88,15 @@ def main():
             out[f"{name}_matern{int(nu * 10):02d}_dls"] = gl.numpy()
     np.savez_compressed(os.path.join(OUT, "kernel_values.npz"), **out)
     print("wrote kernel_values.npz with", len(out), "arrays")
+
+    # parameter transforms (gpytorch/utils/transforms.py imports only torch): the raw <-> constrained maps every
+    # hyper-parameter of the path goes through (constraints/constraints.py:172-194 call these)
+    tr = _load(f"{REF}/utils/transforms.py", "ref_transforms")
+    xs = torch.cat([torch.logspace(-6, 2, 50, dtype=torch.float64), torch.tensor([1e-4, 0.1, 0.6931, 1.0, 20.0], dtype=torch.float64)])
+    ps = torch.linspace(0.001, 0.999, 41, dtype=torch.float64)
+    tout = {"x": xs.numpy(), "inv_softplus": tr.inv_softplus(xs).numpy(), "p": ps.numpy(), "inv_sigmoid": tr.inv_sigmoid(ps).numpy()}
+    np.savez_compressed(os.path.join(OUT, "transform_values.npz"), **tout)
+    print("wrote transform_values.npz")
 
 
 if __name__ == "__main__":

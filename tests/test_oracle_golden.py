@@ -90,3 +90,26 @@ def test_mvn_log_prob_known_answer():
     cov = torch.diag(torch.tensor([1.0, 0.75, 1.5], dtype=torch.float64))
     lp = OG.dense_log_prob(cov, torch.zeros(3, dtype=torch.float64) - mean)
     assert abs(float(lp) - (-4.8157)) < 1e-4
+
+
+def test_parameter_transforms_golden():
+    """Raw <-> constrained parameter maps against outputs of the reference's own ``gpytorch/utils/transforms.py``
+    (tests/golden/transform_values.npz): inv_softplus bit for bit, the sigmoid inverse of the Interval constraint to
+    rounding; softplus(inv_softplus(x)) == x; the noise lower bound of ``noise_models.py:29-30`` (GreaterThan(1e-4))."""
+    import os
+
+    import numpy as np
+
+    from gpytorch_amd.module import GreaterThan, Interval, Positive, inv_softplus
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "transform_values.npz"))
+    x = torch.from_numpy(z["x"])
+    assert torch.equal(inv_softplus(x), torch.from_numpy(z["inv_softplus"]))
+    assert torch.equal(Positive().inverse_transform(x), torch.from_numpy(z["inv_softplus"]))
+    assert torch.allclose(Positive().transform(torch.from_numpy(z["inv_softplus"])), x, rtol=1e-9, atol=0)
+    p = torch.from_numpy(z["p"])
+    iv = Interval(2.0, 5.0)
+    assert torch.allclose(iv.inverse_transform(2.0 + 3.0 * p), torch.from_numpy(z["inv_sigmoid"]), rtol=1e-12, atol=1e-13)
+    gt = GreaterThan(1e-4)
+    assert torch.allclose(gt.transform(gt.inverse_transform(x + 1e-4)), x + 1e-4, rtol=1e-9, atol=0)
+    assert float(gt.transform(torch.tensor(-50.0, dtype=torch.float64))) >= 1e-4
