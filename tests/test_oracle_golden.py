@@ -112,4 +112,4 @@ def test_parameter_transforms_golden():
     assert torch.allclose(iv.inverse_transform(2.0 + 3.0 * p), torch.from_numpy(z["inv_sigmoid"]), rtol=1e-12, atol=1e-13)
     gt = GreaterThan(1e-4)
     assert torch.allclose(gt.transform(gt.inverse_transform(x + 1e-4)), x + 1e-4, rtol=1e-9, atol=0)
-    assert float(gt.transform(torch.tensor(-50.0, dtype=torch.float64))) >= 1e-4
+    assert float(gt.transform(torch.tensor(-50.0, dtype=torch.float64))) >= 1e-4 * (1 - 1e-6)  # the bound is a float32 buffer
