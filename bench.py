@@ -275,7 +275,7 @@ def main():
         }
         if extras is not None:
             out["extras"] = extras
-        if not args.skip_cpu_baseline:
+        if not args.skip_cpu_baseline and world == 1:  # timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(n, d, cols, ls)
         print(json.dumps(out))
     if group is not None:
