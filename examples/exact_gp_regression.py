@@ -73,7 +73,7 @@ def main():
             loss.backward()
             opt.step()
             if rank == 0 and (it % 5 == 0 or it == args.iters - 1):
-                print(f"iter {it:3d}  loss {float(loss):.4f}  lengthscale {model.covar_module.base_kernel.lengthscale.flatten().tolist()}"
+                print(f"iter {it:3d}  loss {loss.item():.4f}  lengthscale {model.covar_module.base_kernel.lengthscale.flatten().tolist()}"
                       f"  noise {float(likelihood.noise):.4f}", flush=True)
         torch.cuda.synchronize(dev)
         t_train = time.perf_counter() - t0
