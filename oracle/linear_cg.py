@@ -34,7 +34,22 @@ def linear_cg(
     preconditioner=None,
     return_info: bool = False,
     mean_residual_fn=None,
+    rowsum_fn=None,
 ):
+    # rowsum_fn (test aid for ROW-sharded solves): the vectors hold only this rank's rows and every
+    # reduction over rows -- inner products, norms -- goes through rowsum_fn (local sum + all-reduce).  None: plain sums.
+    if rowsum_fn is None:
+        def dot(a_, b_):
+            return (a_ * b_).sum(-2, keepdim=True)
+
+        def norm(a_):
+            return a_.norm(2, dim=-2, keepdim=True)
+    else:
+        def dot(a_, b_):
+            return rowsum_fn((a_ * b_).sum(-2, keepdim=True))
+
+        def norm(a_):
+            return rowsum_fn((a_ * a_).sum(-2, keepdim=True)).sqrt()
     n, c = rhs.shape[-2], rhs.shape[-1]
     if preconditioner is None:
         def preconditioner(x):  # noqa: E306
@@ -43,7 +58,7 @@ def linear_cg(
     n_iter = max_iter
     n_tri_iter = min(max_tridiag_iter, n)
 
-    bnorm = rhs.norm(2, dim=-2, keepdim=True)
+    bnorm = norm(rhs)
     zero_rhs = bnorm.lt(eps)
     bnorm = bnorm.masked_fill(zero_rhs, 1)
     B = rhs / bnorm
@@ -53,12 +68,12 @@ def linear_cg(
     if not torch.equal(R, R):
         raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
 
-    rnorm = R.norm(2, dim=-2, keepdim=True)
+    rnorm = norm(R)
     converged = rnorm.lt(stop_updating_after)
 
     Z = preconditioner(R)
     D = Z.clone()
-    rho = (R * Z).sum(-2, keepdim=True)
+    rho = dot(R, Z)
 
     T = torch.zeros(n_tri_iter, n_tri_iter, n_tridiag, dtype=rhs.dtype) if n_tridiag else None
     alpha_hist, beta_hist = [], []
@@ -71,7 +86,7 @@ def linear_cg(
 
     for k in range(n_iter):
         Q = matmul_closure(D)
-        den = (D * Q).sum(-2, keepdim=True)
+        den = dot(D, Q)
         bad = den.lt(eps)
         den = den.masked_fill(bad, 1)
         alpha = rho / den
@@ -83,14 +98,14 @@ def linear_cg(
         X = X + alpha * D
 
         rho_old = rho
-        rho = (R * Z).sum(-2, keepdim=True)
+        rho = dot(R, Z)
         bad = rho_old.lt(eps)
         rho_old = rho_old.masked_fill(bad, 1)
         beta = rho / rho_old
         beta = beta.masked_fill(bad, 0)
         D = Z + beta * D
 
-        rnorm = R.norm(2, dim=-2, keepdim=True)
+        rnorm = norm(R)
         rnorm = rnorm.masked_fill(zero_rhs, 0)
         converged = rnorm.lt(stop_updating_after)
         alpha_hist.append(alpha.reshape(-1).clone())

@@ -145,3 +145,63 @@ def test_row_shard_host_logic():
         assert a[2] == b[1]
     for r in results:
         assert all(r[3:]), r
+
+
+def _row_cg_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from gpytorch_amd import backend as B
+    from gpytorch_amd import distributed as D
+    from oracle import kernels as OK
+    from oracle import linear_cg as OCG
+    from tests.util import make_data
+
+    group = D.init_from_env("gloo")
+    n, t = 403, 3
+    X, y = make_data(n, 3)
+    rhs = torch.cat([y.unsqueeze(-1), torch.randn(n, t - 1, generator=torch.Generator().manual_seed(8), dtype=torch.float64)], -1)
+    # RowShard only needs the shapes of the prepared cloud here; the oracle's dense K stands in for the device kernels
+    rs = D.RowShard(B.PreparedPoints(X.clone(), n, 3, 3, "rbf"), group)
+    K_rows = OK.kernel_matrix("rbf", X[rs.r0 : rs.r1], X, 0.25, 1.0, x1_eq_x2=False)  # this rank's rows of K
+
+    def mm_local(D_loc):  # [n_loc, t] -> this rank's rows of K_hat @ D, D gathered over ranks first
+        full = rs.gather(D_loc.t().contiguous())[:, :n].t()
+        return K_rows @ full + 0.1 * D_loc
+
+    def rowsum(v):
+        return D.allreduce_sum_(v.clone(), group)
+
+    sol_loc, info = OCG.linear_cg(mm_local, rhs[rs.r0 : rs.r1], tolerance=1e-6, max_iter=300, return_info=True, rowsum_fn=rowsum)
+    q.put((rank, rs.r0, rs.r1, info["iters"], sol_loc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_cg_matches_single_process():
+    """SURVEY.md 8e.2 on CPU, 3 ranks over gloo, float64: every rank owns a block of ROWS of K_hat, the search
+    directions are all-gathered per product (RowShard.gather) and every inner product / norm of the restated
+    ``linear_cg`` is all-reduced.  Same iteration count and the same solution (1e-6 of its scale) as the single-process solve."""
+    sys.path.insert(0, ROOT)
+    from oracle import exact_gp as OG
+    from oracle import linear_cg as OCG
+    from tests.util import make_data
+
+    world, port = 3, 33000 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_row_cg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, t = 403, 3
+    X, y = make_data(n, 3)
+    rhs = torch.cat([y.unsqueeze(-1), torch.randn(n, t - 1, generator=torch.Generator().manual_seed(8), dtype=torch.float64)], -1)
+    sol, info = OCG.linear_cg(OG.make_matmul("rbf", X, 0.25, 1.0, 0.1), rhs, tolerance=1e-6, max_iter=300, return_info=True)
+    for rank, r0, r1, iters, sol_loc in results:
+        assert iters == info["iters"]
+        # (unlike probe sharding, the reduction ORDER changes: rounding differences grow along the CG recurrence)
+        assert torch.allclose(sol_loc, sol[r0:r1], rtol=0, atol=1e-6 * float(sol.abs().max()))
