@@ -186,6 +186,49 @@ class ExactGP(GP):
             predictive_mean = predictive_mean.view(-1, *tail)
         return cls(predictive_mean, predictive_covar)
 
+    def get_fantasy_model(self, inputs, targets, **kwargs):
+        """``exact_gp.py:151-263`` / ``exact_prediction_strategies.py:137-265`` (single-output, non-batch): a new model
+        conditioned on the training data PLUS (inputs, targets), without re-solving the n x n system.  With
+        B = K_hat^-1 k (one mBCG solve with m right-hand sides -- the MFMA path), S = k_hat_new - k^T B (m x m, dense
+        Cholesky), alpha = the current mean cache and e = (targets - mean_new) - k^T alpha, the new mean cache is
+        [alpha - B S^-1 e ; S^-1 e].  The LOVE covariance cache is rebuilt on first use (the reference updates its
+        root with a QR of the appended block).  Hyper-parameters are shared with this model, as in the reference."""
+        import copy
+
+        if self.prediction_strategy is None:
+            raise RuntimeError("Fantasy observations can only be added after making predictions with a model so that "
+                               "all test independent caches exist. Call the model on some data first!")
+        if torch.is_tensor(inputs):
+            inputs = (inputs,)
+        inputs = [i.unsqueeze(-1) if i.ndimension() == 1 else i for i in inputs]
+        if targets.dim() != 1 or len(self.prediction_strategy._train_shape) != 1:
+            raise NotImplementedError("get_fantasy_model: single-output, non-batch models")
+        train_inputs = list(self.train_inputs)
+        ps = self.prediction_strategy
+        n, m = ps.num_train, targets.shape[-1]
+        full_inputs = [torch.cat([ti, inp], dim=-2) for ti, inp in zip(train_inputs, inputs)]
+        full_targets = torch.cat([self.train_targets, targets], dim=-1)
+        with torch.no_grad():
+            full_output = Module.__call__(self, *full_inputs, **kwargs)
+            prior_covar = full_output.lazy_covariance_matrix
+            k = to_dense(prior_covar[:n, n:].evaluate_kernel())                               # [n, m] prior cross-covariance
+            new_prior = full_output.__class__(full_output.loc[..., n:], to_dense(prior_covar[n:, n:].evaluate_kernel()))
+            khat_new = to_dense(self.likelihood(new_prior, inputs).lazy_covariance_matrix)   # [m, m] incl. noise
+            with settings.cg_tolerance(settings.eval_cg_tolerance.value()):
+                alpha = ps.mean_cache                                                         # [n]
+                Bm = ps.lik_train_train_covar.solve(k)                                        # [n, m]
+            S = (khat_new - k.mT @ Bm).to(torch.float64)
+            e = ((targets - full_output.loc[..., n:]) - k.mT @ alpha).to(torch.float64)
+            Ls = torch.linalg.cholesky(0.5 * (S + S.mT))
+            w = torch.cholesky_solve(e.unsqueeze(-1), Ls).squeeze(-1).to(alpha.dtype)      # S^-1 e
+            new_cache = torch.cat([alpha - Bm @ w, w], dim=-1)
+        new_model = copy.copy(self)                 # shares parameters / modules (exact_gp.py:244-263 deep-copies only the caches)
+        new_model.train_inputs = tuple(full_inputs)
+        new_model.train_targets = full_targets
+        new_model.prediction_strategy = prediction_strategy(full_inputs, full_output, full_targets, self.likelihood)
+        new_model.prediction_strategy._mean_cache = new_cache.detach()
+        return new_model
+
     def _get_test_prior_mean_and_covariances(self, train_inputs, inputs, **kwargs):
         """exact_gp.py:355-430: joint train u test prior, sliced lazily."""
         full_inputs = [torch.cat([ti, inp], dim=-2) for ti, inp in zip(train_inputs, inputs)]

@@ -399,3 +399,50 @@ def test_mll_with_priors_and_lbfgs_training(dev):
         pred = lik(m(Xs.float().to(dev)))
     assert float((pred.mean.cpu() - ys).abs().mean()) < 0.15
     assert bool((pred.variance > 0).all())
+
+
+def test_fantasy_model_matches_retrained_posterior(dev):
+    """SURVEY.md 8f rank 2 -- ``ExactGP.get_fantasy_model`` (exact_gp.py:151-263; reference test:
+    test_simple_gp_regression.py:264-323): conditioning on 40 extra observations through the Schur-complement update
+    of the mean cache (one mBCG solve with 40 right-hand sides) gives the same predictive mean as a model holding all
+    the data, and as the dense float64 posterior."""
+    import gpytorch_amd as g
+
+    n, m, ns, d = 900, 40, 120, 2
+    X, y = make_data(n + m + ns, d, seed=11)
+    Xt, yt, Xf, yf, Xs = X[:n], y[:n], X[n : n + m], y[n : n + m], X[n + m :]
+
+    class GPModel(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ConstantMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel())
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    def build(xx, yy):
+        lik = g.likelihoods.GaussianLikelihood()
+        mdl = GPModel(xx.float().to(dev), yy.float().to(dev), lik).to(dev)
+        mdl.covar_module.base_kernel.lengthscale = 0.3
+        mdl.covar_module.outputscale = 1.2
+        lik.noise = 0.05
+        mdl.mean_module.constant = 0.1
+        mdl.eval()
+        lik.eval()
+        return mdl
+
+    S = g.settings
+    base = build(Xt, yt)
+    with pytest.raises(RuntimeError):
+        base.get_fantasy_model(Xf.float().to(dev), yf.float().to(dev))
+    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-5), S.skip_posterior_variances():
+        base(Xs.float().to(dev))  # builds the caches
+        fant = base.get_fantasy_model(Xf.float().to(dev), yf.float().to(dev))
+        mu_f = fant(Xs.float().to(dev)).mean
+        full = build(torch.cat([Xt, Xf]), torch.cat([yt, yf]))
+        mu_full = full(Xs.float().to(dev)).mean
+    assert fant.train_inputs[0].shape[0] == n + m and base.train_inputs[0].shape[0] == n
+    mu_ref, _ = OG.dense_posterior("rbf", torch.cat([Xt, Xf]), torch.cat([yt, yf]), Xs, 0.3, 1.2, 0.05, mean=0.1)
+    assert rel_err(mu_f, mu_full) < 1e-3
+    assert rel_err(mu_f, mu_ref) < 1e-3
