@@ -13,6 +13,9 @@ Pinning status
   this container and stores their outputs in ``tests/golden/*.npz``;
   ``tests/test_oracle_golden.py`` checks this oracle against those files and
   against the hand-computed known answers of the reference's unit tests.
+* Parameter transforms (softplus / sigmoid inverses behind every constrained
+  hyper-parameter): PINNED the same way (``gpytorch/utils/transforms.py`` executed,
+  ``tests/golden/transform_values.npz``).
 * MVN log-prob / MLL assembly / predictive equations: PINNED to dense float64
   Cholesky (the same deterministic ground truth every reference test compares
   against) and to the known answer -4.8157 of
