@@ -1,0 +1,74 @@
+"""Error behaviour of the host-side mirror, without a GPU: the same exceptions, at the same points and with the same
+messages, as the reference raises before any arithmetic happens (exact_gp.py:113-149,265-280; kernel.py:492-510;
+matern_kernel.py:80-82; index_kernel.py:60-62; likelihood.py; multivariate_normal.py) -- and the product's own rule
+that nothing runs without the HIP library and a ROCm device (no CPU fallback)."""
+import pytest
+import torch
+
+import gpytorch_amd as g
+
+
+class _GP(g.models.ExactGP):
+    def __init__(self, x, y, lik):
+        super().__init__(x, y, lik)
+        self.mean_module = g.means.ConstantMean()
+        self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel(ard_num_dims=2))
+
+    def forward(self, x):
+        return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+
+def test_exact_gp_argument_errors():
+    lik = g.likelihoods.GaussianLikelihood()
+    with pytest.raises(RuntimeError, match="Train inputs must be a tensor"):
+        _GP([1.0, 2.0], torch.zeros(2), lik)
+    m = _GP(None, None, lik)
+    m.train()
+    with pytest.raises(RuntimeError, match="cannot be None in training mode"):
+        m(torch.zeros(3, 2))
+    m = _GP(torch.zeros(5, 2), torch.zeros(5), lik)
+    with pytest.raises(RuntimeError, match="Cannot modify shape/dtype/device of train inputs"):
+        m.set_train_data(torch.zeros(6, 2), torch.zeros(6), strict=True)
+    with pytest.raises(RuntimeError, match="Cannot modify shape of train targets"):
+        m.set_train_data(targets=torch.zeros(6), strict=True)
+    m.set_train_data(torch.zeros(6, 2), torch.zeros(6), strict=False)
+    assert m.train_inputs[0].shape == (6, 2) and m.prediction_strategy is None
+    m.eval()
+    with pytest.raises(RuntimeError, match="Fantasy observations can only be added after making predictions"):
+        m.get_fantasy_model(torch.zeros(2, 2), torch.zeros(2))
+    # 1-D inputs are promoted to [n, 1] (exact_gp.py:60-61)
+    assert g.models.ExactGP(torch.zeros(4), torch.zeros(4), lik).train_inputs[0].shape == (4, 1)
+
+
+def test_kernel_and_likelihood_argument_errors():
+    with pytest.raises(RuntimeError, match="nu expected to be 0.5, 1.5, or 2.5"):
+        g.kernels.MaternKernel(nu=1.0)
+    k = g.kernels.RBFKernel(ard_num_dims=3)
+    with pytest.raises(RuntimeError, match="Expected the input to have 3 dimensionality"):
+        k(torch.zeros(4, 2))
+    with pytest.raises(NotImplementedError):
+        g.kernels.RBFKernel(batch_shape=torch.Size([2]))
+    with pytest.raises(RuntimeError, match="larger than the number of tasks"):
+        g.kernels.IndexKernel(num_tasks=2, rank=3)
+    with pytest.raises(RuntimeError, match="expects a MultivariateNormal"):
+        g.likelihoods.GaussianLikelihood()(torch.zeros(3))
+    with pytest.raises(RuntimeError, match="sizes do not match"):
+        g.distributions.MultivariateNormal(torch.zeros(3), torch.eye(4))
+    # constraints: the noise lower bound of noise_models.py:29-30 is enforced through the transform
+    lik = g.likelihoods.GaussianLikelihood()
+    lik.noise = 0.5
+    assert abs(float(lik.noise) - 0.5) < 1e-6
+    assert float(lik.noise_covar.raw_noise_constraint.lower_bound) == pytest.approx(1e-4)
+
+
+def test_no_cpu_fallback():
+    """The fused operators refuse host tensors loudly instead of computing on the CPU."""
+    from gpytorch_amd import backend as B
+
+    with pytest.raises(Exception) as ei:
+        B.prep_points("rbf", torch.zeros(4, 2), torch.tensor(1.0))
+    assert "ROCm" in str(ei.value) or "cuda" in str(ei.value).lower() or "device" in str(ei.value).lower()
+    k = g.kernels.ScaleKernel(g.kernels.RBFKernel())
+    op = k(torch.rand(5, 2))  # lazily evaluated: constructing the operator is fine ...
+    with pytest.raises(Exception):
+        op.to_dense()            # ... evaluating it is not
