@@ -13,7 +13,8 @@
 //
 // Accuracy (scripts/micro/gram_f16.hip, checked against float64 on the device): max |S - S_exact| = 6.8e-6 at
 // max |z|^2 = 32 (relative error 4.7e-6 in K = 2^-S), 6e-8 absolute floor near S = 0 (f16 subnormal spacing of the split
-// norms) -- inside the 1e-5 bound the host's |z|^2 <= 32 selection rule already assumes.
+// norms).  Worst case at the host's selection limit max |z|^2 = 32: 2^-22 (|z_i| + |z_j|)^2 ln 2 ~ 2e-5 relative in K
+// (CPU emulation of this slot scheme: tests/test_gram_split_cpu.py).
 #pragma once
 #include "common.hpp"
 

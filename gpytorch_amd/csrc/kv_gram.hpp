@@ -13,7 +13,7 @@
 //
 // Numerics: S carries the cancellation error of the quadratic expansion, <= ~8 eps * (|z_i|+|z_j|)^2 in
 // fp32 (the reference's fp32 path has the same error; it mean-centres for this reason).  The host only
-// selects this kernel when max |z|^2 (after centring) <= 32, i.e. a relative error <= 1e-5 in K, and never
+// selects this kernel when max |z|^2 (after centring) <= 32, i.e. a relative error <= 2e-5 in K (worst case, tests/test_gram_split_cpu.py; typically 5e-6), and never
 // for Matern nu = 1/2 (k = exp(-sqrt(s)) is not Lipschitz in s at 0).  Otherwise kv_mfma.hpp is used.
 //
 // Tried and measured without gain on MI355X (profiles/r01_s13_kv_tune_gram_seq_prefetch.jsonl): row tiles one after
