@@ -97,3 +97,24 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_integration_stub_matches_the_abi():
+    """The binding stub shown to gpytorch maintainers in INTEGRATION.md declares the same argument lists as the
+    library's own ctypes table (which test_header_symbols_exported_and_bound ties to include/gpamd.h)."""
+    import ctypes as C
+    import re
+
+    from gpytorch_amd._lib import SIGNATURES
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = {"_i": C.c_int, "_p": C.c_void_p, "_l": C.c_int64, "C.POINTER(_i)": C.POINTER(C.c_int), "C.POINTER(_l)": C.POINTER(C.c_int64)}
+    found = re.findall(r"_lib\.(gpamd_\w+)\.argtypes\s*=\s*\[([^\]]*)\]", text)
+    assert len(found) >= 3
+    for fn, args in found:
+        got = [names[a.strip()] for a in re.findall(r"C\.POINTER\(_\w\)|_\w", args)]
+        want = list(SIGNATURES[fn][1])
+        assert len(got) == len(want), fn
+        for a, b in zip(got, want):
+            # the product table writes output pointers as plain c_void_p or typed pointers: both are pointer-sized
+            assert a is b or (C.sizeof(a) == C.sizeof(b) == C.sizeof(C.c_void_p)), (fn, a, b)
