@@ -118,3 +118,28 @@ def test_integration_stub_matches_the_abi():
         for a, b in zip(got, want):
             # the product table writes output pointers as plain c_void_p or typed pointers: both are pointer-sized
             assert a is b or (C.sizeof(a) == C.sizeof(b) == C.sizeof(C.c_void_p)), (fn, a, b)
+
+
+def test_slq_logdet_host_logic_matches_oracle():
+    """bbmm.slq_logdet / lanczos.tridiag_to_diag (host side, k <= 20 eigh) against the restated StochasticLQ: random SPD
+    tridiagonals, a matrix with a negative eigenvalue (masked: eigenvalue 1, eigenvector 0) and NaN propagation."""
+    import math
+
+    from gpytorch_amd.bbmm import slq_logdet
+    from oracle import slq as OS
+
+    g = torch.Generator().manual_seed(3)
+    t, k, n = 5, 12, 1000
+    a = 2.0 + torch.rand(t, k, generator=g, dtype=torch.float64)
+    b = 0.3 * torch.rand(t, k - 1, generator=g, dtype=torch.float64)
+    T = torch.diag_embed(a) + torch.diag_embed(b, 1) + torch.diag_embed(b, -1)
+    assert abs(float(slq_logdet(T, n)) - float(OS.slq_logdet(T, n))) < 1e-10 * abs(float(OS.slq_logdet(T, n)))
+    # exactness on a diagonal T: (n / t) * sum_j log T_j[0, 0]
+    Td = torch.diag_embed(a)
+    assert abs(float(slq_logdet(Td, n)) - n / t * float(a[:, 0].log().sum())) < 1e-9
+    Tn = T.clone()
+    Tn[0, 0, 0] = -5.0  # indefinite: the negative eigenvalue is masked, the result stays finite and equals the oracle's
+    assert math.isfinite(float(slq_logdet(Tn, n)))
+    assert abs(float(slq_logdet(Tn, n)) - float(OS.slq_logdet(Tn, n))) < 1e-9 * max(1.0, abs(float(OS.slq_logdet(Tn, n))))
+    Tn[1, 2, 2] = float("nan")
+    assert math.isnan(float(slq_logdet(Tn, n)))
