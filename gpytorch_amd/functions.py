@@ -14,7 +14,6 @@ import torch
 
 from . import backend as B
 from .distributed import allreduce_sum_
-from . import settings
 from .bbmm import inv_quad_logdet_forward
 
 

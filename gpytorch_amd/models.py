@@ -15,7 +15,6 @@ import warnings
 import torch
 
 from . import settings
-from .distributions import MultivariateNormal
 from .module import Module
 from .operators import (
     DenseLinearOperator,

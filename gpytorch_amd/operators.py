@@ -562,7 +562,6 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         opts = dict(opts, group=group, num_probes=b - a, t_total=t_total)
         if "generator" not in opts and opts.get("probes") is None:
             opts["generator"] = torch.Generator(device=self.device).manual_seed(torch.initial_seed() % (2**31) + 7919 * (rank + 1))
-        self._shared_opts = opts  # InvQuadLogdetFn stores "_last_info" in the dict it is given
         return opts
 
     def _preconditioner(self):
