@@ -46,7 +46,6 @@ def work_dtype(t: torch.Tensor) -> torch.dtype:
 
 
 KV_GRAM = 1              # flag of gpamd_kv_partials_f32 (include/gpamd.h)
-KV_ASYNC = 2             # with KV_GRAM: software-pipelined DMA-staged variant (kv_gram2.hpp; measured slower, tests only)
 GRAM_MAX_SQNORM = 32.0   # max |z|^2 for which the split-f16 quadratic expansion keeps K within 2e-5 (gram_f16.hpp)
 FORCE_GENERIC = False    # tests: send float32 / d <= 16 problems down the generic (row-block + GEMM) path too
 FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or KV_GRAM regardless of |z|

@@ -70,14 +70,27 @@ def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=
     return Preconditioner(q1t_pad, sigma2.detach().reshape(()).to(wd), logdet.to(wd), lt_pad)
 
 
+def deterministic_probe_matrix(n: int, t: int, device, dtype=torch.float32):
+    """``settings.deterministic_probes`` (A.5): ONE (n, t) Gaussian matrix, drawn on first use, stored on the setting
+    and re-used by every later evaluation (so line searches / L-BFGS see a deterministic objective).  A user-injected
+    matrix is used as it is; a stored matrix of the wrong length (another model) is redrawn.  ``None`` when the flag is off."""
+    if not settings.deterministic_probes.on():
+        return None
+    z = settings.deterministic_probes.probe_vectors
+    if z is None or z.shape[-2] != n:
+        z = torch.randn(n, t, device=device, dtype=dtype)
+        settings.deterministic_probes.probe_vectors = z
+    return z
+
+
 def probe_vectors(n: int, t: int, precond: Preconditioner | None, device, generator=None, probes=None, dtype=torch.float32):
     """A.5.  Returns (Zt [t, ld] column-normalised, norms [t]).
 
     ``probes``: optional user-supplied UN-normalised (n, t) matrix (``deterministic_probes``-style
     injection; lets CPU and GPU runs share Z)."""
     ld = B.round_up(n, 4)
-    if probes is None and settings.deterministic_probes.on() and settings.deterministic_probes.probe_vectors is not None:
-        probes = settings.deterministic_probes.probe_vectors
+    if probes is None:
+        probes = deterministic_probe_matrix(n, t, device, dtype)
     if probes is not None:
         t = probes.shape[-1]
     zt = torch.zeros(t, ld, device=device, dtype=dtype)
@@ -152,8 +165,8 @@ def inv_quad_logdet_forward(
         precond = None  # the pivoted-Cholesky preconditioner is built for the constant-diagonal branch only (A.4)
     if precond == "auto":
         precond = build_preconditioner(x, scale, sigma2)
-    if probes is None and settings.deterministic_probes.on() and settings.deterministic_probes.probe_vectors is not None:
-        probes = settings.deterministic_probes.probe_vectors
+    if probes is None:
+        probes = deterministic_probe_matrix(n, t, dev, wd)
     if probes is not None:
         t = probes.shape[-1]
     zt, znorm = probe_vectors(n, t, precond, dev, generator, probes, dtype=wd)

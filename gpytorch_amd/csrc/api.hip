@@ -108,14 +108,6 @@ int kernel_dims(int d) {  // kernels exist for these valid-dimension counts; oth
 }
 
 const void* family_ptr(int kind, int mode, int d, int v, int ex) {
-  if (mode == KV_MODE_GRAM2) {
-    switch (kind) {
-      case GPAMD_RBF: return kvs2_kernel_ptr_rbf(d, v, ex);
-      case GPAMD_MATERN32: return kvs2_kernel_ptr_matern32(d, v, ex);
-      case GPAMD_MATERN52: return kvs2_kernel_ptr_matern52(d, v, ex);
-    }
-    return nullptr;
-  }
   if (mode == KV_MODE_GRAMV) {
     switch (kind) {
       case GPAMD_RBF: return kvs_kernel_ptr_rbf(d, v);
@@ -138,7 +130,6 @@ bool gram_ok(int kind, int flags) { return (flags & GPAMD_KV_GRAM) && kind != GP
 int kv_mode(int kind, int flags, int d, const KvVariant& v) {
   const bool gram = gram_ok(kind, flags);
   if (v.valu) return gram ? KV_MODE_GRAMV : KV_MODE_VALU;
-  if (gram && (flags & GPAMD_KV_ASYNC) && v.ct == 2 && d <= 4) return KV_MODE_GRAM2;
   return gram ? KV_MODE_GRAM : KV_MODE_MFMA;
 }
 
@@ -158,7 +149,6 @@ int wg_per_cu(int kind, int mode, int dk, const KvVariant& v) {
   (void)hipGetLastError();
   if (v.valu) return 4;
   if (mode == KV_MODE_GRAM) return 3;
-  if (mode == KV_MODE_GRAM2) return 2;
   return v.ct <= 2 ? 3 : 2;
 }
 

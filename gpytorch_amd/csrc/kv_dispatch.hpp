@@ -4,7 +4,7 @@
 
 namespace gpamd {
 
-enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3, KV_MODE_GRAM2 = 4 };
+enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3 };
 
 // MFMA / Gram variants: CT 32-column tiles (1..4) + EX extra VALU column; NI row tiles per wave by CT.
 // NI*CT*16 accumulator registers: 64 (CT <= 2) .. 128 (CT = 4)
@@ -20,9 +20,5 @@ const void* kv_kernel_ptr_matern52(int mode, int d, int v, int ex);
 const void* kvs_kernel_ptr_rbf(int d, int tpad);
 const void* kvs_kernel_ptr_matern32(int d, int tpad);
 const void* kvs_kernel_ptr_matern52(int d, int tpad);
-// asynchronous double-buffered Gram kernels (kvs_<family>.hip; D <= 3, CT <= 2)
-const void* kvs2_kernel_ptr_rbf(int d, int ct, int ex);
-const void* kvs2_kernel_ptr_matern32(int d, int ct, int ex);
-const void* kvs2_kernel_ptr_matern52(int d, int ct, int ex);
 
 }  // namespace gpamd

@@ -19,8 +19,8 @@
 // when tile T starts, so the first block of tile T+1 can be generated before the barrier that publishes V(T+1).
 // The last, partial tile of the contracted range is staged synchronously with zero fill.  D <= 4 (one 16-byte row).
 #pragma once
-#include "gram_f16.hpp"
-#include "kv_mfma.hpp"
+#include "../gram_f16.hpp"
+#include "../kv_mfma.hpp"
 
 namespace gpamd {
 

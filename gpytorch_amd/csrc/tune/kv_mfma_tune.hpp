@@ -8,7 +8,7 @@
 //   PRIO  s_setprio(1) around the MFMA cluster    GRAM  Gram-trick distance (4 fma) instead of differences
 //   MINW  __launch_bounds__ min waves per SIMD     STG   1: synchronous staging (no register prefetch -> fewer VGPRs)
 #pragma once
-#include "kv_mfma.hpp"
+#include "../kv_mfma.hpp"
 
 namespace gpamd {
 

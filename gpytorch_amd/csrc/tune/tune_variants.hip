@@ -1,11 +1,11 @@
-// Test/tuning-only entry point: launches a numbered structural variant of the fused K*V kernel
+// libgpamd_tune.so (NOT part of the product library; `make tune`).  Tuning-only entry point: launches a numbered structural variant of the fused K*V kernel
 // (RBF, d <= 3 padded to 4, t = 32*CT + 1).  See kv_mfma_tune.hpp and scripts/kv_tune.py.
-#include "../../include/gpamd.h"
+#include "../../../include/gpamd.h"
 
 #include <hip/hip_runtime.h>
 
 #include "kv_mfma_tune.hpp"
-#include "kv_gram.hpp"
+#include "../kv_gram.hpp"
 
 using namespace gpamd;
 

@@ -3,11 +3,19 @@
 ``noise_models.py:29-92``; noise constraint ``GreaterThan(1e-4)``)."""
 from __future__ import annotations
 
+import warnings
+
 import torch
 
+from . import settings
 from .distributions import MultivariateNormal
+from .linear_cg import NumericalWarning
 from .module import GreaterThan, Module
-from .operators import ConstantDiagLinearOperator, DiagLinearOperator
+from .operators import ConstantDiagLinearOperator, DiagLinearOperator, ZeroLinearOperator
+
+
+class GPInputWarning(UserWarning):
+    """Same role as ``gpytorch.utils.warnings.GPInputWarning``."""
 
 
 class HomoskedasticNoise(Module):
@@ -69,23 +77,84 @@ class GaussianLikelihood(_GaussianLikelihoodBase):
         return self.noise_covar.raw_noise
 
 
+class FixedGaussianNoise(Module):
+    """Known per-point observation noise (``noise_models.py:138-176``): the stored diagonal when the requested shape
+    matches it, a caller-supplied ``noise=`` diagonal when given, otherwise nothing (zero operator)."""
+
+    def __init__(self, noise: torch.Tensor):
+        super().__init__()
+        floor = settings.min_fixed_noise.value(noise.dtype)
+        if bool(noise.lt(floor).any()):
+            warnings.warn(f"Very small noise values detected. This will likely lead to numerical instabilities. "
+                          f"Rounding small noise values up to {floor}.", NumericalWarning)
+            noise = noise.clamp_min(floor)
+        self.register_buffer("noise", noise)
+
+    def forward(self, *params, shape=None, noise=None, **kwargs):
+        if shape is None:
+            first = params[0] if torch.is_tensor(params[0]) else params[0][0]
+            shape = first.shape if first.dim() == 1 else first.shape[:-1]
+        diag = noise if noise is not None else (self.noise if shape[-1] == self.noise.shape[-1] else None)
+        if diag is None:
+            return ZeroLinearOperator(shape[-1], shape[-1], dtype=self.noise.dtype, device=self.noise.device)
+        if diag.numel() > 0 and bool((diag == diag.reshape(-1)[0]).all()):
+            return ConstantDiagLinearOperator(diag.reshape(-1)[:1], diag_shape=shape[-1])   # rides the constant-diagonal fused path
+        return DiagLinearOperator(diag)
+
+
 class FixedNoiseGaussianLikelihood(_GaussianLikelihoodBase):
-    """gaussian_likelihood.py:245-362, constant-noise case rides the fused path; a heteroskedastic
-    noise vector falls back to the generic (dense) operator sum."""
+    """``gaussian_likelihood.py:245-362``: fixed (heteroskedastic) training noise, optional learned extra noise,
+    ``noise=`` for test-time noise.  The vector rides in the fused K*V epilogue (``FusedKernelAddedDiagLinearOperator``)."""
 
-    class _Fixed(Module):
-        def __init__(self, noise):
-            super().__init__()
-            self.register_buffer("noise", noise)
-
-        def forward(self, *params, shape=None, **kwargs):
-            if bool((self.noise == self.noise[0]).all()):
-                return ConstantDiagLinearOperator(self.noise[:1], diag_shape=shape[-1])
-            return DiagLinearOperator(self.noise)
-
-    def __init__(self, noise: torch.Tensor, **kwargs):
-        super().__init__(self._Fixed(noise))
+    def __init__(self, noise: torch.Tensor, learn_additional_noise: bool = False, batch_shape=torch.Size(), **kwargs):
+        super().__init__(FixedGaussianNoise(noise))
+        self.second_noise_covar = None
+        if learn_additional_noise:
+            self.second_noise_covar = HomoskedasticNoise(noise_prior=kwargs.get("noise_prior"), noise_constraint=kwargs.get("noise_constraint"))
 
     @property
     def noise(self):
-        return self.noise_covar.noise
+        return self.noise_covar.noise + self.second_noise
+
+    @noise.setter
+    def noise(self, value):
+        self.noise_covar.noise = torch.as_tensor(value).to(self.noise_covar.noise)
+
+    @property
+    def second_noise(self):
+        return 0.0 if self.second_noise_covar is None else self.second_noise_covar.noise
+
+    @second_noise.setter
+    def second_noise(self, value):
+        if self.second_noise_covar is None:
+            raise RuntimeError("Attempting to set secondary learned noise for FixedNoiseGaussianLikelihood, "
+                               "but learn_additional_noise must have been False!")
+        self.second_noise_covar.initialize(noise=value)
+
+    def get_fantasy_likelihood(self, **kwargs):
+        """gaussian_likelihood.py:322-335: the fantasy points bring their own ``noise``."""
+        if "noise" not in kwargs:
+            raise RuntimeError("FixedNoiseGaussianLikelihood.fantasize requires a `noise` kwarg")
+        import copy
+
+        new = copy.deepcopy(self)
+        new.noise_covar = FixedGaussianNoise(torch.cat([self.noise_covar.noise, kwargs["noise"].to(self.noise_covar.noise)], -1))
+        return new
+
+    def _shaped_noise_covar(self, base_shape, *params, **kwargs):
+        shape = None if len(params) > 0 else base_shape
+        res = self.noise_covar(*params, shape=shape, **kwargs)
+        if self.second_noise_covar is not None:
+            extra = self.second_noise_covar(*params, shape=base_shape)
+            res = extra if isinstance(res, ZeroLinearOperator) else _add_diags(res, extra)
+        elif isinstance(res, ZeroLinearOperator):
+            warnings.warn("You have passed data through a FixedNoiseGaussianLikelihood that did not match the size of the "
+                          "fixed noise, *and* you did not specify noise. This is treated as a no-op.", GPInputWarning)
+        return res
+
+
+def _add_diags(a, b):
+    """Sum of two diagonal operators as ONE diagonal operator (so the fused K + D path still applies)."""
+    if isinstance(a, ConstantDiagLinearOperator) and isinstance(b, ConstantDiagLinearOperator):
+        return ConstantDiagLinearOperator(a.diag_values.reshape(-1)[:1] + b.diag_values.reshape(-1)[:1], a.diag_shape)
+    return DiagLinearOperator(a._diag + b._diag)

@@ -18,7 +18,7 @@ import torch
 
 from . import backend as B
 from . import settings
-from .bbmm import slq_logdet
+from .bbmm import deterministic_probe_matrix, slq_logdet
 from .distributions import MultivariateNormal
 from .functions import KernelSpec, hyper_grads
 from .kernels import Kernel
@@ -253,8 +253,8 @@ class KroneckerInvQuadLogdetFn(torch.autograd.Function):
         ld = B.round_up(N, 4)
         zt = torch.zeros(t, ld, device=dev, dtype=wd)
         probes = opts.get("probes")
-        if probes is None and settings.deterministic_probes.on() and settings.deterministic_probes.probe_vectors is not None:
-            probes = settings.deterministic_probes.probe_vectors
+        if probes is None:
+            probes = deterministic_probe_matrix(N, t, dev, wd)
         if probes is not None:
             t = probes.shape[-1]
             zt = torch.zeros(t, ld, device=dev, dtype=wd)

@@ -517,6 +517,12 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
     def detach(self):
         return FusedKernelAddedDiagLinearOperator(self.kernel_op.detach(), self.noise.detach(), self.bbmm_opts, self.noise_vec)
 
+    def restrict(self, idx: torch.Tensor):
+        """K_hat[idx][:, idx] as a fused operator over the selected points (``observation_nan_policy("mask")``:
+        the reference wraps the operator in a ``MaskedLinearOperator``, exact_marginal_log_likelihood.py:68-77)."""
+        nv = None if self.noise_vec is None else self.noise_vec[idx]
+        return FusedKernelAddedDiagLinearOperator(self.kernel_op[idx, idx], self.noise, self.bbmm_opts, nv)
+
     def _use_cholesky(self, flag) -> bool:
         return flag.off() or self.shape[-1] <= settings.max_cholesky_size.value()
 
@@ -561,7 +567,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             raise ValueError(f"probe sharding needs num_trace_samples >= world size ({t_total} < {world})")
         opts = dict(opts, group=group, num_probes=b - a, t_total=t_total)
         if "generator" not in opts and opts.get("probes") is None:
-            opts["generator"] = torch.Generator(device=self.device).manual_seed(torch.initial_seed() % (2**31) + 7919 * (rank + 1))
+            opts["generator"] = settings.sharding.rank_generator(group, self.device)
         return opts
 
     def _preconditioner(self):

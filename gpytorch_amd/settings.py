@@ -12,11 +12,44 @@ from __future__ import annotations
 import torch
 
 
-class _feature_flag:
-    """``settings.py:84-119``."""
+_KEEP = object()
 
+
+class _Scoped:
+    """One process-global knob.  The state lives in the class attributes named by ``_fields``; an instance is a
+    ``with`` scope that installs new values on entry and puts the previous ones back on exit (saved at ENTRY, so
+    scopes nest and instances can be re-used).  Same surface as the three context bases of ``gpytorch/settings.py``
+    (``_feature_flag.on()/off()``, ``_value_context.value()``, ``_dtype_value_context.value(dtype)``)."""
+
+    _fields: tuple = ()
+
+    def __init__(self, *new):
+        self._new = new
+
+    def __enter__(self):
+        cls = type(self)
+        self._saved = tuple(getattr(cls, f) for f in cls._fields)
+        for f, v in zip(cls._fields, self._new):
+            if v is not _KEEP:
+                setattr(cls, f, v)
+        return self
+
+    def __exit__(self, *exc):
+        cls = type(self)
+        for f, v in zip(cls._fields, self._saved):
+            setattr(cls, f, v)
+        return False
+
+
+class _feature_flag(_Scoped):
+    """Boolean knob: ``_default`` unless a scope (or ``_set_state``) overrides it."""
+
+    _fields = ("_state",)
     _default = False
     _state = None
+
+    def __init__(self, state=True):
+        super().__init__(bool(state))
 
     @classmethod
     def is_default(cls):
@@ -24,7 +57,7 @@ class _feature_flag:
 
     @classmethod
     def on(cls):
-        return cls._default if cls.is_default() else cls._state
+        return cls._default if cls._state is None else cls._state
 
     @classmethod
     def off(cls):
@@ -34,22 +67,15 @@ class _feature_flag:
     def _set_state(cls, state):
         cls._state = state
 
-    def __init__(self, state=True):
-        self.prev = self.__class__._state
-        self.state = state
 
-    def __enter__(self):
-        self.__class__._set_state(self.state)
+class _value_context(_Scoped):
+    """Scalar knob; the class attribute ``_global_value`` is the default."""
 
-    def __exit__(self, *args):
-        self.__class__._set_state(self.prev)
-        return False
-
-
-class _value_context:
-    """``settings.py:122-144``."""
-
+    _fields = ("_global_value",)
     _global_value = None
+
+    def __init__(self, value):
+        super().__init__(value)
 
     @classmethod
     def value(cls):
@@ -59,56 +85,23 @@ class _value_context:
     def _set_value(cls, value):
         cls._global_value = value
 
-    def __init__(self, value):
-        self._orig_value = self.__class__.value()
-        self._instance_value = value
 
-    def __enter__(self):
-        self.__class__._set_value(self._instance_value)
+class _dtype_value_context(_Scoped):
+    """Knob with one value per floating dtype (float / double / half); ``None`` arguments keep the current value."""
 
-    def __exit__(self, *args):
-        self.__class__._set_value(self._orig_value)
-        return False
+    _fields = ("_global_float_value", "_global_double_value", "_global_half_value")
+    _global_float_value = _global_double_value = _global_half_value = None
 
-
-class _dtype_value_context:
-    """``settings.py:35-81``: per-dtype values (float / double / half)."""
-
-    _global_float_value = None
-    _global_double_value = None
-    _global_half_value = None
+    def __init__(self, float_value=None, double_value=None, half_value=None):
+        super().__init__(*(_KEEP if v is None else v for v in (float_value, double_value, half_value)))
 
     @classmethod
     def value(cls, dtype):
-        if torch.is_tensor(dtype):
-            dtype = dtype.dtype
-        if dtype == torch.float:
-            return cls._global_float_value
-        if dtype == torch.double:
-            return cls._global_double_value
-        if dtype == torch.half:
-            return cls._global_half_value
-        raise RuntimeError(f"Unsupported dtype for {cls.__name__}.")
-
-    def __init__(self, float_value=None, double_value=None, half_value=None):
-        self._new = (float_value, double_value, half_value)
-        c = self.__class__
-        self._orig = (c._global_float_value, c._global_double_value, c._global_half_value)
-
-    def __enter__(self):
-        c = self.__class__
-        f, d, h = self._new
-        if f is not None:
-            c._global_float_value = f
-        if d is not None:
-            c._global_double_value = d
-        if h is not None:
-            c._global_half_value = h
-
-    def __exit__(self, *args):
-        c = self.__class__
-        c._global_float_value, c._global_double_value, c._global_half_value = self._orig
-        return False
+        dtype = dtype.dtype if torch.is_tensor(dtype) else dtype
+        slot = {torch.float32: "_global_float_value", torch.float64: "_global_double_value", torch.float16: "_global_half_value"}.get(dtype)
+        if slot is None:
+            raise RuntimeError(f"Unsupported dtype for {cls.__name__}.")
+        return getattr(cls, slot)
 
 
 # ---- BBMM knobs (defaults of linear_operator.settings v0.6.x; SURVEY.md section 5) ----
@@ -206,6 +199,28 @@ class min_variance(_dtype_value_context):
     _global_half_value = 1e-3
 
 
+class min_fixed_noise(_dtype_value_context):
+    """``gpytorch/settings.py:272-296``: floor of FixedNoiseGaussianLikelihood noise values."""
+    _global_float_value = 1e-4
+    _global_double_value = 1e-6
+    _global_half_value = 1e-3
+
+
+class observation_nan_policy(_value_context):
+    """``gpytorch/settings.py:416-446``: "ignore" | "mask" | "fill" -- how NaN observations are treated by the MLL."""
+    _global_value = "ignore"
+
+    def __init__(self, value):
+        if value not in ("ignore", "mask", "fill"):
+            raise ValueError(f"NaN handling policy {value} not supported!")
+        super().__init__(value)
+
+
+class fast_pred_samples(_feature_flag):
+    """``gpytorch/settings.py:225-243``: draw posterior samples from the LOVE (Lanczos) root instead of a Cholesky factor."""
+    _default = False
+
+
 class cholesky_jitter(_dtype_value_context):
     _global_float_value = 1e-6
     _global_double_value = 1e-8
@@ -262,6 +277,7 @@ class sharding:
 
     _probe_group = None
     _row_group = None
+    _generators: dict = {}
 
     def __init__(self, probe_group=None, row_group=None):
         self._new = (probe_group, row_group)
@@ -273,6 +289,23 @@ class sharding:
     @classmethod
     def row_group(cls):
         return cls._row_group
+
+    @classmethod
+    def rank_generator(cls, group, device):
+        """The probe generator of this rank: created ONCE per (group, device) from the process seed and the rank, then
+        left to advance -- consecutive MLL evaluations draw fresh probes (as the single-GPU path does from the global
+        RNG) while ranks stay decorrelated.  ``torch.manual_seed`` followed by ``sharding.reset_generators()`` re-seeds."""
+        key = (id(group), str(device))
+        gen = cls._generators.get(key)
+        if gen is None:
+            rank = torch.distributed.get_rank(group)
+            gen = torch.Generator(device=device).manual_seed(torch.initial_seed() % (2**31) + 7919 * (rank + 1))
+            cls._generators[key] = gen
+        return gen
+
+    @classmethod
+    def reset_generators(cls):
+        cls._generators.clear()
 
     def __enter__(self):
         self._old = (sharding._probe_group, sharding._row_group)

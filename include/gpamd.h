@@ -35,7 +35,7 @@ enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
  * the squared distances may be formed by the quadratic expansion on the matrix pipe (kv_gram.hpp; the expansion
  * the reference itself uses, gpytorch/kernels/kernel.py:26-49) with <= 2e-5 relative error in K (worst case at the limit; typically 5e-6).  Ignored for
  * Matern nu = 1/2. */
-enum { GPAMD_KV_GRAM = 1, GPAMD_KV_ASYNC = 2 /* with GRAM: double-buffered DMA-staged variant (d <= 3, t <= 65) */ };
+enum { GPAMD_KV_GRAM = 1 };
 
 int gpamd_abi_version(void);
 const char* gpamd_last_error(void);

@@ -135,3 +135,27 @@ def kernel_matmul_chunked(kind, x1, x2, lengthscale, outputscale, rhs, chunk=409
             kc = e if nu == 0.5 else ((r + 1) * e if nu == 1.5 else (1 + r + r.pow(2) / 3) * e)
         outs.append((kc * outputscale) @ rhs)
     return torch.cat(outs, dim=-2)
+
+
+def kernel_matmul_rows(kind, x, rows, lengthscale, outputscale, rhs, chunk=128):
+    """Rows ``rows`` of ``K(x, x) @ rhs`` through the reference's DEFAULT dense formulas, one row chunk at a time:
+    RBF via the mean-centred Gram-trick ``sq_dist`` (kernels/kernel.py:26-49, functions/rbf_covariance.py:14-19),
+    Matern via ``dist`` = ``torch.cdist`` for x1 != x2 (kernels/kernel.py:52-60, functions/matern_covariance.py:18-50).
+    In float64 the Gram-trick cancellation is ~1e-15, so this is the exact value to the tolerance of any float32 path,
+    while the temporaries stay at chunk x n (the pairwise-difference form needs chunk x n x d)."""
+    outs = []
+    xr = x[rows]
+    if kind != "rbf":
+        mean = x.mean(dim=-2, keepdim=True)  # matern_kernel.py:94: centred by the mean of the full x1
+        xr, x = xr - mean, x - mean
+    for s in range(0, xr.shape[-2], chunk):
+        xc = xr[s : s + chunk]
+        if kind == "rbf":
+            kc = sq_dist(xc / lengthscale, x / lengthscale, False).div_(-2.0).exp_()
+        else:
+            nu = KINDS[kind]
+            r = torch.cdist(xc / lengthscale, x / lengthscale).clamp_min_(1e-15).mul_(math.sqrt(2 * nu))
+            e = torch.exp(-r)
+            kc = e if nu == 0.5 else (e.mul_(r + 1) if nu == 1.5 else e.mul_(1 + r + r.pow(2) / 3))
+        outs.append((kc @ rhs) * outputscale)
+    return torch.cat(outs, dim=-2)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B the structural variants of the fused K*V kernel (kv_mfma_tune.hpp) in ONE process.
+"""A/B the structural variants of the fused K*V kernel (csrc/tune/kv_mfma_tune.hpp, built into libgpamd_tune.so by `make -C gpytorch_amd/csrc tune`) in ONE process.
 
 For each variant and a sweep of split counts S: 2 warm-up + R timed launches bracketed by HIP events
 on the launch stream; reports median TFLOP/s (2 n^2 t / time) and the max abs deviation of the
@@ -15,13 +15,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gpytorch_amd import backend as B  # noqa: E402
-from gpytorch_amd._lib import LIB_PATH  # noqa: E402
+TUNE_LIB = os.path.join(ROOT, "gpytorch_amd", "csrc", "libgpamd_tune.so")  # make -C gpytorch_amd/csrc tune
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 t, d = 65, 3
 dev = torch.device("cuda:0")
-h = C.CDLL(LIB_PATH)
+h = C.CDLL(TUNE_LIB)
 h.gpamd_kv_partials_variant_f32.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                             C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
 torch.manual_seed(0)

@@ -11,6 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from tests.util import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -40,7 +42,7 @@ def _worker(rank, world, port, q):
     sol, T, info = OCG.linear_cg(mm, rhs, n_tridiag=t, tolerance=0.5, return_info=True, mean_residual_fn=mean_fn)
     ld = OS.slq_logdet(T, n) * (t / t_total)
     D.allreduce_sum_(ld, group)
-    q.put((rank, info["iters"], sol, float(ld), (a, b)))
+    q.put((rank, info["iters"], sol.numpy(), float(ld), (a, b)))  # plain data: a tensor would travel as a shm handle that dies with the worker
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,7 +54,7 @@ def test_probe_sharding_matches_single_process():
     from oracle import slq as OS
     from tests.util import make_data
 
-    world, port = 2, 29000 + os.getpid() % 2000
+    world, port = 2, free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -73,6 +75,7 @@ def test_probe_sharding_matches_single_process():
     sol, T, info = OCG.linear_cg(mm, rhs, n_tridiag=t_total, tolerance=0.5, return_info=True)
     ld = OS.slq_logdet(T, n)
     for rank, iters, s, ldr, (a, b) in results:
+        s = torch.from_numpy(s)
         assert iters == info["iters"]
         assert torch.allclose(s[:, : b - a], sol[:, a:b], rtol=0, atol=1e-12)
         assert torch.allclose(s[:, -1], sol[:, t_total], rtol=0, atol=1e-12)
@@ -130,7 +133,7 @@ def test_row_shard_host_logic():
     """RowShard on CPU tensors over gloo, 3 ranks: the row partition covers [0, n) without overlap,
     gather(local(v)) reproduces v (zero padded tail), the replicated cloud is padded consistently, the solver's partial
     arrays are summed over ranks into entry 0, broadcast takes rank 0's value."""
-    world, port = 3, 31000 + os.getpid() % 2000
+    world, port = 3, free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_row_worker, args=(r, world, port, q)) for r in range(world)]
@@ -173,7 +176,7 @@ def _row_cg_worker(rank, world, port, q):
         return D.allreduce_sum_(v.clone(), group)
 
     sol_loc, info = OCG.linear_cg(mm_local, rhs[rs.r0 : rs.r1], tolerance=1e-6, max_iter=300, return_info=True, rowsum_fn=rowsum)
-    q.put((rank, rs.r0, rs.r1, info["iters"], sol_loc))
+    q.put((rank, rs.r0, rs.r1, info["iters"], sol_loc.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -187,7 +190,7 @@ def test_row_sharded_cg_matches_single_process():
     from oracle import linear_cg as OCG
     from tests.util import make_data
 
-    world, port = 3, 33000 + os.getpid() % 2000
+    world, port = 3, free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_row_cg_worker, args=(r, world, port, q)) for r in range(world)]
@@ -202,6 +205,7 @@ def test_row_sharded_cg_matches_single_process():
     rhs = torch.cat([y.unsqueeze(-1), torch.randn(n, t - 1, generator=torch.Generator().manual_seed(8), dtype=torch.float64)], -1)
     sol, info = OCG.linear_cg(OG.make_matmul("rbf", X, 0.25, 1.0, 0.1), rhs, tolerance=1e-6, max_iter=300, return_info=True)
     for rank, r0, r1, iters, sol_loc in results:
+        sol_loc = torch.from_numpy(sol_loc)
         assert iters == info["iters"]
         # (unlike probe sharding, the reduction ORDER changes: rounding differences grow along the CG recurrence)
         assert torch.allclose(sol_loc, sol[r0:r1], rtol=0, atol=1e-6 * float(sol.abs().max()))

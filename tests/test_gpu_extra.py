@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from oracle import exact_gp as OG
 from oracle import kernels as OK
-from tests.util import make_data, rel_err
+from tests.util import free_port, make_data, rel_err
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -145,7 +145,7 @@ def test_two_rank_probe_sharding_on_device(dev):
     from gpytorch_amd import backend as B
     from gpytorch_amd.bbmm import inv_quad_logdet_forward
 
-    world, port = 2, 29500 + os.getpid() % 400
+    world, port = 2, free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_rank_worker, args=(r, world, port, q)) for r in range(world)]
@@ -202,7 +202,7 @@ def _row_worker(rank, world, port, q, fixed_noise):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     mu, var, info = _posterior(g, dev, fixed_noise, dist.group.WORLD)
-    q.put((rank, mu.cpu(), var.cpu(), info))
+    q.put((rank, mu.cpu().numpy(), var.cpu().numpy(), info))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -253,7 +253,7 @@ def test_row_sharded_posterior_on_device(world, fixed_noise, dev):
     single-process run, on every rank."""
     import gpytorch_amd as g
 
-    port = 29100 + os.getpid() % 400 + world
+    port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_row_worker, args=(r, world, port, q, fixed_noise)) for r in range(world)]
@@ -265,6 +265,7 @@ def test_row_sharded_posterior_on_device(world, fixed_noise, dev):
     assert iters > 10
     assert float(var.min()) > 1e-4  # the single-process LOVE variances are themselves converged (nothing clipped)
     for rank, mu_r, var_r, it_r in results:
+        mu_r, var_r = torch.from_numpy(mu_r), torch.from_numpy(var_r)
         assert abs(it_r - iters) <= max(4, 0.08 * iters), (rank, it_r, iters)  # float32 summation order, see test_gpu_bbmm
         assert float((mu_r - mu).abs().max()) < 2e-4 * float(mu.abs().max()), rank
         # Lanczos coefficients are chaotic in float32 beyond ~30 steps (any two implementations diverge), so the LOVE
@@ -317,7 +318,7 @@ def test_probe_sharding_through_the_model_api(dev):
     """settings.sharding(probe_group=...): ExactMarginalLogLikelihood through the gpytorch-shaped API on 2 ranks sharing
     cuda:0; each rank solves 24 of the 48 probes (+ y).  Every rank reports the same value and gradients (all-reduced),
     and they agree with the dense float64 MLL to the accuracy of a 48-probe trace estimate."""
-    world, port = 2, 29900 + os.getpid() % 300
+    world, port = 2, free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_probe_api_worker, args=(r, world, port, q)) for r in range(world)]

@@ -202,7 +202,7 @@ def test_gram_split_is_consistent_on_rounding_ties(dev):
     """Regression: the hi/lo f16 split of the Gram-form kernels must take lo from the hi that is stored.  With this
     cloud one contracted point has |z|^2 within one float32 ulp of an f16 rounding tie; a recomputed norm once put hi on
     the other neighbour and every K entry of that column was off by 3e-4 (found by scripts/micro/pack_check.hip).
-    K is extracted column block by column block through unit vectors, for the synchronous and the DMA-staged kernel."""
+    K is extracted column block by column block through unit vectors."""
     from gpytorch_amd import backend as B
 
     kind, d, n, m, t = "matern52", 3, 1025, 1300, 64
@@ -216,7 +216,7 @@ def test_gram_split_is_consistent_on_rounding_ties(dev):
     r = s2.sqrt()
     K = (1 + r + s2 / 3) * torch.exp(-r)
     try:
-        for flags in (B.KV_GRAM, B.KV_GRAM | B.KV_ASYNC):
+        for flags in (B.KV_GRAM,):
             B.FORCE_KV_FLAGS = flags
             for j0 in (1152, 0):
                 E = torch.zeros(t, B.round_up(m, 4), device=dev)
@@ -226,27 +226,3 @@ def test_gram_split_is_consistent_on_rounding_ties(dev):
                 assert float((cols - K[:, idx]).abs().max()) < 3e-6, (flags, j0)
     finally:
         B.FORCE_KV_FLAGS = None
-
-
-@pytest.mark.parametrize("kind,n,m,d,t", [("rbf", 700, 1100, 3, 33), ("rbf", 1025, 1300, 2, 64), ("matern52", 999, 3001, 3, 65),
-                                          ("rbf", 5000, 4097, 4, 40), ("matern32", 300, 31, 3, 50)])
-def test_dma_staged_kernel_equals_synchronous_kernel(kind, n, m, d, t, dev):
-    """kv_gram2.hpp (software-pipelined, global_load_lds staging; flag KV_ASYNC, not selected by default) performs the
-    same arithmetic in the same order as kv_gram.hpp: results are bit-identical, ragged tails included."""
-    from gpytorch_amd import backend as B
-
-    g = torch.Generator().manual_seed(n + m)
-    X1 = torch.rand(n, d, generator=g).to(dev)
-    X2 = torch.rand(m, d, generator=g).to(dev)
-    sh = X1.mean(0)
-    p1, p2 = B.prep_points(kind, X1, torch.tensor(0.4), sh), B.prep_points(kind, X2, torch.tensor(0.4), sh)
-    vt = torch.randn(t, B.round_up(m, 4), device=dev)
-    vt[:, m:] = 0
-    try:
-        B.FORCE_KV_FLAGS = B.KV_GRAM
-        a = B.kv(p1, p2, vt).clone()
-        B.FORCE_KV_FLAGS = B.KV_GRAM | B.KV_ASYNC
-        b = B.kv(p1, p2, vt).clone()
-    finally:
-        B.FORCE_KV_FLAGS = None
-    assert torch.equal(a[:, :n], b[:, :n])

@@ -29,6 +29,21 @@ def test_header_symbols_exported_and_bound():
     assert h.gpamd_abi_version() == 1
 
 
+def test_library_exports_nothing_beyond_the_header():
+    """The converse: every ``gpamd_*`` symbol the product library exports is declared in include/gpamd.h (tuning /
+    ablation entry points live in libgpamd_tune.so, not here)."""
+    import subprocess
+
+    from gpytorch_amd._lib import LIB_PATH
+
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-nm") else "nm"
+    out = subprocess.run([nm, "-D", "--defined-only", LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("gpamd_")})
+    declared = _declared_symbols()
+    extra = [s_ for s_ in exported if s_ not in declared]
+    assert not extra, f"exported but not declared in include/gpamd.h: {extra}"
+
+
 def test_kv_plan_covers_and_fills():
     from gpytorch_amd import backend as B
 
