@@ -71,6 +71,9 @@ SIGNATURES = {
     "gpamd_cg64_stop": (_i, [_p, _i, _i, _i, C.c_double, _p]),
     "gpamd_cg64_finish": (_i, [_p, _p]),
     "gpamd_kv_grad_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p]),
+    "gpamd_kv_grad2_workspace_doubles": (_i64, [_i, _i, _i, _i]),
+    "gpamd_kv_grad2_xworkspace_floats": (_i64, [_i, _i, _i, _i]),
+    "gpamd_kv_grad2_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p, _i64, _p, _i64, _p]),
 }
 
 

@@ -46,6 +46,8 @@ def work_dtype(t: torch.Tensor) -> torch.dtype:
 
 
 KV_GRAM = 1              # flag of gpamd_kv_partials_f32 (include/gpamd.h)
+KV_WIDE = 2              # with KV_GRAM, tuning / A-B only: keep 3..32 columns off the 4-column-group kernel (kv_gram4.hpp)
+KV_G4 = 4                # with KV_GRAM, tuning / A-B only: 9..12 columns on kv_gram4 (three groups) instead of kv_gram16
 GRAM_MAX_SQNORM = 32.0   # max |z|^2 for which the split-f16 quadratic expansion keeps K within 2e-5 (gram_f16.hpp)
 FORCE_GENERIC = False    # tests: send float32 / d <= 16 problems down the generic (row-block + GEMM) path too
 FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or KV_GRAM regardless of |z|
@@ -379,6 +381,51 @@ def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.
         "kv_grad",
     )
     return out
+
+
+FORCE_GRAD_DIRECT = False  # tests: keep the bilinear derivative on the direct-difference kernel (kv_grad.hpp)
+
+
+def grad_gram_ok(x1: PreparedPoints, x2: PreparedPoints) -> bool:
+    """The Gram-form derivative kernel (kv_grad2.hpp) applies: fused float32 clouds, not Matern-1/2, max |z|^2 <= 32."""
+    if FORCE_GRAD_DIRECT or not (x1.fused and x2.fused) or x1.kind == "matern12":
+        return False
+    return max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) <= GRAM_MAX_SQNORM
+
+
+def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor, iso: bool = False, want_gz1: bool = False):
+    """Gram-form fused bilinear derivative (same return convention as :func:`kv_grad`), optionally with the gradient with
+    respect to the PREPARED left points: returns (g float32 [1 + dp], gz1 float32 [n, d] or None)."""
+    _require_gpu(lt, "left")
+    assert x1.kind == x2.kind and x1.dp == x2.dp and lt.shape[0] == rt.shape[0]
+    lt = lt if lt.dtype == torch.float32 else lt.to(torch.float32)
+    rt = rt if rt.dtype == torch.float32 else rt.to(torch.float32)
+    t, dev, L = lt.shape[0], lt.device, lib()
+    nd = int(L.gpamd_kv_grad2_workspace_doubles(x1.n, x2.n, t, x1.d))
+    ws = torch.empty(nd, device=dev, dtype=torch.float64)
+    out = torch.empty(1 + x1.dp, device=dev, dtype=torch.float32)
+    gzt = xws = None
+    nx = 0
+    ldg = round_up(x1.n, 4)
+    if want_gz1:
+        nx = int(L.gpamd_kv_grad2_xworkspace_floats(x1.n, x2.n, t, x1.d))
+        xws = torch.empty(nx, device=dev, dtype=torch.float32)
+        gzt = torch.empty(x1.d, ldg, device=dev, dtype=torch.float32)
+    check(
+        L.gpamd_kv_grad2_f32(
+            KIND_IDS[x1.kind], _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.d, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
+            1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, _stream(dev),
+        ),
+        "kv_grad2",
+    )
+    if iso and want_gz1:  # the kernel ran in per-dimension mode: fold to the single-lengthscale convention of kv_grad
+        out = torch.cat([out[:1], out[1 : 1 + x1.d].sum().reshape(1), torch.zeros(x1.dp - 1, device=dev)])
+    return out, (None if gzt is None else gzt[:, : x1.n].t().contiguous())
+
+
+def prep_coef(kind: str) -> float:
+    """z = coef * (x - shift) / lengthscale (prep_points): sqrt(log2(e)/2) for RBF, sqrt(2 nu) for Matern."""
+    return {"rbf": RBF_PREP_COEF, "matern12": 1.0, "matern32": math.sqrt(3.0), "matern52": math.sqrt(5.0)}[kind]
 
 
 def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor) -> torch.Tensor:

@@ -11,6 +11,8 @@
 #include "kv_dispatch.hpp"
 #include "kv_valu.hpp"
 #include "kv_gramv.hpp"
+#include "kv_gram4.hpp"
+#include "kv_gram16.hpp"
 #include "misc_kernels.hpp"
 
 using namespace gpamd;
@@ -64,17 +66,29 @@ struct KvVariant {
   bool valu;
   int tpad;    // valu: 1,2,4,8
   int ct, ex;  // mfma
+  int g4;      // > 0: kv_gram4 with this many column groups of four (2, 3, 6); 16: kv_gram16
   int bm;      // rows per workgroup
   int bn;      // j tile
 };
 
 bool gram_ok(int kind, int flags);
 
-// gram: the Gram-form kernels apply -- then 9..16 columns also stay on the VALU-contraction kernel (kv_gramv, T = 16:
-// exp + 8 packed fmas per pair beats a 32-column MFMA tile that is at most half full)
-KvVariant pick_variant(int t, bool gram) {  // t <= 129 handled per launch group
+// gram: the Gram-form kernels apply.  Column-count ladder (measured at n = 500 000, profiles/r02_s*_kv_small_t*.json):
+//   1..4   kv_gramv (VALU contraction)            5..8   kv_gram4, two column groups of four (4x4x1 MFMA)
+//   9..16  kv_gram16 (16-column 16x16x1_4B tile)  17..24 kv_gram4, six groups     25..  kv_gram (32-column tiles)
+// flags (tuning / A-B only): GPAMD_KV_WIDE restores the older selection (VALU contraction up to 16 columns, the 32-column
+// tile above), GPAMD_KV_G4 sends 9..12 columns to kv_gram4 with three groups
+KvVariant pick_variant(int t, bool gram, int flags = 0) {  // t <= 129 handled per launch group
   KvVariant v{};
-  if (t <= 8 || (gram && t <= 16)) {
+  const bool wide = flags & GPAMD_KV_WIDE;
+  if (gram && !wide && t >= 5 && t <= 24) {
+    if (t <= 8) v.g4 = 2;
+    else if (t <= 12 && (flags & GPAMD_KV_G4)) v.g4 = 3;
+    else if (t <= 16) v.g4 = 16;   // kv_gram16
+    else v.g4 = 6;
+    v.bm = v.g4 == 16 ? KG16_BM : kg4_bm(v.g4);
+    v.bn = v.g4 == 16 ? KG16_BN : KG4_BN;
+  } else if (t <= 8 || (gram && t <= 16)) {
     v.valu = true;
     v.tpad = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : (t <= 8 ? 8 : 16)));
     v.bm = KVV_BM;
@@ -108,6 +122,14 @@ int kernel_dims(int d) {  // kernels exist for these valid-dimension counts; oth
 }
 
 const void* family_ptr(int kind, int mode, int d, int v, int ex) {
+  if (mode == KV_MODE_GRAM4) {
+    switch (kind) {
+      case GPAMD_RBF: return kvm_kernel_ptr_rbf(d, v);
+      case GPAMD_MATERN32: return kvm_kernel_ptr_matern32(d, v);
+      case GPAMD_MATERN52: return kvm_kernel_ptr_matern52(d, v);
+    }
+    return nullptr;
+  }
   if (mode == KV_MODE_GRAMV) {
     switch (kind) {
       case GPAMD_RBF: return kvs_kernel_ptr_rbf(d, v);
@@ -129,6 +151,7 @@ bool gram_ok(int kind, int flags) { return (flags & GPAMD_KV_GRAM) && kind != GP
 
 int kv_mode(int kind, int flags, int d, const KvVariant& v) {
   const bool gram = gram_ok(kind, flags);
+  if (v.g4) return KV_MODE_GRAM4;
   if (v.valu) return gram ? KV_MODE_GRAMV : KV_MODE_VALU;
   return gram ? KV_MODE_GRAM : KV_MODE_MFMA;
 }
@@ -141,12 +164,15 @@ void variant_geometry(int mode, KvVariant* v) {
   }
 }
 
+int variant_key(const KvVariant& v) { return v.g4 ? v.g4 : (v.valu ? v.tpad : v.ct); }
+
 // resident workgroups per CU of the selected kernel (runtime occupancy query; static table without a device)
 int wg_per_cu(int kind, int mode, int dk, const KvVariant& v) {
-  const void* fn = family_ptr(kind, mode, dk, v.valu ? v.tpad : v.ct, v.ex);
+  const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex);
   int nb = 0;
   if (fn && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) return nb;
   (void)hipGetLastError();
+  if (v.g4) return 2;
   if (v.valu) return 4;
   if (mode == KV_MODE_GRAM) return 3;
   return v.ct <= 2 ? 3 : 2;
@@ -157,7 +183,7 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // runs in ceil(units / slots) rounds of resident workgroups: pick the S whose last round is nearly
   // full (efficiency = units / (rounds * slots)), keeping every chunk >= 16 LDS tiles (per-unit prologue
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
-  KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t, gram_ok(kind, flags));
+  KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t, gram_ok(kind, flags), flags);
   const int mode = kv_mode(kind, flags, d, v);
   variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
@@ -240,7 +266,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
   hipStream_t st = (hipStream_t)stream;
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0);
-    KvVariant v = pick_variant(tg, gram_ok(kind, flags));
+    KvVariant v = pick_variant(tg, gram_ok(kind, flags), flags);
     const int mode = kv_mode(kind, flags, d, v);
     variant_geometry(mode, &v);
     KvArgs a;
@@ -253,7 +279,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
-    const void* fn = family_ptr(kind, mode, dk, v.valu ? v.tpad : v.ct, v.ex);
+    const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
     void* kargs[] = {(void*)&a};
     (void)hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, 0, st);

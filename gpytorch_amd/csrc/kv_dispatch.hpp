@@ -4,7 +4,7 @@
 
 namespace gpamd {
 
-enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3 };
+enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3, KV_MODE_GRAM4 = 4 };
 
 // MFMA / Gram variants: CT 32-column tiles (1..4) + EX extra VALU column; NI row tiles per wave by CT.
 // NI*CT*16 accumulator registers: 64 (CT <= 2) .. 128 (CT = 4)
@@ -20,5 +20,10 @@ const void* kv_kernel_ptr_matern52(int mode, int d, int v, int ex);
 const void* kvs_kernel_ptr_rbf(int d, int tpad);
 const void* kvs_kernel_ptr_matern32(int d, int tpad);
 const void* kvs_kernel_ptr_matern52(int d, int tpad);
+
+// 3..32-column Gram-form kernels, contraction in column groups of four on v_mfma_f32_4x4x1 (kvm_<family>.hip)
+const void* kvm_kernel_ptr_rbf(int d, int groups);
+const void* kvm_kernel_ptr_matern32(int d, int groups);
+const void* kvm_kernel_ptr_matern52(int d, int groups);
 
 }  // namespace gpamd

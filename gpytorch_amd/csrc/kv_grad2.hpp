@@ -1,0 +1,266 @@
+// Fused bilinear derivative, Gram-form generation, workgroup-shared right tile, input gradients.
+//
+//   G_theta = sum_ij W_ij dK_ij/dtheta,   Gx1[i] = sum_j W_ij dK_ij/dx1_i,   W = L^T R (never formed in HBM)
+//
+// Same contract as kv_grad.hpp (LinearOperator._bilinear_derivative on the kernel operator + the dense kernel backward
+// of gpytorch/functions/rbf_covariance.py:26-29, matern_covariance.py:53-56; input gradients as the KeOps precedent
+// provides them, gpytorch/test/base_keops_test_case.py:105-132).  What changed against kv_grad.hpp (measured 0.37 of the
+// fp32 MFMA peak: every wave fetched its own copy of the R tile from L2, one dword per MFMA, latency-bound):
+//   * the R tile of a 64-row j step is staged ONCE per workgroup in LDS, transposed to Rs[j][k-half][c/2] so that a lane
+//     fetches the A operands of FOUR MFMA steps with one ds_read_b128 (the L tile, per wave, likewise: B operands);
+//   * squared distances come from the split-f16 Gram MFMA (gram_f16.hpp) instead of 3 D VALU ops per pair -- its result
+//     layout S[j(r,h)][i] is the layout of the W^T tile, so k, dk/ds and W meet in the same register slot;
+//   * per-dimension sums never touch (z_i - z_j) per pair: with A = W o dk/ds,
+//         sum_ij A_ij (z_iq - z_jq)^2 = sum_i [ z_iq^2 rs_i - 2 z_iq u_iq + v_iq ],
+//         rs_i = sum_j A_ij,  u_iq = sum_j A_ij z_jq,  v_iq = sum_j A_ij z_jq^2
+//     and [rs | u | v] = A^T-contraction against the columns [1 | z_j | z_j^2] -- the K*V contraction of kv_gram4.hpp with A
+//     in the place of K (v_mfma_f32_4x4x1, column groups of four).  The same rs / u give the input gradient for free:
+//         dS_ij/dz_iq = 2 (z_iq - z_jq)   ->   Gz1[i][q] = 2 (z_iq rs_i - u_iq)
+//     (the host applies dz/dx = coef / l_q and theta).  The combination is carried in float64 per j tile.
+//   * single-lengthscale hyper-gradients without input gradients (MODE 0) need only sum A_ij S_ij: one fma per pair.
+// Host policy as for kv_gram.hpp: max |z|^2 <= 32, never Matern nu = 1/2 (kv_grad.hpp remains the fallback).
+#pragma once
+#include "gram_f16.hpp"
+
+namespace gpamd {
+
+struct Grad2Args {
+  const float* X1;  // [n][DP] prepared
+  const float* X2;  // [m][DP]
+  const float* Lt;  // [t][ldl] left vectors (index i, with X1)
+  const float* Rt;  // [t][ldr] right vectors (index j, with X2)
+  int64_t ldl, ldr;
+  int n, m, t;
+  int S, jchunk, nrb;  // j split, chunk length (multiple of 64), row blocks of 128
+  int th4;             // MFMA k-steps (2 columns each) rounded up to a multiple of 4
+  int rs;              // LDS row stride (floats) of the L / R tiles: >= 2*th4, == 4 mod 32
+  double* part;        // [nrb*S][1 + DP]   (hyper-parameter partial sums)
+  float* Px;           // optional [S][DP][ldx] partial slabs of Gz1 (probe-major: one coordinate per row) or nullptr
+  int64_t ldx, pxstride;
+};
+
+constexpr int G2_BN = 64;  // j rows per step (two 32-row MFMA tiles)
+
+template <int KIND>
+__device__ __forceinline__ void cov_and_dcov(float s, float& k, float& dk) {
+  if constexpr (KIND == KIND_RBF) {
+    k = __builtin_amdgcn_exp2f(-s);
+    dk = -0.6931471805599453f * k;
+  } else {
+    const float r = __builtin_amdgcn_sqrtf(s);
+    const float e = __builtin_amdgcn_exp2f(-r * LOG2E);
+    if constexpr (KIND == KIND_MATERN32) {
+      k = (1.0f + r) * e;
+      dk = -0.5f * e;
+    } else {  // Matern 5/2
+      k = __builtin_fmaf(s, 1.0f / 3.0f, 1.0f + r) * e;
+      dk = -(1.0f + r) * e * (1.0f / 6.0f);
+    }
+  }
+}
+
+// MODE 0: one lengthscale, no input gradients (VALU: sum A S).   MODE 1: per-dimension sums + optional input gradients.
+template <int KIND, int D, int MODE>
+__global__ __launch_bounds__(256) void kv_grad2_kernel(Grad2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
+  constexpr int KH = GramF16<D>::KH;
+  constexpr int BN = G2_BN;
+  constexpr int NZ = 1 + 2 * D, GZ = (NZ + 3) / 4, LDZ = BN + 4;
+  const int RS = a.rs, TH4 = a.th4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5, l3 = lane & 3;
+  float* Ls = dyn + (size_t)wave * 32 * RS;                       // [32 i][RS]: this wave's L tile, [h][c2] within a row
+  float* Rs = dyn + (size_t)4 * 32 * RS;                          // [BN j][RS]
+  _Float16* Xh = reinterpret_cast<_Float16*>(Rs + (size_t)BN * RS);  // [KH][BN][16]
+  float* Zs = reinterpret_cast<float*>(Xh + KH * BN * 16);        // [4*GZ][LDZ]  (MODE 1)
+  __shared__ double red[4][1 + DP];
+
+  const int unit = blockIdx.x;
+  const int s = unit / a.nrb, rb = unit - s * a.nrb;
+  const int jbeg = s * a.jchunk;
+  const int jend = min(a.m, jbeg + a.jchunk);
+  const int i0 = rb * 128 + wave * 32;
+  const int i = i0 + l31;
+
+  // zero the padded tiles once (columns >= t and the k-step padding stay zero for the whole kernel)
+  for (int e = tid; e < (4 * 32 + BN) * RS; e += 256) dyn[e] = 0.f;
+  if constexpr (MODE == 1)
+    for (int e = tid; e < 4 * GZ * LDZ; e += 256) Zs[e] = 0.f;
+  __syncthreads();
+  // this wave's L tile: Ls[ic][h_c][c2] = L[c][i0 + ic], c = 2 c2 + h_c   (128-B coalesced rows of Lt)
+  for (int c = h; c < a.t; c += 2) {
+    float v = 0.f;
+    if (i < a.n) v = a.Lt[(int64_t)c * a.ldl + i];
+    Ls[l31 * RS + (c & 1) * TH4 + (c >> 1)] = v;
+  }
+  float zi[DP];
+  {
+    const int ic = min(i, a.n - 1);
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.X1 + (int64_t)ic * DP + 4 * q);
+      zi[4 * q + 0] = v[0]; zi[4 * q + 1] = v[1]; zi[4 * q + 2] = v[2]; zi[4 * q + 3] = v[3];
+    }
+  }
+  f16x8 bq[KH];
+  gram_pack_b<D>(zi, h, bq);
+  double g[1 + DP];
+#pragma unroll
+  for (int q = 0; q <= DP; ++q) g[q] = 0.0;
+  float gx[DP];
+#pragma unroll
+  for (int q = 0; q < DP; ++q) gx[q] = 0.f;
+
+  for (int j0 = jbeg; j0 < jend; j0 += BN) {
+    __syncthreads();
+    // ---- stage the R tile, transposed: global rows of Rt are read 16 B per thread (coalesced along j)
+    for (int idx = tid; idx < a.t * (BN / 4); idx += 256) {
+      const int c = idx / (BN / 4), q = idx % (BN / 4);
+      const int j = j0 + 4 * q;
+      const float* src = a.Rt + (int64_t)c * a.ldr + j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (j + 4 <= jend && ((a.ldr & 3) == 0)) {
+        v = *reinterpret_cast<const f32x4*>(src);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (j + e < jend) v[e] = src[e];
+      }
+      float* dst = Rs + (size_t)(4 * q) * RS + (c & 1) * TH4 + (c >> 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[(size_t)e * RS] = v[e];
+    }
+    if (tid < BN) {  // contracted points of this step: split augmented rows (+ the [1 | z | z^2] columns)
+      const int j = j0 + tid;
+      float z[DP];
+#pragma unroll
+      for (int q = 0; q < DQ; ++q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP + 4 * q);
+        z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
+      }
+      gram_pack_a<D>(z, j < jend, Xh, tid, BN);
+      if constexpr (MODE == 1) {
+        Zs[tid] = j < jend ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+          Zs[(1 + q) * LDZ + tid] = z[q];
+          Zs[(1 + D + q) * LDZ + tid] = z[q] * z[q];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- W^T tiles of the two 32-row j blocks on the matrix pipe (A = R, B = L; 4 k-steps per LDS read)
+    f32x16 w0, w1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { w0[r] = 0.f; w1[r] = 0.f; }
+    const float* lrow = Ls + l31 * RS + h * TH4;
+    const float* r0row = Rs + (size_t)l31 * RS + h * TH4;
+    const float* r1row = Rs + (size_t)(32 + l31) * RS + h * TH4;
+    for (int c4 = 0; c4 < TH4; c4 += 4) {
+      const f32x4 lb = *reinterpret_cast<const f32x4*>(lrow + c4);
+      const f32x4 ra = *reinterpret_cast<const f32x4*>(r0row + c4);
+      const f32x4 rbv = *reinterpret_cast<const f32x4*>(r1row + c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        w0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[e], lb[e], w0, 0, 0, 0);
+        w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(rbv[e], lb[e], w1, 0, 0, 0);
+      }
+    }
+    // ---- squared distances of the same two blocks (Gram form)
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      const f16x8 a0 = *reinterpret_cast<const f16x8*>(&Xh[(kh * BN + l31) * 16 + 8 * h]);
+      const f16x8 a1 = *reinterpret_cast<const f16x8*>(&Xh[(kh * BN + 32 + l31) * 16 + 8 * h]);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[kh], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[kh], s1, 0, 0, 0);
+    }
+    // ---- consume: k, dk/ds, A = W dk/ds
+    float f0 = 0.f, f1 = 0.f;
+    f32x4 zacc[GZ];
+#pragma unroll
+    for (int gz = 0; gz < GZ; ++gz) zacc[gz] = (f32x4)(0.f);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        f32x4 zv[GZ];
+        if constexpr (MODE == 1) {
+          const int jl = half * 32 + 8 * q4 + 4 * h;
+#pragma unroll
+          for (int gz = 0; gz < GZ; ++gz) zv[gz] = *reinterpret_cast<const f32x4*>(&Zs[(4 * gz + l3) * LDZ + jl]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q4 + e;
+          float sv = half ? s1[r] : s0[r];
+          sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
+          const float w = half ? w1[r] : w0[r];
+          float kv, dk;
+          cov_and_dcov<KIND>(sv, kv, dk);
+          f0 = __builtin_fmaf(w, kv, f0);
+          const float av = w * dk;
+          if constexpr (MODE == 0) {
+            f1 = __builtin_fmaf(av, sv, f1);
+          } else {
+#pragma unroll
+            for (int gz = 0; gz < GZ; ++gz) zacc[gz] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv[gz][e], av, zacc[gz], 0, 0, 0);
+          }
+        }
+      }
+    }
+    g[0] += (double)f0;
+    if constexpr (MODE == 0) {
+      g[1] += (double)f1;
+    } else {
+      // columns: 0 -> rs, 1 + q -> u_q, 1 + D + q -> v_q   (this lane's j half; the combination is linear in them)
+      const float rs = zacc[0][0];
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const float u = zacc[(1 + q) / 4][(1 + q) % 4];
+        const float v = zacc[(1 + D + q) / 4][(1 + D + q) % 4];
+        const double zq = (double)zi[q];
+        g[1 + q] += zq * zq * (double)rs - 2.0 * zq * (double)u + (double)v;
+        gx[q] += 2.f * (zi[q] * rs - u);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int q = 0; q <= DP; ++q) {
+    double v = wave_sum(g[q]);
+    if (lane == 0) red[wave][q] = v;
+  }
+  __syncthreads();
+  if (tid <= DP) a.part[(int64_t)unit * (1 + DP) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if constexpr (MODE == 1) {
+    if (a.Px) {
+      float* Pout = a.Px + (int64_t)s * a.pxstride;
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const float tot = gx[q] + __shfl_xor(gx[q], 32, 64);
+        if (h == 0 && i < a.n) Pout[(int64_t)q * a.ldx + i] = tot;
+      }
+    }
+  }
+}
+
+// out[q] = sum_u part[u][q]   (1 block of 256 threads; fixed order -> reproducible)
+template <int UNUSED>
+__global__ __launch_bounds__(256) void grad2_finalize_kernel(const double* __restrict__ part, int units, int nq, float* __restrict__ out) {
+  __shared__ double sm[4];
+  for (int q = 0; q < nq; ++q) {
+    double acc = 0.0;
+    for (int u = threadIdx.x; u < units; u += 256) acc += part[(int64_t)u * nq + q];
+    acc = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) out[q] = (float)acc;
+    __syncthreads();
+  }
+}
+
+}  // namespace gpamd

@@ -1,0 +1,182 @@
+// extern "C" entry points of the Gram-form fused bilinear-derivative kernel with input gradients (kv_grad2.hpp).
+// A kvm_* translation unit: compiled with -mllvm -amdgpu-mfma-vgpr-form=1 (the W^T and distance tiles are consumed by the
+// VALU straight from the MFMA destination registers).
+#include "../../include/gpamd.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "cg_kernels.hpp"
+#include "kv_grad2.hpp"
+
+using namespace gpamd;
+namespace gpamd {
+extern thread_local char g_err[512];
+}
+
+namespace {
+constexpr int G2_MAXCOLS = 66;  // columns per launch: 33 MFMA k-steps -> 36 padded -> LDS rows of 76 floats (2 workgroups / CU)
+
+int g2_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+int g2_groups(int t) {
+  int g = 0;
+  for (int rem = t; rem > 0; ++g) rem -= rem > G2_MAXCOLS ? 64 : rem;
+  return g;
+}
+
+void g2_plan(int n, int m, int* S, int* jchunk, int* nrb) {
+  *nrb = (n + 127) / 128;
+  const int slots = g2_num_cus() * 2;
+  int smax = m / 512;
+  if (smax < 1) smax = 1;
+  if (smax > 64) smax = 64;
+  int best = 1;
+  double best_eff = -1;
+  for (int s = 1; s <= smax; ++s) {
+    const int jc = ((m + s - 1) / s + G2_BN - 1) / G2_BN * G2_BN;
+    const int se = (m + jc - 1) / jc;
+    const long units = (long)(*nrb) * se;
+    const long rounds = (units + slots - 1) / slots;
+    const double eff = (double)units / (double)(rounds * slots);
+    if (eff > best_eff + 0.01) { best_eff = eff; best = s; }
+  }
+  const int jc = ((m + best - 1) / best + G2_BN - 1) / G2_BN * G2_BN;
+  *jchunk = jc;
+  *S = (m + jc - 1) / jc;
+}
+
+int kdims(int d) { return d <= 6 ? d : (d <= 8 ? 8 : (d <= 10 ? 10 : (d <= 12 ? 12 : 16))); }
+
+template <int KIND, int D>
+size_t g2_lds(int rs, int mode) {
+  constexpr int KH = GramF16<D>::KH;
+  constexpr int GZ = (1 + 2 * D + 3) / 4;
+  return (size_t)(4 * 32 + G2_BN) * rs * 4 + (size_t)KH * G2_BN * 16 * 2 + (mode ? (size_t)4 * GZ * (G2_BN + 4) * 4 : 0);
+}
+
+template <int KIND, int D>
+int launch_d(int mode, const Grad2Args& a, unsigned grid, hipStream_t st) {
+  const size_t lds = g2_lds<KIND, D>(a.rs, mode);
+  if (mode == 0) {
+    auto kfn = kv_grad2_kernel<KIND, D, 0>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
+  } else {
+    auto kfn = kv_grad2_kernel<KIND, D, 1>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
+  }
+  return 0;
+}
+
+template <int KIND>
+int launch_kind(int dk, int mode, const Grad2Args& a, unsigned grid, hipStream_t st) {
+  switch (dk) {
+    case 1: return launch_d<KIND, 1>(mode, a, grid, st);
+    case 2: return launch_d<KIND, 2>(mode, a, grid, st);
+    case 3: return launch_d<KIND, 3>(mode, a, grid, st);
+    case 4: return launch_d<KIND, 4>(mode, a, grid, st);
+    case 5: return launch_d<KIND, 5>(mode, a, grid, st);
+    case 6: return launch_d<KIND, 6>(mode, a, grid, st);
+    case 8: return launch_d<KIND, 8>(mode, a, grid, st);
+    case 10: return launch_d<KIND, 10>(mode, a, grid, st);
+    case 12: return launch_d<KIND, 12>(mode, a, grid, st);
+    case 16: return launch_d<KIND, 16>(mode, a, grid, st);
+  }
+  return -2;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d) {
+  if (n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return 0;
+  int S, jc, nrb;
+  g2_plan(n, m, &S, &jc, &nrb);
+  const int dp = (d + 3) / 4 * 4;
+  return (int64_t)g2_groups(t) * nrb * S * (1 + dp);
+}
+
+int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d) {
+  if (n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return 0;
+  int S, jc, nrb;
+  g2_plan(n, m, &S, &jc, &nrb);
+  const int dp = (d + 3) / 4 * 4;
+  return (int64_t)g2_groups(t) * S * dp * ((n + 3) / 4 * 4);
+}
+
+int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Lt, int64_t ldl,
+                       const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
+                       int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, void* stream) {
+  if (n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m || d < 1 || d > 16) {
+    snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: bad arguments");
+    return GPAMD_EINVAL;
+  }
+  if (kind != GPAMD_RBF && kind != GPAMD_MATERN32 && kind != GPAMD_MATERN52) {
+    snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: Gram-form generation needs RBF / Matern 3/2 / Matern 5/2 (use gpamd_kv_grad_f32)");
+    return GPAMD_EUNSUPPORTED;
+  }
+  const int dp = (d + 3) / 4 * 4, dk = kdims(d);
+  int S, jc, nrb;
+  g2_plan(n, m, &S, &jc, &nrb);
+  const int groups = g2_groups(t);
+  const int64_t units = (int64_t)nrb * S;
+  const int64_t ldx = (n + 3) / 4 * 4;
+  if (workspace_doubles < groups * units * (1 + dp)) return GPAMD_EWORKSPACE;
+  if (Gz1t && (xworkspace_floats < (int64_t)groups * S * dp * ldx || ldg < n || ldg % 4)) return GPAMD_EWORKSPACE;
+  const int mode = (iso && !Gz1t) ? 0 : 1;
+  hipStream_t st = (hipStream_t)stream;
+  int c0 = 0;
+  for (int g = 0; g < groups; ++g) {
+    const int rem = t - c0;
+    const int tg = rem > G2_MAXCOLS ? 64 : rem;
+    Grad2Args a;
+    a.X1 = X1p; a.X2 = X2p;
+    a.Lt = Lt + (int64_t)c0 * ldl;
+    a.Rt = Rt + (int64_t)c0 * ldr;
+    a.ldl = ldl; a.ldr = ldr;
+    a.n = n; a.m = m; a.t = tg;
+    a.S = S; a.jchunk = jc; a.nrb = nrb;
+    a.th4 = ((tg + 1) / 2 + 3) / 4 * 4;
+    a.rs = 2 * a.th4 + 4;   // = 4 * odd: eight lanes' 16-byte reads at this row stride cover all 32 banks exactly once
+    a.part = workspace + (int64_t)g * units * (1 + dp);
+    a.Px = Gz1t ? xworkspace + (int64_t)g * S * dp * ldx : nullptr;
+    a.ldx = ldx;
+    a.pxstride = (int64_t)dp * ldx;
+    int rc = -2;
+    switch (kind) {
+      case GPAMD_RBF: rc = launch_kind<KIND_RBF>(dk, mode, a, (unsigned)units, st); break;
+      case GPAMD_MATERN32: rc = launch_kind<KIND_MATERN32>(dk, mode, a, (unsigned)units, st); break;
+      case GPAMD_MATERN52: rc = launch_kind<KIND_MATERN52>(dk, mode, a, (unsigned)units, st); break;
+    }
+    if (rc) return GPAMD_EUNSUPPORTED;
+    c0 += tg;
+  }
+  // hyper-parameter sums: out[0] = sum W k, out[1 + q] = per-dimension sums (mode 0: out[1] = the single-lengthscale sum)
+  hipLaunchKernelGGL(grad2_finalize_kernel<0>, dim3(1), dim3(256), 0, st, workspace, (int)(groups * units), 1 + dp, out);
+  if (Gz1t) {
+    long nb = ((long)n + 1023) / 1024;
+    if (nb > CG_MAXNB) nb = CG_MAXNB;
+    hipLaunchKernelGGL((kv_reduce_kernel<float, false>), dim3((unsigned)nb, d), dim3(256), 0, st, (const float*)xworkspace, groups * S,
+                       (int64_t)dp * ldx, ldx, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (int64_t)0, Gz1t, ldg, n, (float*)nullptr, (const int*)nullptr);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+}  // extern "C"

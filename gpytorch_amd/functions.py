@@ -5,8 +5,9 @@ Mirror (third-party linear_operator):
     derivative with left = [K^-1 z c | -K^-1 y], right = [P^-1 z | K^-1 y])
   * ``functions/_matmul.py::Matmul`` / ``KernelLinearOperator._bilinear_derivative``
 and the kernel-side backward of ``gpytorch/functions/rbf_covariance.py:26-29`` /
-``matern_covariance.py:53-56``.  Like those Functions, gradients with respect to the INPUT
-LOCATIONS x are not provided (``rbf_covariance.py:9-10`` raises for them).
+``matern_covariance.py:53-56``.  Gradients with respect to the INPUT LOCATIONS x -- which those dense Functions
+refuse (``rbf_covariance.py:9-10``) and the KeOps precedent provides (``gpytorch/test/base_keops_test_case.py:105-132``)
+-- come from the same fused pass (``kv_grad2.hpp``); outside its accuracy policy they are refused loudly, never silently zero.
 """
 from __future__ import annotations
 
@@ -29,23 +30,42 @@ class KernelSpec:
         return KernelSpec(self.kind, self.shift, dvec)
 
 
-def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t):
-    """d/d(lengthscale), d/d(outputscale) of sum_c left[c]^T (outputscale * k(x1, x2)) right[c]."""
+def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t, want_x1=False, want_x2=False):
+    """d/d(lengthscale), d/d(outputscale) of  sum_c left[c]^T (outputscale * k(x1, x2)) right[c]  and, on request, its
+    gradients with respect to the input locations x1 / x2 ([n, d] / [m, d], in the units of the ORIGINAL points).
+
+    Returns (d_ls, d_os) or, with ``want_x1`` / ``want_x2``, (d_ls, d_os, d_x1, d_x2)."""
     wd = xp1.dtype
     ls = lengthscale.detach().to(wd).reshape(-1)
-    if xp1.fused and xp2.fused:
-        g = B.kv_grad(xp1, xp2, left_t, right_t, iso=ls.numel() == 1)
+    iso = ls.numel() == 1
+    gz1 = gz2 = None
+    if B.grad_gram_ok(xp1, xp2):
+        g, gz1 = B.kv_grad2(xp1, xp2, left_t, right_t, iso=iso, want_gz1=want_x1)
+        if want_x2:  # the same kernel with the roles of the two clouds exchanged
+            _, gz2 = B.kv_grad2(xp2, xp1, right_t, left_t, iso=iso, want_gz1=True)
     else:
-        g = B.kv_grad_generic(xp1, xp2, left_t, right_t).to(wd)
+        if want_x1 or want_x2:
+            raise RuntimeError(
+                "gradients with respect to the inputs need the Gram-form derivative kernel (float32, d <= 16, RBF / Matern "
+                "3/2 / 5/2, max |x / lengthscale|^2 within the accuracy policy); this operator is outside it"
+            )
+        if xp1.fused and xp2.fused:
+            g = B.kv_grad(xp1, xp2, left_t, right_t, iso=iso)
+        else:
+            g = B.kv_grad_generic(xp1, xp2, left_t, right_t).to(wd)
     d = xp1.d
     theta = 1.0 if outputscale is None else outputscale.detach().reshape(()).to(wd)
     gq = g[1 : 1 + d]
-    if ls.numel() == 1:
+    if iso:
         d_ls = (theta * (-2.0) / ls * gq.sum()).reshape(lengthscale.shape)
     else:
         d_ls = (theta * (-2.0) / ls * gq).reshape(lengthscale.shape)
     d_os = None if outputscale is None else g[0].reshape(outputscale.shape)
-    return d_ls.to(lengthscale.dtype), (None if d_os is None else d_os.to(outputscale.dtype))
+    d_ls, d_os = d_ls.to(lengthscale.dtype), (None if d_os is None else d_os.to(outputscale.dtype))
+    if not (want_x1 or want_x2):
+        return d_ls, d_os
+    chain = theta * B.prep_coef(xp1.kind) / ls  # dz/dx per dimension (1 or d values), times the outputscale
+    return d_ls, d_os, (None if gz1 is None else gz1 * chain), (None if gz2 is None else gz2 * chain)
 
 
 class InvQuadLogdetFn(torch.autograd.Function):
@@ -65,6 +85,7 @@ class InvQuadLogdetFn(torch.autograd.Function):
             group=opts.get("group"), t_total=opts.get("t_total"), dvec=spec.dvec,
         )
         ctx.xp, ctx.res, ctx.n = xp, res, n
+        ctx.x_dtype = x.dtype
         ctx.group = opts.get("group")
         ctx.t_total = opts.get("t_total") or res.zt.shape[0]
         ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0), noise, rhs)
@@ -90,7 +111,12 @@ class InvQuadLogdetFn(torch.autograd.Function):
         # the replicated y block is weighted 1/world so the all-reduced sum counts it once
         left = torch.cat([s_z * (g_ld / ctx.t_total), -s_y * (g_iq / world)], dim=0).contiguous()
         right = torch.cat([zr, s_y], dim=0).contiguous()
-        d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, left, right)
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            d_ls, d_os, gx1, gx2 = hyper_grads(xp, xp, lengthscale, outputscale, left, right, want_x1=True, want_x2=True)
+            d_x = (gx1 + gx2).to(ctx.x_dtype)
+        else:
+            d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, left, right)
         d_noise = B.coldot(left, right, n).sum().reshape(noise.shape).to(noise.dtype)
         if ctx.group is not None:
             pack = torch.cat([d_ls.reshape(-1).to(xp.dtype), d_noise.reshape(-1).to(xp.dtype)] + ([d_os.reshape(-1).to(xp.dtype)] if d_os is not None else []))
@@ -103,7 +129,9 @@ class InvQuadLogdetFn(torch.autograd.Function):
         d_rhs = None
         if ctx.needs_input_grad[4]:
             d_rhs = (2.0 * B.from_probe_major(s_y, n) * g_iq.reshape(1, c)).to(rhs.dtype)
-        return None, d_ls, d_os, d_noise, d_rhs, None, None
+        if d_x is not None and ctx.group is not None:
+            allreduce_sum_(d_x, ctx.group)
+        return d_x, d_ls, d_os, d_noise, d_rhs, None, None
 
 
 class CholeskyInvQuadLogdetFn(torch.autograd.Function):
@@ -143,10 +171,15 @@ class CholeskyInvQuadLogdetFn(torch.autograd.Function):
         rt = torch.zeros(n + c, ld, device=sol.device, dtype=xp.dtype)
         lt[:, :n] = left
         rt[:, :n] = right
-        d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, lt, rt)
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            d_ls, d_os, gx1, gx2 = hyper_grads(xp, xp, lengthscale, outputscale, lt, rt, want_x1=True, want_x2=True)
+            d_x = gx1 + gx2
+        else:
+            d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, lt, rt)
         d_noise = (left * right).sum().reshape(noise.shape).to(noise.dtype)
         d_rhs = (2.0 * sol * g_iq.to(torch.float64).reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[4] else None
-        return None, d_ls, d_os, d_noise, d_rhs, None
+        return d_x, d_ls, d_os, d_noise, d_rhs, None
 
 
 class KernelMatmulFn(torch.autograd.Function):
@@ -154,6 +187,7 @@ class KernelMatmulFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, lengthscale, outputscale, noise, rhs, spec: KernelSpec):
+        ctx.same_x = x2 is x1
         xp1 = B.prep_points(spec.kind, x1, lengthscale, spec.shift)
         xp2 = xp1 if x2 is x1 else B.prep_points(spec.kind, x2.to(x1.dtype), lengthscale, spec.shift)
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp1.dtype).contiguous()
@@ -175,8 +209,11 @@ class KernelMatmulFn(torch.autograd.Function):
         wd = ctx.xp1.dtype
         gt = B.to_probe_major(g, wd)
         rt = B.to_probe_major(rhs, wd)
-        d_ls = d_os = d_noise = d_rhs = None
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+        d_ls = d_os = d_noise = d_rhs = d_x1 = d_x2 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            d_ls, d_os, d_x1, d_x2 = hyper_grads(ctx.xp1, ctx.xp2, lengthscale, outputscale, gt, rt,
+                                                 want_x1=ctx.needs_input_grad[0], want_x2=ctx.needs_input_grad[1])
+        elif ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             d_ls, d_os = hyper_grads(ctx.xp1, ctx.xp2, lengthscale, outputscale, gt, rt)
         if noise is not None and ctx.needs_input_grad[4]:
             d_noise = (g * rhs).sum().reshape(noise.shape).to(noise.dtype)
@@ -185,4 +222,82 @@ class KernelMatmulFn(torch.autograd.Function):
             nz = None if noise is None else noise.detach().reshape(-1)[:1].to(wd).contiguous()
             out_t = B.kv(ctx.xp2, ctx.xp1, gt, scale=os_, dscale=nz, vd=gt if nz is not None else None, dvec=ctx.dvec)
             d_rhs = B.from_probe_major(out_t, ctx.xp2.n).to(rhs.dtype)
-        return None, None, d_ls, d_os, d_noise, d_rhs, None
+        return d_x1, d_x2, d_ls, d_os, d_noise, d_rhs, None
+
+
+class KernelDenseFn(torch.autograd.Function):
+    """``to_dense()`` of outputscale * k(x1, x2) with hyper-parameter gradients (the eager branch of
+    ``exact_prediction``, ``exact_prediction_strategies.py:331-369``, when n + m <= max_eager_kernel_size).
+    Backward: sum_ij G_ij dK_ij/dtheta = the fused bilinear derivative with left = I, right = G."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, lengthscale, outputscale, spec: KernelSpec):
+        xp1 = B.prep_points(spec.kind, x1, lengthscale, spec.shift)
+        xp2 = xp1 if x2 is x1 else B.prep_points(spec.kind, x2.to(x1.dtype), lengthscale, spec.shift)
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp1.dtype).contiguous()
+        ctx.xp1, ctx.xp2 = xp1, xp2
+        ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0))
+        ctx.has_os = outputscale is not None
+        return B.kernel_dense(xp1, xp2, os_).to(x1.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        lengthscale, outputscale = ctx.saved_tensors
+        outputscale = outputscale if ctx.has_os else None
+        xp1, xp2 = ctx.xp1, ctx.xp2
+        n, m = xp1.n, xp2.n
+        wd = xp1.dtype
+        lt = torch.zeros(n, B.round_up(n, 4), device=g.device, dtype=wd)
+        lt[:, :n] = torch.eye(n, device=g.device, dtype=wd)
+        rt = torch.zeros(n, B.round_up(m, 4), device=g.device, dtype=wd)
+        rt[:, :m] = g.to(wd)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            d_ls, d_os, d_x1, d_x2 = hyper_grads(xp1, xp2, lengthscale, outputscale, lt, rt, want_x1=ctx.needs_input_grad[0],
+                                                 want_x2=ctx.needs_input_grad[1])
+            return d_x1, d_x2, d_ls, d_os, None
+        d_ls, d_os = hyper_grads(xp1, xp2, lengthscale, outputscale, lt, rt)
+        return None, None, d_ls, d_os, None
+
+
+class SolveFn(torch.autograd.Function):
+    """K_hat^-1 rhs by preconditioned mBCG with the reference's ``Solve`` backward (linear_operator functions/_solve.py;
+    exercised by test/lazy/test_lazy_evaluated_kernel_tensor.py:69-113): with X = K_hat^-1 B and Y = K_hat^-1 G,
+    d/dB = Y and d/dtheta = -sum_c Y_c^T (dK_hat/dtheta) X_c -- ONE more mBCG solve and ONE fused bilinear derivative."""
+
+    @staticmethod
+    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec, precond, tolerance):
+        from .linear_cg import linear_cg
+
+        xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
+        nz = noise.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
+        sol_t, info = linear_cg(xp, os_, nz, B.to_probe_major(rhs.detach(), xp.dtype), n_tridiag=0, tolerance=tolerance,
+                                preconditioner=precond, dvec=spec.dvec)
+        ctx.xp, ctx.os_, ctx.nz, ctx.sol_t, ctx.spec, ctx.precond, ctx.tol = xp, os_, nz, sol_t, spec, precond, tolerance
+        ctx.info = info
+        ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0), noise)
+        ctx.has_os = outputscale is not None
+        ctx.rhs_dtype = rhs.dtype
+        return B.from_probe_major(sol_t, xp.n).to(rhs.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .linear_cg import linear_cg
+
+        lengthscale, outputscale, noise = ctx.saved_tensors
+        outputscale = outputscale if ctx.has_os else None
+        xp = ctx.xp
+        y_t, _ = linear_cg(xp, ctx.os_, ctx.nz, B.to_probe_major(g, xp.dtype), n_tridiag=0, tolerance=ctx.tol,
+                           preconditioner=ctx.precond, dvec=ctx.spec.dvec)
+        left = -y_t
+        d_ls = d_os = d_noise = d_rhs = d_x = None
+        if ctx.needs_input_grad[0]:
+            d_ls, d_os, gx1, gx2 = hyper_grads(xp, xp, lengthscale, outputscale, left.contiguous(), ctx.sol_t, want_x1=True, want_x2=True)
+            d_x = gx1 + gx2
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, left.contiguous(), ctx.sol_t)
+        if ctx.needs_input_grad[3]:
+            d_noise = B.coldot(left.contiguous(), ctx.sol_t, xp.n).sum().reshape(noise.shape).to(noise.dtype)
+        if ctx.needs_input_grad[4]:
+            d_rhs = B.from_probe_major(y_t, xp.n).to(ctx.rhs_dtype)
+        return d_x, d_ls, d_os, d_noise, d_rhs, None, None, None

@@ -21,7 +21,7 @@ import torch
 
 from . import backend as B
 from . import settings
-from .functions import CholeskyInvQuadLogdetFn, InvQuadLogdetFn, KernelMatmulFn, KernelSpec
+from .functions import CholeskyInvQuadLogdetFn, InvQuadLogdetFn, KernelDenseFn, KernelMatmulFn, KernelSpec, SolveFn
 
 
 class LinearOperator:
@@ -119,6 +119,17 @@ class LinearOperator:
 
     def detach(self):
         return self
+
+    def sum(self, dim=None):
+        """``LinearOperator.sum``: row / column sums through one product with a ones vector (matrix-free)."""
+        n, m = self.shape[-2], self.shape[-1]
+        if dim is None:
+            return self._matmul(torch.ones(m, 1, device=self.device, dtype=self.dtype)).sum()
+        if dim in (-1, 1):
+            return self._matmul(torch.ones(m, 1, device=self.device, dtype=self.dtype)).squeeze(-1)
+        if dim in (-2, 0):
+            return self._transpose_nonbatch()._matmul(torch.ones(n, 1, device=self.device, dtype=self.dtype)).squeeze(-1)
+        raise ValueError(f"invalid dim {dim}")
 
     def numel(self):
         return self.shape[-1] * self.shape[-2]
@@ -360,17 +371,24 @@ class FusedKernelLinearOperator(LinearOperator):
         self.spec = spec
         self.lengthscale, self.outputscale = lengthscale, outputscale
         self._prep = None
+        self._same = None
 
     dtype = property(lambda self: self.x1.dtype)
     device = property(lambda self: self.x1.device)
 
     @property
     def requires_grad(self):
-        return bool(self.lengthscale.requires_grad or (self.outputscale is not None and self.outputscale.requires_grad))
+        return bool(self.lengthscale.requires_grad or (self.outputscale is not None and self.outputscale.requires_grad)
+                    or self.x1.requires_grad or self.x2.requires_grad)
 
     @property
     def square_same_inputs(self):
-        return self.x1 is self.x2 or (self.x1.shape == self.x2.shape and self.x1.data_ptr() == self.x2.data_ptr())
+        """x1 and x2 are the same points (``torch.equal(x1, x2)`` in ``kernels/rbf_kernel.py:72``-style checks): identical
+        storage, or -- compared once and cached -- identical values."""
+        if self._same is None:
+            x1, x2 = self.x1, self.x2
+            self._same = x1 is x2 or (x1.shape == x2.shape and (x1.data_ptr() == x2.data_ptr() or bool(torch.equal(x1, x2))))
+        return self._same
 
     def _size(self):
         return torch.Size([self.x1.shape[-2], self.x2.shape[-2]])
@@ -405,6 +423,9 @@ class FusedKernelLinearOperator(LinearOperator):
         return B.kernel_diag(p1, p2, self._os()).to(self.dtype)
 
     def to_dense(self):
+        if torch.is_grad_enabled() and self.requires_grad:
+            x2 = self.x1 if self.square_same_inputs else self.x2
+            return KernelDenseFn.apply(self.x1, x2, self.lengthscale, self.outputscale, self.spec)
         p1, p2 = self.prepared()
         return B.kernel_dense(p1, p2, self._os()).to(self.dtype)
 
@@ -434,9 +455,27 @@ class FusedKernelLinearOperator(LinearOperator):
         return super().__add__(other)
 
     def detach(self):
+        x1 = self.x1.detach()
+        x2 = x1 if self.x2 is self.x1 else self.x2.detach()
         return FusedKernelLinearOperator(
-            self.x1, self.x2, self.spec, self.lengthscale.detach(), None if self.outputscale is None else self.outputscale.detach()
+            x1, x2, self.spec, self.lengthscale.detach(), None if self.outputscale is None else self.outputscale.detach()
         )
+
+    # ---- solves on the noise-free kernel matrix itself (``kernel(x, x).solve(rhs)``,
+    # test/lazy/test_lazy_evaluated_kernel_tensor.py:69-113): the same BBMM machinery with a zero diagonal
+    def _with_zero_diag(self):
+        if not (self.is_square and self.square_same_inputs):
+            raise RuntimeError("solve / inv_quad_logdet need a square kernel matrix k(x, x)")
+        return FusedKernelAddedDiagLinearOperator(self, torch.zeros(1, device=self.device, dtype=self.dtype))
+
+    def solve(self, rhs, lhs=None):
+        return self._with_zero_diag().solve(rhs, lhs)
+
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        return self._with_zero_diag().inv_quad_logdet(inv_quad_rhs, logdet, reduce_inv_quad)
+
+    def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
+        return self._with_zero_diag().root_inv_decomposition(initial_vectors, test_vectors, method)
 
     def pivoted_cholesky(self, rank, error_tol=None, return_pivots=False):
         """``LinearOperator.pivoted_cholesky`` (wrapper ``gpytorch/__init__.py:146-173``): returns L (n x m)."""
@@ -588,8 +627,9 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         return closure, None, pre.logdet
 
     def solve(self, rhs: torch.Tensor, lhs=None) -> torch.Tensor:
-        """K_hat^-1 rhs (``exact_prediction_strategies.py:286,444``).  No autograd through the solve
-        (prediction caches are detached: ``settings.detach_test_caches``)."""
+        """K_hat^-1 rhs (``exact_prediction_strategies.py:286,444``).  Differentiable (``SolveFn``) when gradients are
+        enabled and the operator or the right-hand side requires them; prediction caches normally run detached
+        (``settings.detach_test_caches``) and take the plain path."""
         from .bbmm import build_preconditioner
         from .linear_cg import linear_cg
 
@@ -599,6 +639,11 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             sol = torch.cholesky_solve(r.detach().to(torch.float64), torch.linalg.cholesky(self.to_dense().detach().to(torch.float64))).to(rhs.dtype)
         elif self._row_shard() is not None:
             sol = self._solve_row_sharded(r).to(rhs.dtype)
+        elif torch.is_grad_enabled() and (self.requires_grad or r.requires_grad) and self.kernel_op.prepared()[0].fused:
+            k = self.kernel_op
+            self._preconditioner()
+            sol = SolveFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, r, self._spec(), self._cache["precond"],
+                                settings.cg_tolerance.value())
         else:
             p1, _ = self.kernel_op.prepared()
             if "precond" not in self._cache:

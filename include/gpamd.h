@@ -35,7 +35,11 @@ enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
  * the squared distances may be formed by the quadratic expansion on the matrix pipe (kv_gram.hpp; the expansion
  * the reference itself uses, gpytorch/kernels/kernel.py:26-49) with <= 2e-5 relative error in K (worst case at the limit; typically 5e-6).  Ignored for
  * Matern nu = 1/2. */
-enum { GPAMD_KV_GRAM = 1 };
+enum {
+  GPAMD_KV_GRAM = 1,
+  GPAMD_KV_WIDE = 2, /* tuning / A-B only: with GRAM, the pre-round-2 selection (no kv_gram4 / kv_gram16) */
+  GPAMD_KV_G4 = 4    /* tuning / A-B only: with GRAM, 9..12 columns on kv_gram4 instead of kv_gram16 */
+};
 
 int gpamd_abi_version(void);
 const char* gpamd_last_error(void);
@@ -147,6 +151,19 @@ int64_t gpamd_kv_grad_workspace_doubles(int n, int m, int t, int dp);
 int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Lt, int64_t ldl,
                       const float* Rt, int64_t ldr, int t, int iso, float* out, double* workspace,
                       int64_t workspace_doubles, void* stream);
+
+/* ---- the same derivative with Gram-form generation (squared distances on the matrix pipe, kv_grad2.hpp) and, optionally,
+ * the gradient with respect to the PREPARED left points:  Gz1t[q][i] = sum_j W_ij dk/ds_ij * 2 (z_iq - z_jq)  (probe-major
+ * [d][ldg]; the caller applies dz/dx = coef / lengthscale_q and theta -- the input gradients the KeOps precedent provides,
+ * gpytorch/test/base_keops_test_case.py:105-132; the reference's dense Functions refuse them, rbf_covariance.py:9-10).
+ * RBF / Matern 3/2 / Matern 5/2 only, accurate while max |z|^2 <= 32 (the host's policy for every Gram-form kernel); d = valid
+ * dimensions (points are [n][round_up(d,4)]).  out: float[1 + round_up(d,4)] as gpamd_kv_grad_f32.  Gz1t == NULL: hyper-
+ * parameters only (xworkspace unused). ---- */
+int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d);
+int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d);
+int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Lt, int64_t ldl,
+                       const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
+                       int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, void* stream);
 
 /* ---- float64 (the reference honours float64 inputs).  Same conventions with double buffers.  The fused MFMA K*V
  * kernels are float32-only; in float64 K @ V is formed from dense row blocks of K generated by

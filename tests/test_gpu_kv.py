@@ -93,11 +93,16 @@ def test_golden_kernel_values(dev):
     "n,m,d,t",
     [
         (300, 300, 3, 1),     # VALU T=1
-        (513, 700, 3, 3),     # VALU T=4 padded, ragged n/m
-        (1000, 900, 10, 8),   # VALU T=8
-        (777, 1000, 3, 11),   # 9..16 columns: small-t Gram kernel T=16 (default num_trace_samples = 10 + y) / MFMA CT=1 when direct
-        (640, 900, 6, 16),    # same, full tile
-        (257, 300, 3, 32),    # MFMA CT=1
+        (411, 300, 2, 2),     # VALU T=2
+        (513, 700, 3, 3),     # Gram: 4-column-group kernel G=1 / direct: VALU T=4 padded; ragged n/m
+        (1000, 900, 10, 8),   # G=2 / VALU T=8
+        (777, 1000, 3, 11),   # G=3: the reference's default MLL shape (num_trace_samples = 10 + y) / MFMA CT=1 when direct
+        (900, 1500, 5, 13),   # G=4, ragged t
+        (640, 900, 6, 16),    # G=4, full
+        (515, 777, 3, 17),    # G=6 (two 32-row tiles per wave), ragged
+        (1030, 800, 4, 24),   # G=6, full
+        (700, 600, 3, 29),    # G=8, ragged
+        (257, 300, 3, 32),    # G=8 / MFMA CT=1
         (700, 1100, 3, 33),   # MFMA CT=1 + EX
         (1025, 1300, 6, 64),  # MFMA CT=2
         (600, 2100, 3, 65),   # MFMA CT=2 + EX (the MLL shape)
@@ -109,10 +114,11 @@ def test_golden_kernel_values(dev):
 )
 def test_kv_matches_oracle(kind, n, m, d, t, dev):
     """Both generation paths: direct differences (kv_mfma.hpp / kv_valu.hpp) and, for nu != 1/2, the Gram form
-    on the matrix pipe (kv_gram.hpp, kv_gramv.hpp for t <= 8; tolerance 5e-5: quadratic-expansion cancellation)."""
+    on the matrix pipe (kv_gram.hpp above 32 columns, kv_gram4.hpp for 3..32, kv_gramv.hpp for 1..2 -- and the older
+    VALU / 32-column-tile selection behind KV_WIDE; tolerance 5e-5: quadratic-expansion cancellation)."""
     from gpytorch_amd import backend as B
 
-    if kind != "rbf" and (t in (3, 8, 16, 70, 128, 129, 140)):
+    if kind != "rbf" and (t in (2, 3, 8, 13, 16, 17, 29, 70, 128, 129, 140)):
         pytest.skip("shape sweep is exhaustive for rbf; other families cover one shape per code path")
     g = torch.Generator().manual_seed(n + 7 * m + 13 * t)
     X1 = torch.rand(n, d, generator=g, dtype=torch.float64)
@@ -130,9 +136,10 @@ def test_kv_matches_oracle(kind, n, m, d, t, dev):
         assert rel_err(out, ref) < 2e-5
         if kind != "matern12":  # t <= 8: kv_gramv.hpp; t > 8: kv_gram.hpp
             assert max(p1.zmax2, p2.zmax2) <= B.GRAM_MAX_SQNORM  # the automatic policy would pick Gram here
-            B.FORCE_KV_FLAGS = B.KV_GRAM
-            out = B.from_probe_major(B.kv(p1, p2, vt), n)
-            assert rel_err(out, ref) < 5e-5
+            for flags in (B.KV_GRAM, B.KV_GRAM | B.KV_G4, B.KV_GRAM | B.KV_WIDE):
+                B.FORCE_KV_FLAGS = flags
+                out = B.from_probe_major(B.kv(p1, p2, vt), n)
+                assert rel_err(out, ref) < 5e-5, flags
     finally:
         B.FORCE_KV_FLAGS = None
 
