@@ -16,9 +16,13 @@ configs[1] itself.  Inputs are resident in HBM before the timed region.
                lazy_evaluated_kernel_tensor.py:245-275, restated in torch) timed on the host cores
                on a bounded row-sample of the same K*V
 
-N > 1: one process per GPU; each rank owns 64 probes of a 64*N global probe set (weak scaling);
-the only data-path collective is the 2-float stopping-rule all-reduce per CG iteration and the
-final scalar SLQ all-reduce (RCCL).
+  parity     = rows of the benchmarked K*V (same kernel instantiation, same n and column count, probe-like V) compared
+               with the float64 oracle OUTSIDE the timed region: max |GPU - oracle| / max |oracle|
+
+N > 1: one process per GPU.  Default (`--config metric`): each rank owns 64 probes of a 64*N global probe set (WEAK scaling;
+the y column is solved on rank 0 only).  `--config c4` = BASELINE configs[3]: n = 1 000 000, 256 probes in total split over
+the N ranks (32 + y on rank 0 at N = 8; STRONG scaling over the probe set).  The only data-path collectives are the 2-float
+stopping-rule all-reduce per CG iteration (stream-ordered RCCL), one scalar SLQ all-reduce and one broadcast of the y solve.
 """
 from __future__ import annotations
 
@@ -45,26 +49,58 @@ def synth(n, d, seed=0):
     return X, y
 
 
-def cpu_baseline(n, d, t, ls, budget_pairs=1.0e9):
-    """Oracle (port) K*V throughput on the host: rows [0, r) of one K*V against all n columns, r chosen so the
-    sample is ~1e9 kernel evaluations (10-30 s on a many-core host); row chunks sized to ~0.8 GB of temporaries."""
+def cpu_baseline(n, d, t, ls, budget_s=12.0):
+    """The reference's matrix-free K*V on the host cores, as SURVEY.md 8(d) prescribes: float32 (the reference computes in the
+    dtype of its inputs), row chunks of 4096 (`lazy_evaluated_kernel_tensor.py:245-275`: split x1, build the chunk of K with
+    the kernel's own forward -- the mean-centred Gram-trick `sq_dist` of `kernels/kernel.py:26-49` -- multiply, cat), restated
+    by the oracle.  Timed on a bounded sample: whole 4096-row chunks of ONE n x n product until ~budget_s seconds."""
+    import psutil
+
     from oracle import kernels as OK
 
     X, _ = synth(n, d)
-    X = X.double()
-    V = torch.randn(n, t, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
-    rows = int(max(64, min(n, budget_pairs // n)))
-    chunk = int(max(8, min(1024, 1.0e8 // (n * d))))
-    t0 = time.perf_counter()
-    OK.kernel_matmul_chunked("rbf", X[:rows], X, ls, 1.0, V, chunk=chunk)
+    V = torch.randn(n, t, generator=torch.Generator().manual_seed(1))
+    chunk = 4096
+    # a 4096 x n float32 chunk of K plus the temporaries of sq_dist / exp is ~4 chunk-sized buffers
+    if psutil.virtual_memory().available < 6 * chunk * n * 4:
+        chunk = max(64, int(psutil.virtual_memory().available // (6 * n * 4)) // 64 * 64)
+    rows_done, t0 = 0, time.perf_counter()
+    while rows_done < n and (rows_done == 0 or time.perf_counter() - t0 < budget_s):
+        xc = X[rows_done : rows_done + chunk]
+        kc = OK.rbf(xc, X, ls, x1_eq_x2=False)      # functions/rbf_covariance.py:14-19 on kernels/kernel.py:26-49
+        _ = kc @ V
+        rows_done += xc.shape[0]
     dt = time.perf_counter() - t0
-    flops = 2.0 * rows * n * t
     return {
-        "value": flops / dt / 1e12,
+        "value": 2.0 * rows_done * n * t / dt / 1e12,
         "unit": "TFLOP/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"rows 0:{rows} of one n={n} K*V with t={t} (chunked matrix-free path, float64, chunk {chunk}), {dt:.1f} s",
+        "dtype": "f32",
+        "sample": f"port of the reference's chunked matrix-free K*V, sampled: rows 0:{rows_done} of one n={n} product with t={t} in "
+                  f"{chunk}-row chunks (float32, Gram-trick sq_dist), {dt:.1f} s on {torch.get_num_threads()} threads",
+    }
+
+
+def parity_block(xp, Xcpu, n, d, t, ls, dev, nrows=2048):
+    """Rows of the benchmarked product vs the float64 oracle (reference formulas: oracle.kernels.kernel_matmul_rows)."""
+    from gpytorch_amd import backend as B
+    from oracle import kernels as OK
+
+    g = torch.Generator().manual_seed(99)
+    V = torch.randn(n, t, generator=g)
+    V = V / V.norm(dim=0, keepdim=True)                      # probe-like: unit columns, as the CG right-hand sides
+    out_t = B.kv(xp, xp, B.to_probe_major(V.to(dev)))
+    q = nrows // 4
+    rows = torch.cat([torch.arange(q), torch.randint(q, n - q, (nrows - 2 * q,), generator=g), torch.arange(n - q, n)]).unique()
+    got = out_t[:, rows.to(dev)].t().double().cpu()
+    ref = OK.kernel_matmul_rows("rbf", Xcpu.double(), rows, ls, 1.0, V.double())
+    return {
+        "kv_rel_err": float((got - ref).abs().max() / ref.abs().max()),
+        "rows": int(rows.numel()),
+        "columns": t,
+        "vs": "oracle fp64 (reference dense formulas, kernels/kernel.py:26-49 + functions/rbf_covariance.py:14-19)",
+        "tolerance": 2e-5,
     }
 
 
@@ -136,9 +172,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=500_000, help="number of training points n (not --n: torch.distributed.run's parser treats that as an ambiguous prefix)")
+    ap.add_argument("--config", choices=["metric", "c2", "c4"], default="metric",
+                    help="metric: n=500k, 64 probes/GPU + y (weak scaling; the configuration BASELINE.json's metric is quoted on); "
+                         "c2: configs[1] (n=100k); c4: configs[3], n=1e6 with 256 probes IN TOTAL split over the ranks (strong scaling)")
+    ap.add_argument("--size", type=int, default=None, help="override the number of training points n (not --n: torch.distributed.run's parser treats that as an ambiguous prefix)")
     ap.add_argument("--dims", type=int, default=3)
-    ap.add_argument("--probes", type=int, default=64)
+    ap.add_argument("--probes", type=int, default=None, help="override: probes per GPU (metric / c2) or in total (c4)")
+    ap.add_argument("--skip-parity", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="skip the untimed API-level MLL fwd+bwd / posterior timings")
     args = ap.parse_args()
@@ -168,7 +208,18 @@ def main():
     from gpytorch_amd import linear_cg as LCG
     from gpytorch_amd.bbmm import LOG_2PI, inv_quad_logdet_forward
 
-    n, d, t = args.size, args.dims, args.probes
+    strong = args.config == "c4"
+    n = args.size if args.size is not None else {"metric": 500_000, "c2": 100_000, "c4": 1_000_000}[args.config]
+    d = args.dims
+    if strong:
+        from gpytorch_amd.distributed import probe_shard
+
+        t_total = args.probes if args.probes is not None else 256
+        a_, b_ = probe_shard(t_total, world, rank)
+        t = b_ - a_
+    else:
+        t = args.probes if args.probes is not None else 64
+        t_total = t * world
     ls = {3: 0.25, 10: 0.8, 6: 0.5}.get(d, 0.25)
     X, y = synth(n, d)
     Xd, yd = X.to(dev), y.to(dev)
@@ -177,7 +228,6 @@ def main():
     noise = torch.tensor([0.1], device=dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     rhs_t = B.to_probe_major(yd.unsqueeze(-1))
-    t_total = t * world
     shift = Xd.mean(dim=0)
 
     def step():
@@ -216,7 +266,7 @@ def main():
     med = durs[len(durs) // 2]
     live = [x for x in durs if x > 0.2 * med]  # launches issued after convergence are device-side no-ops
     kv_ms = sum(live) / len(live)
-    cols = t + 1
+    cols = t + (1 if rank == 0 else 0)      # the y column is solved by rank 0 only
     flop_per_launch = 2.0 * n * n * cols
     achieved = flop_per_launch / (kv_ms * 1e-3) / 1e12
 
@@ -226,13 +276,17 @@ def main():
     traffic = None
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "kv_pmc_current.json")))
-        if prof.get("shape") == [n, d, t + 1]:
+        if prof.get("shape") == [n, d, cols]:
             traffic = prof.get("hbm_bytes_per_launch")
     except Exception:
         traffic = None
 
-    flops_step_rank = flop_per_launch * (iters_total / args.steps)
-    value = flops_step_rank * world * args.steps / elapsed / 1e12
+    # whole-job algorithmic flops of the timed region: every rank's columns (t_total probes + one y) x CG iterations
+    flops_job = 2.0 * n * n * (t_total + 1) * iters_total
+    value = flops_job / elapsed / 1e12
+    parity = None
+    if rank == 0 and not args.skip_parity:
+        parity = parity_block(B.prep_points("rbf", Xd, lengthscale, shift), X, n, d, cols, ls, dev)
 
     extras = None
     if world == 1 and not args.skip_extras:
@@ -248,15 +302,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"ExactGP MLL evaluation (mBCG + SLQ), RBF, n={n}, d={d}, {t} probes/GPU + y column, fused K*V HIP kernel, "
-                            "no preconditioner, cg_tolerance=1.0 (BASELINE metric config n=500k d=3 RBF; --size 100000 = configs[1])",
-                "n": n, "d": d, "probes_per_gpu": t, "rhs_columns": cols, "cg_iterations_per_step": iters_total / args.steps,
-                "parallelism": f"probe-sharded x{world}",
+                "workload": f"ExactGP MLL evaluation (mBCG + SLQ), RBF, n={n}, d={d}, {t_total} probes in total ({t} on rank 0) + y column, "
+                            f"fused K*V HIP kernel, no preconditioner, cg_tolerance=1.0 (--config {args.config}: "
+                            + {"metric": "the configuration BASELINE.json's metric is quoted on", "c2": "BASELINE configs[1]",
+                               "c4": "BASELINE configs[3], 256 probes split over the ranks"}[args.config] + ")",
+                "name": args.config, "n": n, "d": d, "probes_total": t_total, "probes_rank0": t, "rhs_columns_rank0": cols,
+                "cg_iterations_per_step": iters_total / args.steps,
+                "parallelism": f"probe-sharded x{world}, y column on rank 0",
             },
             "mll": float(mll),
             "roofline": {
@@ -267,12 +324,15 @@ def main():
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
-                "kernel": "kv_gram_kernel<RBF,D=3,CT=2,NI=2,EX=1> (Gram-form generation on split-f16 MFMA + fp32 MFMA contraction; kv_mfma_kernel when max|z|^2 > 32)",
+                "kernel": f"kv_gram_kernel<RBF,D=3,CT={(cols - 1) // 32 if cols % 32 == 1 else (cols + 31) // 32},EX={1 if cols % 32 == 1 else 0}> on rank 0 (Gram-form generation "
+                          "on split-f16 MFMA + fp32 MFMA contraction; kv_mfma_kernel when max|z|^2 > 32)",
                 "kernel_ms": kv_ms,
                 "launches_timed": len(live),
                 "flop_per_launch": flop_per_launch,
             },
         }
+        if parity is not None:
+            out["parity"] = parity
         if extras is not None:
             out["extras"] = extras
         if not args.skip_cpu_baseline and world == 1:  # timed on rank 0 at N = 1 only

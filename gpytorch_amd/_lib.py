@@ -42,6 +42,8 @@ SIGNATURES = {
     "gpamd_cg_init_norms_f32": (_i, [_p, _p, _i64, _p]),
     "gpamd_cg_init_apply_f32": (_i, [_p, _p, _i64, _i, _p]),
     "gpamd_cg_begin_apply_f32": (_i, [_p, _p]),
+    "gpamd_cg_dot_rz_f32": (_i, [_p, _p]),
+    "gpamd_cg_update_d_apply_f32": (_i, [_p, _i, _p]),
     "gpamd_cg_begin_f32": (_i, [_p, _p]),
     "gpamd_cg_reduce_q_f32": (_i, [_p, _p, _i, _i64, _p, _p, _p, _p]),
     "gpamd_cg_update_xr_f32": (_i, [_p, _i, _p]),

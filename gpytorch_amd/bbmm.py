@@ -16,7 +16,7 @@ from dataclasses import dataclass
 import torch
 
 from . import backend as B
-from .distributed import allreduce_sum_
+from .distributed import allreduce_sum_, broadcast_
 from . import settings
 from .linear_cg import CGInfo, Preconditioner, linear_cg
 
@@ -127,12 +127,13 @@ def slq_logdet(t_mats: torch.Tensor, n: int) -> torch.Tensor:
 class InvQuadLogdetResult:
     inv_quad: torch.Tensor       # [c] per rhs column (device float32)
     logdet: torch.Tensor         # scalar (device float32)
-    solves_t: torch.Tensor       # [t + c, ld] probe-major solves (probes first)
+    solves_t: torch.Tensor       # [t + c, ld] probe-major solves (probes first); sharded: the c rhs solves are the owner's, broadcast
     zt: torch.Tensor             # [t, ld] normalised probes
     znorm: torch.Tensor          # [t]
     precond: Preconditioner | None
     info: CGInfo
     logdet_pinvk: torch.Tensor   # SLQ part (before adding log|P|); local partial sum when sharded
+    owns_rhs: bool = True        # sharded: this rank solved the rhs columns (their gradient contribution is counted here only)
 
 
 def inv_quad_logdet_forward(
@@ -149,14 +150,16 @@ def inv_quad_logdet_forward(
     group=None,
     t_total=None,
     dvec=None,
+    rhs_owner: int = 0,
 ) -> InvQuadLogdetResult:
     """A.6 forward for K_hat = scale*K(x,x) + sigma2*I.
 
     rhs_t: [c, ld] probe-major ``inv_quad_rhs`` (usually c = 1: y - mu).
-    With ``group`` set the probe columns are sharded over ranks: ``num_probes`` / ``probes`` are
-    THIS rank's probes, ``t_total`` the global probe count (default: all-reduced sum); the rhs
-    columns ride on every rank (replicated, identical results); the only communication is the
-    2-float stopping-rule all-reduce per CG iteration and one scalar all-reduce of the SLQ sums."""
+    With ``group`` set the probe columns are sharded over ranks: ``num_probes`` / ``probes`` are THIS rank's probes,
+    ``t_total`` the global probe count (default: all-reduced sum).  The rhs columns are solved by ONE rank
+    (``rhs_owner``, a rank of the group; default 0) -- the others carry probes only -- and their solves / inverse quadratic
+    forms are broadcast once at the end.  Communication: the 2-float stopping-rule all-reduce per CG iteration (stream-
+    ordered under RCCL), one scalar all-reduce of the SLQ sums, one broadcast of the c rhs solves."""
     n = x.n
     dev = rhs_t.device
     wd = x.dtype
@@ -170,13 +173,17 @@ def inv_quad_logdet_forward(
     if probes is not None:
         t = probes.shape[-1]
     zt, znorm = probe_vectors(n, t, precond, dev, generator, probes, dtype=wd)
+    owns_rhs = True
+    if group is not None:
+        owns_rhs = torch.distributed.get_rank(group) == rhs_owner
     if t_total is None:
         t_total = t
         if group is not None:
             tt = torch.tensor([float(t)], device=dev, dtype=torch.float32)
             allreduce_sum_(tt, group)
             t_total = int(tt.item())
-    full = torch.cat([zt, rhs_t.to(wd)], dim=0).contiguous()
+    c = rhs_t.shape[0]
+    full = torch.cat([zt, rhs_t.to(wd)], dim=0).contiguous() if owns_rhs else zt
     solves_t, info = linear_cg(
         x, scale, sigma2, full, n_tridiag=t, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, group=group,
         dvec=dvec,
@@ -189,10 +196,14 @@ def inv_quad_logdet_forward(
     ld_slq = ld_slq.to(device=dev, dtype=wd)
     if group is not None:
         allreduce_sum_(ld_slq, group)
+        if not owns_rhs:
+            solves_t = torch.cat([solves_t, torch.zeros(c, solves_t.shape[1], device=dev, dtype=solves_t.dtype)], dim=0)
+        ysol = solves_t[t : t + c].contiguous()
+        broadcast_(ysol, rhs_owner, group)
+        solves_t[t : t + c] = ysol
     logdet = ld_slq + (precond.logdet if precond is not None else 0.0)
-    c = rhs_t.shape[0]
     inv_quad = B.coldot(solves_t[t : t + c], rhs_t.to(wd), n)
-    return InvQuadLogdetResult(inv_quad, logdet, solves_t, zt, znorm, precond, info, ld_slq)
+    return InvQuadLogdetResult(inv_quad, logdet, solves_t, zt, znorm, precond, info, ld_slq, owns_rhs)
 
 
 def solve(x: B.PreparedPoints, scale, sigma2, rhs_t, tolerance=None, max_iter=None, precond="auto"):

@@ -66,7 +66,7 @@ struct KvVariant {
   bool valu;
   int tpad;    // valu: 1,2,4,8
   int ct, ex;  // mfma
-  int g4;      // > 0: kv_gram4 with this many column groups of four (2, 3, 6); 16: kv_gram16
+  int g4;      // > 0: kv_gram4 with this many column groups of four (2, 3, 6); 16 / 17: kv_gram16 without / with EX
   int bm;      // rows per workgroup
   int bn;      // j tile
 };
@@ -78,16 +78,21 @@ bool gram_ok(int kind, int flags);
 //   9..16  kv_gram16 (16-column 16x16x1_4B tile)  17..24 kv_gram4, six groups     25..  kv_gram (32-column tiles)
 // flags (tuning / A-B only): GPAMD_KV_WIDE restores the older selection (VALU contraction up to 16 columns, the 32-column
 // tile above), GPAMD_KV_G4 sends 9..12 columns to kv_gram4 with three groups
-KvVariant pick_variant(int t, bool gram, int flags = 0) {  // t <= 129 handled per launch group
+KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false) {  // t <= 129 handled per launch group; light: RBF, d <= 3
   KvVariant v{};
   const bool wide = flags & GPAMD_KV_WIDE;
   if (gram && !wide && t >= 5 && t <= 24) {
     if (t <= 8) v.g4 = 2;
     else if (t <= 12 && (flags & GPAMD_KV_G4)) v.g4 = 3;
     else if (t <= 16) v.g4 = 16;   // kv_gram16
+    else if (t == 17) v.g4 = 17;   // kv_gram16 + the extra VALU column (16 probes + y)
     else v.g4 = 6;
-    v.bm = v.g4 == 16 ? KG16_BM : kg4_bm(v.g4);
-    v.bn = v.g4 == 16 ? KG16_BN : KG4_BN;
+    // RBF in <= 3 dimensions, 9..12 columns: generation is one v_exp_f32 per pair and three column groups on 4x4x1 beat the
+    // 16-column tile by 7 % (64.0 vs 68.7 ms at n = 500 000, t = 11); every heavier generation (Matern: + v_sqrt_f32, d > 3:
+    // more Gram MFMAs) does not issue under the 8-cycle MFMAs and is faster on the 16-column tile
+    if (v.g4 == 16 && t <= 12 && light) v.g4 = 3;
+    v.bm = v.g4 >= 16 ? KG16_BM : kg4_bm(v.g4);
+    v.bn = v.g4 >= 16 ? KG16_BN : KG4_BN;
   } else if (t <= 8 || (gram && t <= 16)) {
     v.valu = true;
     v.tpad = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : (t <= 8 ? 8 : 16)));
@@ -183,7 +188,7 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // runs in ceil(units / slots) rounds of resident workgroups: pick the S whose last round is nearly
   // full (efficiency = units / (rounds * slots)), keeping every chunk >= 16 LDS tiles (per-unit prologue
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
-  KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t, gram_ok(kind, flags), flags);
+  KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3);
   const int mode = kv_mode(kind, flags, d, v);
   variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
@@ -266,7 +271,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
   hipStream_t st = (hipStream_t)stream;
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0);
-    KvVariant v = pick_variant(tg, gram_ok(kind, flags), flags);
+    KvVariant v = pick_variant(tg, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3);
     const int mode = kv_mode(kind, flags, d, v);
     variant_geometry(mode, &v);
     KvArgs a;
@@ -457,6 +462,23 @@ int gpamd_cg_begin_apply_f32(gpamd_cg_t* h, void* stream) {
   if (!h) return fail(GPAMD_EINVAL, "cg_begin_apply: null handle");
   hipLaunchKernelGGL((cg_begin_kernel<float>), dim3(h->st.t), dim3(256), 0, (hipStream_t)stream, h->st);
   return check_launch("cg_begin_apply");
+}
+
+int gpamd_cg_dot_rz_f32(gpamd_cg_t* h, void* stream) {
+  if (!h) return fail(GPAMD_EINVAL, "cg_dot_rz: null handle");
+  CgState<float>& s = h->st;
+  hipLaunchKernelGGL((coldot_kernel<float>), dim3(s.nb, s.t), dim3(256), 0, (hipStream_t)stream, s.R, s.Z, s.ld, s.n, s.part_rz,
+                     (const int*)s.done);
+  return check_launch("cg_dot_rz");
+}
+
+int gpamd_cg_update_d_apply_f32(gpamd_cg_t* h, int k, void* stream) {
+  if (!h) return fail(GPAMD_EINVAL, "cg_update_d_apply: null handle");
+  CgState<float>& s = h->st;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((cg_update_d_kernel<float>), dim3(s.nb, s.t), dim3(256), 0, st, s, k);
+  hipLaunchKernelGGL((cg_stats_kernel<float>), dim3(1), dim3(256), 0, st, s);
+  return check_launch("cg_update_d_apply");
 }
 
 int gpamd_cg_begin_f32(gpamd_cg_t* h, void* stream) {

@@ -39,7 +39,8 @@ struct Grad2Args {
   int64_t ldx, pxstride;
 };
 
-constexpr int G2_BN = 64;  // j rows per step (two 32-row MFMA tiles)
+constexpr int G2_BN = 64;    // j rows per step (two 32-row MFMA tiles)
+constexpr int G2_MAXT = 66;  // columns per launch (host: kvm_grad2.hip)
 
 template <int KIND>
 __device__ __forceinline__ void cov_and_dcov(float s, float& k, float& dk) {
@@ -61,7 +62,7 @@ __device__ __forceinline__ void cov_and_dcov(float s, float& k, float& dk) {
 
 // MODE 0: one lengthscale, no input gradients (VALU: sum A S).   MODE 1: per-dimension sums + optional input gradients.
 template <int KIND, int D, int MODE>
-__global__ __launch_bounds__(256) void kv_grad2_kernel(Grad2Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void kv_grad2_kernel(Grad2Args a) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;
@@ -112,45 +113,71 @@ __global__ __launch_bounds__(256) void kv_grad2_kernel(Grad2Args a) {
 #pragma unroll
   for (int q = 0; q < DP; ++q) gx[q] = 0.f;
 
-  for (int j0 = jbeg; j0 < jend; j0 += BN) {
-    __syncthreads();
-    // ---- stage the R tile, transposed: global rows of Rt are read 16 B per thread (coalesced along j)
-    for (int idx = tid; idx < a.t * (BN / 4); idx += 256) {
+  // Staging is software-pipelined through registers: the global loads of step k+1 (R tile: <= 5 float4 per thread, x_j:
+  // one point per thread of the first wave) are issued BEFORE the MFMA phase of step k and land in LDS after it -- with two
+  // workgroups per CU nothing else would hide the ~2 us L2 latency of a synchronous stage (first build: 391 ms vs 242 ms for
+  // the K*V of equal flops, profiles/r02_s3_grad_timing_first.json).
+  constexpr int NR = (G2_MAXT * (BN / 4) + 255) / 256;
+  f32x4 rreg[NR];
+  float zreg[DP];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      const int idx = tid + 256 * rr;
       const int c = idx / (BN / 4), q = idx % (BN / 4);
       const int j = j0 + 4 * q;
-      const float* src = a.Rt + (int64_t)c * a.ldr + j;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (j + 4 <= jend && ((a.ldr & 3) == 0)) {
-        v = *reinterpret_cast<const f32x4*>(src);
-      } else {
+      if (c < a.t) {
+        const float* src = a.Rt + (int64_t)c * a.ldr + j;
+        if (j + 4 <= jend && ((a.ldr & 3) == 0)) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (j + e < jend) v[e] = src[e];
+          for (int e = 0; e < 4; ++e)
+            if (j + e < jend) v[e] = src[e];
+        }
       }
-      float* dst = Rs + (size_t)(4 * q) * RS + (c & 1) * TH4 + (c >> 1);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dst[(size_t)e * RS] = v[e];
+      rreg[rr] = v;
     }
-    if (tid < BN) {  // contracted points of this step: split augmented rows (+ the [1 | z | z^2] columns)
+    if (tid < BN) {
       const int j = j0 + tid;
-      float z[DP];
 #pragma unroll
       for (int q = 0; q < DQ; ++q) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP + 4 * q);
-        z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
+        zreg[4 * q + 0] = v[0]; zreg[4 * q + 1] = v[1]; zreg[4 * q + 2] = v[2]; zreg[4 * q + 3] = v[3];
       }
-      gram_pack_a<D>(z, j < jend, Xh, tid, BN);
+    }
+  };
+  fetch(jbeg);
+
+  for (int j0 = jbeg; j0 < jend; j0 += BN) {
+    __syncthreads();
+    // ---- registers -> LDS: the R tile transposed to Rs[j][k-half][c/2], the split augmented x_j rows, the [1 | z | z^2] columns
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      const int idx = tid + 256 * rr;
+      const int c = idx / (BN / 4), q = idx % (BN / 4);
+      if (c < a.t) {
+        float* dst = Rs + (size_t)(4 * q) * RS + (c & 1) * TH4 + (c >> 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(size_t)e * RS] = rreg[rr][e];
+      }
+    }
+    if (tid < BN) {
+      const int j = j0 + tid;
+      gram_pack_a<D>(zreg, j < jend, Xh, tid, BN);
       if constexpr (MODE == 1) {
         Zs[tid] = j < jend ? 1.f : 0.f;
 #pragma unroll
         for (int q = 0; q < D; ++q) {
-          Zs[(1 + q) * LDZ + tid] = z[q];
-          Zs[(1 + D + q) * LDZ + tid] = z[q] * z[q];
+          Zs[(1 + q) * LDZ + tid] = zreg[q];
+          Zs[(1 + D + q) * LDZ + tid] = zreg[q] * zreg[q];
         }
       }
     }
     __syncthreads();
+    if (j0 + BN < jend) fetch(j0 + BN);
 
     // ---- W^T tiles of the two 32-row j blocks on the matrix pipe (A = R, B = L; 4 k-steps per LDS read)
     f32x16 w0, w1;

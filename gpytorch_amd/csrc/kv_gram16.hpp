@@ -1,4 +1,4 @@
-// Fused covariance MVM for 9 <= t <= 16 right-hand sides: Gram-form generation (gram_f16.hpp) + contraction on a
+// Fused covariance MVM for 9 <= t <= 17 right-hand sides (the 17th -- 16 probes + y -- rides on the VALU, EX = 1): Gram-form generation (gram_f16.hpp) + contraction on a
 // 16-COLUMN matrix-pipe tile (v_mfma_f32_16x16x1_4B_f32).
 //
 // The reference's DEFAULT marginal-log-likelihood evaluation is an 11-column solve (num_trace_samples = 10 probes + y).
@@ -30,13 +30,14 @@ constexpr int KG16_LDT = KG16_BN + 4;    // padded LDS row of the V tile
 constexpr int KG16_NI = 4;               // 32-row tiles per wave
 constexpr int KG16_BM = 4 * KG16_NI * 32;
 
-template <int KIND, int D>
+template <int KIND, int D, int EX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GramF16<D>::KH == 1 ? 3 : 2, GramF16<D>::KH == 1 ? 3 : 2))) void kv_gram16_kernel(KvArgs a) {
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;
   constexpr int BN = KG16_BN, LDT = KG16_LDT, NI = KG16_NI, T = 16;
   __shared__ __attribute__((aligned(16))) float Vs[T * LDT];           // [c][j]
   __shared__ __attribute__((aligned(16))) _Float16 Xh[KH * BN * 16];   // [kh][j][16]
+  __shared__ __attribute__((aligned(16))) float Es[EX ? BN : 4];       // 17th column (EX): rides on the VALU
 
   if (a.done && *a.done) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,10 +61,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GramF16<D>:
     gram_pack_b<D>(z, h, bq[ni]);
   }
   f32x16 acc[NI];
+  float eacc[NI];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
+  for (int ni = 0; ni < NI; ++ni) {
+    eacc[ni] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+  }
 
   for (int j0 = jbeg; j0 < jend; j0 += BN) {
     __syncthreads();
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GramF16<D>:
         z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
       }
       gram_pack_a<D>(z, j < jend, Xh, tid, BN);
+      if constexpr (EX) Es[tid] = j < jend ? a.Vt[(int64_t)T * a.ldv + j] : 0.f;
     }
     __syncthreads();
 
@@ -123,12 +128,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GramF16<D>:
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(&Vs[l15 * LDT + jb + 8 * q + 4 * h]);
+        f32x4 ev;
+        if constexpr (EX) ev = *reinterpret_cast<const f32x4*>(&Es[jb + 8 * q + 4 * h]);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
+          for (int ni = 0; ni < NI; ++ni) {
             acc[ni] = __builtin_amdgcn_mfma_f32_16x16x1f32(av[e], kk[ni][4 * q + e], acc[ni], 0, 0, 0);
+            if constexpr (EX) eacc[ni] = __builtin_fmaf(kk[ni][4 * q + e], ev[e], eacc[ni]);
+          }
         __builtin_amdgcn_s_setprio(0);
       }
     }
@@ -149,6 +158,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GramF16<D>:
         if (i < a.n && c < a.t) Pout[(int64_t)c * a.ldo + i] = tot;
       }
     }
+  if constexpr (EX) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int i = ibase + ni * 32 + l31;
+      const float tot = eacc[ni] + __shfl_xor(eacc[ni], 32, 64);
+      if (h == 0 && i < a.n) Pout[(int64_t)T * a.ldo + i] = tot;
+    }
+  }
 }
 
 }  // namespace gpamd

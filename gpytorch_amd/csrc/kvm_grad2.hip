@@ -15,7 +15,7 @@ extern thread_local char g_err[512];
 }
 
 namespace {
-constexpr int G2_MAXCOLS = 66;  // columns per launch: 33 MFMA k-steps -> 36 padded -> LDS rows of 76 floats (2 workgroups / CU)
+constexpr int G2_MAXCOLS = G2_MAXT;  // columns per launch: 33 MFMA k-steps -> 36 padded -> LDS rows of 76 floats (2 workgroups / CU)
 
 int g2_num_cus() {
   static int cus = 0;

@@ -66,6 +66,30 @@ def allreduce_sum_(t: torch.Tensor, group=None):
     return t
 
 
+def allreduce_max_int(v: int, group=None) -> int:
+    """max over ranks of a host integer (one tiny collective; used to make launch / polling schedules rank-independent)."""
+    if group is None and not (dist.is_initialized() and dist.get_world_size() > 1):
+        return v
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([v], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+def broadcast_(t: torch.Tensor, src_group_rank: int, group=None):
+    """In-place broadcast from rank ``src_group_rank`` OF THE GROUP (host-staged under gloo with device tensors)."""
+    if group is None and not (dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    src = dist.get_global_rank(group, src_group_rank) if (group is not None and group is not dist.group.WORLD) else src_group_rank
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        tmp = t.detach().cpu()
+        dist.broadcast(tmp, src=src, group=group)
+        t.copy_(tmp)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
 class RowShard:
     """Row sharding of K_hat for solves with few right-hand sides.
 

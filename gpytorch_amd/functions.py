@@ -102,15 +102,17 @@ class InvQuadLogdetFn(torch.autograd.Function):
         c = res.solves_t.shape[0] - t
         g_iq = g_iq.to(xp.dtype).reshape(c, 1)
         g_ld = g_ld.to(xp.dtype).reshape(())
-        world = 1 if ctx.group is None else torch.distributed.get_world_size(ctx.group)
         s_z = res.solves_t[:t] * res.znorm.unsqueeze(-1)
         s_y = res.solves_t[t:]
         zr = res.zt * res.znorm.unsqueeze(-1)
         if res.precond is not None:
             zr = res.precond.apply_(zr, torch.zeros_like(zr))
-        # the replicated y block is weighted 1/world so the all-reduced sum counts it once
-        left = torch.cat([s_z * (g_ld / ctx.t_total), -s_y * (g_iq / world)], dim=0).contiguous()
-        right = torch.cat([zr, s_y], dim=0).contiguous()
+        if res.owns_rhs:
+            left = torch.cat([s_z * (g_ld / ctx.t_total), -s_y * g_iq], dim=0).contiguous()
+            right = torch.cat([zr, s_y], dim=0).contiguous()
+        else:  # sharded: the rhs block is differentiated by its owner only; the all-reduce below adds it once
+            left = (s_z * (g_ld / ctx.t_total)).contiguous()
+            right = zr.contiguous()
         d_x = None
         if ctx.needs_input_grad[0]:
             d_ls, d_os, gx1, gx2 = hyper_grads(xp, xp, lengthscale, outputscale, left, right, want_x1=True, want_x2=True)

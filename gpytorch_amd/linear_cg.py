@@ -25,7 +25,7 @@ from dataclasses import dataclass
 import torch
 
 from . import backend as B
-from .distributed import allreduce_sum_
+from .distributed import allreduce_max_int, allreduce_sum_
 from . import settings
 from ._lib import check, lib
 
@@ -83,13 +83,21 @@ class Preconditioner:
 
     ``q1t``: [k, ld] (rows = columns of Q1), ``sigma2``: 1-element device tensor."""
 
-    def __init__(self, q1t: torch.Tensor, sigma2: torch.Tensor, logdet: torch.Tensor, lt: torch.Tensor):
+    def __init__(self, q1t: torch.Tensor, sigma2: torch.Tensor, logdet: torch.Tensor, lt: torch.Tensor, reduce=None):
         self.q1t, self.sigma2, self.logdet, self.lt = q1t, sigma2, logdet, lt
+        self.reduce = reduce  # row-sharded: in-place sum over ranks of the k x t coefficients R Q1
+
+    def row_sharded(self, row_shard) -> "Preconditioner":
+        """The same preconditioner acting on vectors of which every rank holds a block of rows: Q1 is sliced to the local
+        rows and the k x t inner products R Q1 are all-reduced per apply (k <= 128, t small: a few KB over xGMI)."""
+        return Preconditioner(row_shard.local(self.q1t), self.sigma2, self.logdet, row_shard.local(self.lt), reduce=row_shard.allreduce)
 
     def apply_(self, rt: torch.Tensor, out: torch.Tensor):
         # out = (R - (R Q1) Q1^T) / s2   in probe-major form: rows are vectors
         q1t = self.q1t if self.q1t.dtype == rt.dtype else self.q1t.to(rt.dtype)
         w = rt @ q1t.t()
+        if self.reduce is not None:
+            self.reduce(w)
         torch.addmm(rt, w, q1t, alpha=-1.0, out=out)
         out.div_(self.sigma2.to(rt.dtype))
         return out
@@ -120,13 +128,16 @@ def linear_cg(
     sum is ``K_op @ D``; ``x`` may then be ``None`` and the vector length is taken from ``nvec``.
     ``row_shard`` (:class:`gpytorch_amd.distributed.RowShard`): this rank owns a block of ROWS of the system; ``rhs_t``,
     ``dvec`` and the returned solves are its local slices, products gather the search directions over ranks, and the
-    solver's inner products are all-reduced (float32, no preconditioner).
+    solver's inner products are all-reduced (float32; a full-length ``preconditioner`` is sliced to the local rows and its
+    k x t coefficients are all-reduced per apply).
     Returns (solves_t [t, ld], CGInfo)."""
     B._require_gpu(rhs_t, "rhs")
     L = lib()
     if row_shard is not None:
-        if preconditioner is not None or rhs_t.dtype != torch.float32 or kv_partials is not None:
-            raise NotImplementedError("row-sharded solves: float32, no preconditioner, fused kernel operator")
+        if rhs_t.dtype != torch.float32 or kv_partials is not None:
+            raise NotImplementedError("row-sharded solves: float32, fused kernel operator")
+        if preconditioner is not None and preconditioner.reduce is None:
+            preconditioner = preconditioner.row_sharded(row_shard)
         x, nvec = None, row_shard.n_loc
 
         def kv_partials(dt_, _rs=row_shard):
@@ -194,16 +205,22 @@ def linear_cg(
         if row_shard is not None:
             check(L.gpamd_cg_init_norms_f32(h, B._ptr(rhs_t), rhs_t.stride(0), st), "cg_init_norms")
             ar(0)
-            check(L.gpamd_cg_init_apply_f32(h, B._ptr(rhs_t), rhs_t.stride(0), 1, st), "cg_init_apply")
+            check(L.gpamd_cg_init_apply_f32(h, B._ptr(rhs_t), rhs_t.stride(0), 0 if preconditioner is not None else 1, st), "cg_init_apply")
             ar(2)
-            ar(1)
+            if preconditioner is None:
+                ar(1)
+            else:
+                preconditioner.apply_(Rt, Zt)
+                Dt.copy_(Zt)
+                check(L.gpamd_cg_dot_rz_f32(h, st), "cg_dot_rz")
+                ar(1)
             check(L.gpamd_cg_begin_apply_f32(h, st), "cg_begin_apply")
         else:
             check(F["init"](h, B._ptr(rhs_t), rhs_t.stride(0), 1 if preconditioner is not None else 0, st), "cg_init")
-        if preconditioner is not None:
-            preconditioner.apply_(Rt, Zt)
-            Dt.copy_(Zt)
-            check(F["begin"](h, st), "cg_begin")
+            if preconditioner is not None:
+                preconditioner.apply_(Rt, Zt)
+                Dt.copy_(Zt)
+                check(F["begin"](h, st), "cg_begin")
 
         if kv_partials is None:
             flags = B.kv_flags(x, x, t)
@@ -216,10 +233,13 @@ def linear_cg(
         first_poll = max(min_iter, tri_floor)
         # (row-sharded: the schedule must not depend on the local row count -- a rank that stops polling-late would issue
         # collectives its peers never join)
+        # sharded solves: every rank must leave the loop at the SAME iteration (a rank that polls later would issue collectives
+        # its peers never join), so the polling schedule is built from rank-independent quantities only -- the padded local row
+        # count and the LARGEST column count of any rank.  The stopping statistics themselves are all-reduced on the device
+        # stream (RCCL), so the done flag flips at the same iteration everywhere and nobody needs to poll every iteration.
         n_poll = row_shard.n_pad if row_shard is not None else n
-        poll_every = 1 if float(n_poll) * n_poll * t > 2e11 else 8
-        if group is not None or row_shard is not None:
-            poll_every = 1  # every rank must leave the loop at the same iteration (ranks may hold different column counts)
+        t_poll = allreduce_max_int(t, group) if group is not None else t
+        poll_every = 1 if float(n_poll) * n_poll * t_poll > 2e11 else 8
         flag = 0
         iters = 0
         for k in range(max_iter):
@@ -246,10 +266,17 @@ def linear_cg(
             check(F["update_xr"](h, k, st), "cg_update_xr")
             if row_shard is not None:
                 ar(2)
-                ar(1)
-            if preconditioner is not None:
-                preconditioner.apply_(Rt, Zt)
-            check(F["update_d"](h, k, st), "cg_update_d")
+                if preconditioner is None:
+                    ar(1)
+                else:
+                    preconditioner.apply_(Rt, Zt)
+                    check(L.gpamd_cg_dot_rz_f32(h, st), "cg_dot_rz")
+                    ar(1)
+                check(L.gpamd_cg_update_d_apply_f32(h, k, st), "cg_update_d_apply")
+            else:
+                if preconditioner is not None:
+                    preconditioner.apply_(Rt, Zt)
+                check(F["update_d"](h, k, st), "cg_update_d")
             if group is not None:
                 allreduce_sum_(stats, group)
             check(F["stop"](h, k, min_iter, tri_floor, float(tolerance), st), "cg_stop")

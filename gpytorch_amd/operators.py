@@ -404,7 +404,8 @@ class FusedKernelLinearOperator(LinearOperator):
         return self._prep
 
     def _matmul(self, rhs):
-        x2 = self.x1 if self.square_same_inputs else self.x2
+        # (distinct x2 tensors keep their own identity so that autograd can hand each its gradient)
+        x2 = self.x1 if (self.x2 is self.x1 or (self.square_same_inputs and not self.x2.requires_grad)) else self.x2
         return KernelMatmulFn.apply(self.x1, x2, self.lengthscale, self.outputscale, None, rhs, self.spec)
 
     def _transpose_nonbatch(self):
@@ -424,7 +425,7 @@ class FusedKernelLinearOperator(LinearOperator):
 
     def to_dense(self):
         if torch.is_grad_enabled() and self.requires_grad:
-            x2 = self.x1 if self.square_same_inputs else self.x2
+            x2 = self.x1 if (self.x2 is self.x1 or (self.square_same_inputs and not self.x2.requires_grad)) else self.x2
             return KernelDenseFn.apply(self.x1, x2, self.lengthscale, self.outputscale, self.spec)
         p1, p2 = self.prepared()
         return B.kernel_dense(p1, p2, self._os()).to(self.dtype)
@@ -683,8 +684,9 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         rs = self._row_shard()
         n = self.shape[-1]
         rhs_loc = rs.local(B.to_probe_major(r.detach()))
+        self._preconditioner()  # the reference default has one (max_preconditioner_size = 15): built replicated, applied row-sharded
         sol_loc, info = linear_cg(None, self.kernel_op._os(), self._nz(), rhs_loc, n_tridiag=0, tolerance=settings.cg_tolerance.value(),
-                                  dvec=self._dvec_local(rs), row_shard=rs)
+                                  dvec=self._dvec_local(rs), row_shard=rs, preconditioner=self._cache["precond"])
         self._cache["last_cg_info"] = info
         return B.from_probe_major(rs.gather(sol_loc), n)
 

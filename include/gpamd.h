@@ -122,6 +122,11 @@ int gpamd_cg_partials_layout(int n, int t, int hist_len, int64_t* offs, int* str
 int gpamd_cg_init_norms_f32(gpamd_cg_t* h, const float* B, int64_t ldb, void* stream);
 int gpamd_cg_init_apply_f32(gpamd_cg_t* h, const float* B, int64_t ldb, int copy_d, void* stream);
 int gpamd_cg_begin_apply_f32(gpamd_cg_t* h, void* stream);
+/* preconditioned row-sharded solves: gpamd_cg_begin_f32 / gpamd_cg_update_d_f32 split at the r^T z partial sums --
+ * dot_rz writes the per-workgroup partials of r^T z (layout: gpamd_cg_partials_layout, offs[1]); the host all-reduces them;
+ * begin_apply / update_d_apply consume them. */
+int gpamd_cg_dot_rz_f32(gpamd_cg_t* h, void* stream);
+int gpamd_cg_update_d_apply_f32(gpamd_cg_t* h, int k, void* stream);
 /* Q = scale * sum_s P[s] + (dscale + dvec) .* D, and d.q partials */
 int gpamd_cg_reduce_q_f32(gpamd_cg_t* h, const float* P, int S, int64_t ldp, const float* scale, const float* dscale,
                           const float* dvec, void* stream);

@@ -1,6 +1,6 @@
 """CPU, world_size = 2, gloo: the probe-column sharding design is exact -- two ranks that
-each own half of the probes (+ the replicated y column), exchanging only the 2-float residual
-statistics per iteration and the scalar SLQ sums, reproduce the single-process solve bit for bit:
+each own half of the probes (the y column rides on rank 0 only and its solve is broadcast at the end), exchanging only
+the 2-float residual statistics per iteration and the scalar SLQ sums, reproduce the single-process solve bit for bit:
 same iteration count, same solutions, same log-det.  Exercises gpytorch_amd.distributed (host logic)
 with the oracle standing in for the device kernels (no GPU here)."""
 import os
@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
     mm = OG.make_matmul("rbf", X, 0.25, 1.0, 0.1)
     a, b = D.probe_shard(t_total, world, rank)
     t = b - a
-    rhs = torch.cat([Z[:, a:b], y.unsqueeze(-1)], dim=-1)
+    rhs = torch.cat([Z[:, a:b], y.unsqueeze(-1)], dim=-1) if rank == 0 else Z[:, a:b]   # the rhs owner is rank 0
 
     def mean_fn(rnorm):
         return D.allreduce_residual_stats(rnorm.sum(), torch.tensor(float(rnorm.numel())), group)
@@ -42,6 +42,9 @@ def _worker(rank, world, port, q):
     sol, T, info = OCG.linear_cg(mm, rhs, n_tridiag=t, tolerance=0.5, return_info=True, mean_residual_fn=mean_fn)
     ld = OS.slq_logdet(T, n) * (t / t_total)
     D.allreduce_sum_(ld, group)
+    ysol = sol[:, -1].clone() if rank == 0 else torch.zeros(n, dtype=sol.dtype)
+    D.broadcast_(ysol, 0, group)
+    sol = torch.cat([sol[:, :t], ysol.unsqueeze(-1)], dim=-1)
     q.put((rank, info["iters"], sol.numpy(), float(ld), (a, b)))  # plain data: a tensor would travel as a shm handle that dies with the worker
     dist.barrier()
     dist.destroy_process_group()
@@ -70,8 +73,8 @@ def test_probe_sharding_matches_single_process():
     Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
     Z = Z / Z.norm(dim=-2, keepdim=True)
     mm = OG.make_matmul("rbf", X, 0.25, 1.0, 0.1)
-    # single process: all probes + y replicated `world` times so the global mean matches the sharded one
-    rhs = torch.cat([Z, y.unsqueeze(-1).repeat(1, world)], dim=-1)
+    # single process: all probes + y -- the sharded run averages the residual norms over exactly these columns
+    rhs = torch.cat([Z, y.unsqueeze(-1)], dim=-1)
     sol, T, info = OCG.linear_cg(mm, rhs, n_tridiag=t_total, tolerance=0.5, return_info=True)
     ld = OS.slq_logdet(T, n)
     for rank, iters, s, ldr, (a, b) in results:

@@ -140,8 +140,9 @@ def _rank_worker(rank, world, port, q):
 
 
 def test_two_rank_probe_sharding_on_device(dev):
-    """Two processes share cuda:0 (gloo carries the 2-float / scalar all-reduces): the sharded MLL terms equal
-    the single-process ones computed with all probes and the y column replicated `world` times."""
+    """Two processes share cuda:0 (gloo carries the 2-float / scalar all-reduces and the broadcast of the y solve): the
+    sharded MLL terms equal the single-process ones computed with all probes + y (the y column lives on rank 0 only, so the
+    global mean-residual stopping rule averages over exactly the same t_total + 1 columns)."""
     from gpytorch_amd import backend as B
     from gpytorch_amd.bbmm import inv_quad_logdet_forward
 
@@ -160,10 +161,10 @@ def test_two_rank_probe_sharding_on_device(dev):
     Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
     xp = B.prep_points("rbf", X.float().to(dev), torch.tensor(0.25), X.mean(0).to(dev))
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
-    rhs = B.to_probe_major(y.unsqueeze(-1).repeat(1, world).to(dev))
+    rhs = B.to_probe_major(y.unsqueeze(-1).to(dev))
     ref = inv_quad_logdet_forward(xp, sc, s2, rhs, precond=None, probes=Z, tolerance=1e-3)
     for rank, iters, iq, ld in results:
-        # 8 probes + y per rank run on the small-t kernel, the 18-column reference on the MFMA kernel: different float32
+        # 8 probes (+ y on rank 0) per rank and the 17-column reference run on different kernels: different float32
         # summation orders move the stopping iteration by a few steps (see test_gpu_bbmm); the converged values agree
         assert abs(iters - ref.info.iterations) <= max(2, 0.03 * ref.info.iterations)
         assert abs(iq - float(ref.inv_quad[0])) < 1e-4 * abs(float(ref.inv_quad[0]))
@@ -192,7 +193,7 @@ def _collect(q, procs, world, budget=240.0):
     return sorted(results, key=lambda r: r[0])
 
 
-def _row_worker(rank, world, port, q, fixed_noise):
+def _row_worker(rank, world, port, q, fixed_noise, precond=0):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -201,13 +202,13 @@ def _row_worker(rank, world, port, q, fixed_noise):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
-    mu, var, info = _posterior(g, dev, fixed_noise, dist.group.WORLD)
+    mu, var, info = _posterior(g, dev, fixed_noise, dist.group.WORLD, precond)
     q.put((rank, mu.cpu().numpy(), var.cpu().numpy(), info))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _posterior(g, dev, fixed_noise, row_group):
+def _posterior(g, dev, fixed_noise, row_group, precond=0):
     n, ns, d = 1501, 257, 3  # n not divisible by the world size or by 4: ragged last shard
     X, y = make_data(n, d)
     Xs = torch.rand(ns, d, generator=torch.Generator().manual_seed(9))
@@ -236,7 +237,7 @@ def _posterior(g, dev, fixed_noise, row_group):
     S = g.settings
     torch.manual_seed(77)  # the Lanczos start vector of the LOVE cache comes from the default generator (rank 0's, when sharded)
     with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.fast_pred_var(), S.max_root_decomposition_size(500), \
-            S.max_preconditioner_size(0), S.sharding(row_group=row_group):
+            S.max_preconditioner_size(precond), S.min_preconditioning_size(100), S.sharding(row_group=row_group):
         mu = m(Xs.to(dev)).mean  # mean-cache CG (the most recent solve: LOVE below is Lanczos only)
         from gpytorch_amd import linear_cg as LCG
 
@@ -245,24 +246,25 @@ def _posterior(g, dev, fixed_noise, row_group):
     return mu, var, iters
 
 
-@pytest.mark.parametrize("world,fixed_noise", [(2, False), (3, True)])
-def test_row_sharded_posterior_on_device(world, fixed_noise, dev):
+@pytest.mark.parametrize("world,fixed_noise,precond", [(2, False, 0), (3, True, 0), (2, False, 15)])
+def test_row_sharded_posterior_on_device(world, fixed_noise, precond, dev):
     """the small-t solves of the predictive posterior (mean-cache CG, LOVE Lanczos) with every rank owning
     a block of ROWS of K_hat.  `world` processes share cuda:0 (gloo carries the all-gathers of the search directions and the
     per-iteration all-reduces of the solver's partial sums): same CG iteration count, mean and LOVE variance as the
-    single-process run, on every rank."""
+    single-process run, on every rank.  precond = 15: the reference-default pivoted-Cholesky preconditioner, built replicated and
+    applied row-sharded (its k x t coefficients all-reduced per apply)."""
     import gpytorch_amd as g
 
     port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_row_worker, args=(r, world, port, q, fixed_noise)) for r in range(world)]
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, q, fixed_noise, precond)) for r in range(world)]
     for p in procs:
         p.start()
     results = _collect(q, procs, world)
-    mu, var, iters = _posterior(g, dev, fixed_noise, None)
+    mu, var, iters = _posterior(g, dev, fixed_noise, None, precond)
     mu, var = mu.cpu(), var.cpu()
-    assert iters > 10
+    assert iters > (3 if precond else 10)
     assert float(var.min()) > 1e-4  # the single-process LOVE variances are themselves converged (nothing clipped)
     for rank, mu_r, var_r, it_r in results:
         mu_r, var_r = torch.from_numpy(mu_r), torch.from_numpy(var_r)
