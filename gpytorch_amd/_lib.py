@@ -51,6 +51,13 @@ SIGNATURES = {
     "gpamd_cg_stop_f32": (_i, [_p, _i, _i, _i, _f, _p]),
     "gpamd_cg_finish_f32": (_i, [_p, _p]),
     "gpamd_pivoted_cholesky_f32": (_i, [_i, _p, _i, _i, _p, _i, _f, _p, _i64, _p, _p, _p, _p]),
+    "gpamd_lanczos_num_partials": (_i, [_i]),
+    "gpamd_lanczos_partial_stride": (_i, []),
+    "gpamd_lanczos_residual_f32": (_i, [_p, _p, _p, _p, _i, _p]),
+    "gpamd_lanczos_project_f32": (_i, [_p, _i64, _i, _p, _i, _p, _p]),
+    "gpamd_lanczos_coef_f32": (_i, [_p, _i, _i, _f, _p, _p, _p]),
+    "gpamd_lanczos_subtract_f32": (_i, [_p, _i64, _i, _p, _p, _i, _p, _p]),
+    "gpamd_lanczos_normalize_f32": (_i, [_p, _i, _p, _p, _p, _f, _p, _p]),
     "gpamd_kv_grad_workspace_doubles": (_i64, [_i, _i, _i, _i]),
     # ---- float64 section
     "gpamd_prep_points_f64": (_i, [_i, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),

@@ -1,0 +1,70 @@
+// extern "C" entry points of the Lanczos vector kernels (lanczos_kernels.hpp); see include/gpamd.h.
+#include "../../include/gpamd.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "lanczos_kernels.hpp"
+
+using namespace gpamd;
+namespace gpamd {
+extern thread_local char g_err[512];
+}
+
+namespace {
+int lz_fail(const char* msg) {
+  snprintf(gpamd::g_err, sizeof(gpamd::g_err), "%s", msg);
+  return GPAMD_EINVAL;
+}
+int lz_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(gpamd::g_err, sizeof(gpamd::g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+unsigned lz_blocks(int n) {
+  long nb = ((long)n + 1023) / 1024;
+  if (nb < 1) nb = 1;
+  if (nb > LZ_MAXNB) nb = LZ_MAXNB;
+  return (unsigned)nb;
+}
+}  // namespace
+
+extern "C" {
+
+int gpamd_lanczos_num_partials(int n) { return n > 0 ? (int)lz_blocks(n) : 0; }
+int gpamd_lanczos_partial_stride(void) { return LZ_MAXNB; }
+
+int gpamd_lanczos_residual_f32(const float* w, const float* q_prev, const float* beta_prev, float* r, int n, void* stream) {
+  if (!w || !r || n <= 0) return lz_fail("lanczos_residual: bad arguments");
+  hipLaunchKernelGGL(lz_residual_kernel, dim3(lz_blocks(n)), dim3(256), 0, (hipStream_t)stream, w, q_prev, beta_prev, r, n);
+  return lz_check("lanczos_residual");
+}
+
+int gpamd_lanczos_project_f32(const float* Q, int64_t ldq, int k, const float* r, int n, float* part, void* stream) {
+  if (!Q || !r || !part || n <= 0 || k <= 0 || k > LZ_MAXK || ldq < n || ldq % 4) return lz_fail("lanczos_project: bad arguments (k <= 512, ldq % 4 == 0)");
+  hipLaunchKernelGGL(lz_project_kernel, dim3(lz_blocks(n)), dim3(256), 0, (hipStream_t)stream, Q, ldq, k, r, n, part);
+  return lz_check("lanczos_project");
+}
+
+int gpamd_lanczos_coef_f32(const float* part, int k, int nb, float tol, float* coef, int* flag, void* stream) {
+  if (!part || !coef || k <= 0 || nb <= 0 || nb > LZ_MAXNB || (tol >= 0.f && !flag)) return lz_fail("lanczos_coef: bad arguments");
+  hipLaunchKernelGGL(lz_coef_kernel, dim3(k), dim3(64), 0, (hipStream_t)stream, part, nb, tol, coef, flag);
+  return lz_check("lanczos_coef");
+}
+
+int gpamd_lanczos_subtract_f32(const float* Q, int64_t ldq, int k, const float* coef, float* r, int n, float* part_rr, void* stream) {
+  if (!Q || !r || !coef || !part_rr || n <= 0 || k <= 0 || k > LZ_MAXK || ldq < n || ldq % 4) return lz_fail("lanczos_subtract: bad arguments");
+  hipLaunchKernelGGL(lz_subtract_kernel, dim3(lz_blocks(n)), dim3(256), 0, (hipStream_t)stream, Q, ldq, k, coef, r, n, part_rr);
+  return lz_check("lanczos_subtract");
+}
+
+int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* out, float* norm_out, float tiny, int* stop, void* stream) {
+  if (!r || !rr || !out || n <= 0) return lz_fail("lanczos_normalize: bad arguments");
+  hipLaunchKernelGGL(lz_normalize_kernel, dim3(lz_blocks(n)), dim3(256), 0, (hipStream_t)stream, r, n, rr, out, norm_out, tiny, stop);
+  return lz_check("lanczos_normalize");
+}
+
+}  // extern "C"

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "cg_kernels.hpp"
 #include "kv_grad2.hpp"
@@ -15,7 +16,22 @@ extern thread_local char g_err[512];
 }
 
 namespace {
-constexpr int G2_MAXCOLS = G2_MAXT;  // columns per launch: 33 MFMA k-steps -> 36 padded -> LDS rows of 76 floats (2 workgroups / CU)
+// Columns per launch.  The kernel supports up to G2_MAXT = 66 (33 MFMA k-steps -> 36 padded -> LDS rows of 76 floats: 61 KB,
+// two workgroups per CU).  Default 34: LDS rows of 44 floats (36 KB, four workgroups per CU) -- with twice the resident waves the
+// per-pair VALU work (k, dk/ds, A = W dk/ds) of one wave hides under the MFMA phase of the others, which more than pays for
+// generating the pairs once per 32-column group (measured at n = 500 000, t = 65: see profiles/r02_s5_grad_timing.json).
+// GPAMD_GRAD2_MAXCOLS overrides (tuning only).
+int g2_maxcols() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("GPAMD_GRAD2_MAXCOLS");
+    v = e ? atoi(e) : 34;
+    if (v < 4) v = 4;
+    if (v > G2_MAXT) v = G2_MAXT;
+    v &= ~1;
+  }
+  return v;
+}
 
 int g2_num_cus() {
   static int cus = 0;
@@ -28,9 +44,11 @@ int g2_num_cus() {
   return cus;
 }
 
+// column groups: whole groups of (maxcols - 2), the last one may take up to maxcols (so 65 = 32 + 33, 66 = 32 + 34)
+int g2_take(int rem) { return rem > g2_maxcols() ? g2_maxcols() - 2 : rem; }
 int g2_groups(int t) {
   int g = 0;
-  for (int rem = t; rem > 0; ++g) rem -= rem > G2_MAXCOLS ? 64 : rem;
+  for (int rem = t; rem > 0; ++g) rem -= g2_take(rem);
   return g;
 }
 
@@ -139,7 +157,7 @@ int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int 
   int c0 = 0;
   for (int g = 0; g < groups; ++g) {
     const int rem = t - c0;
-    const int tg = rem > G2_MAXCOLS ? 64 : rem;
+    const int tg = g2_take(rem);
     Grad2Args a;
     a.X1 = X1p; a.X2 = X2p;
     a.Lt = Lt + (int64_t)c0 * ldl;

@@ -1,0 +1,110 @@
+// Lanczos vector kernels (probe-major rows, float32): the O(n k) work of one Lanczos step with full re-orthogonalisation.
+//
+// Replaces the torch GEMV / norm chain of linear_operator.utils.lanczos.lanczos_tridiag (third-party; algorithm restated in
+// oracle/lanczos.py and SURVEY.md A.7; reached from gpytorch/models/exact_prediction_strategies.py:202,234-238,271) by five
+// kernels whose scalars (alpha, beta, the projection coefficients, the "needs another pass" flag) stay on the device:
+//   residual : r = w - beta_prev q_prev
+//   project  : partial sums of  c_m = <Q[m], r>,  m < k      (one pass over the basis; wave-shuffle + LDS reduction)
+//   coef     : c_m = sum of partials (fixed order), flag |= any |c_m| > tol     (all-reduced by the host when row-sharded)
+//   subtract : r -= sum_m c_m Q[m]   and partial sums of |r|^2       (one pass over the basis)
+//   normalize: beta = sqrt(|r|^2), q_next = r / beta, stop |= beta < 1e-6
+// Reductions: float4 loads, wave-shuffle sums, one partial per workgroup, summed in a fixed order -> bitwise reproducible.
+#pragma once
+#include "cg_kernels.hpp"
+
+namespace gpamd {
+
+constexpr int LZ_MAXNB = 128;   // workgroups (partials) per reduction
+constexpr int LZ_MAXK = 512;    // basis vectors per project / subtract launch
+
+__global__ __launch_bounds__(256) void lz_residual_kernel(const float* __restrict__ w, const float* __restrict__ qprev,
+                                                          const float* __restrict__ beta_prev, float* __restrict__ r, int n) {
+  const float b = (qprev && beta_prev) ? *beta_prev : 0.f;
+  for (int64_t i = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x); i < n; i += 4 * (int64_t)gridDim.x * 256) {
+    V4<float> x = ld4(w, i, n);
+    if (qprev) {
+      V4<float> p = ld4(qprev, i, n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x.v[e] -= b * p.v[e];
+    }
+    st4(r, i, n, x);
+  }
+}
+
+// part[m][blockIdx.x] = sum over this block's slice of Q[m][i] * r[i]      (grid.x = nb <= LZ_MAXNB, k <= LZ_MAXK)
+__global__ __launch_bounds__(256) void lz_project_kernel(const float* __restrict__ Q, int64_t ldq, int k, const float* __restrict__ r,
+                                                         int n, float* __restrict__ part) {
+  __shared__ float wsum[4][LZ_MAXK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = 0; m < k; ++m) {
+    const float* q = Q + (int64_t)m * ldq;
+    float acc = 0.f;
+    for (int64_t i = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x); i < n; i += 4 * (int64_t)gridDim.x * 256) {
+      V4<float> x = ld4(q, i, n), y = ld4(r, i, n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc += x.v[e] * y.v[e];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) wsum[wave][m] = acc;
+  }
+  __syncthreads();
+  for (int m = threadIdx.x; m < k; m += 256)
+    part[(int64_t)m * LZ_MAXNB + blockIdx.x] = wsum[0][m] + wsum[1][m] + wsum[2][m] + wsum[3][m];
+}
+
+// coef[m] = sum_b part[m][b]; flag[0] |= any |coef| > tol  (tol < 0: no flag).  One block per coefficient.
+__global__ __launch_bounds__(64) void lz_coef_kernel(const float* __restrict__ part, int nb, float tol, float* __restrict__ coef,
+                                                     int* __restrict__ flag) {
+  const int m = blockIdx.x;
+  float v = 0.f;
+  for (int b = threadIdx.x; b < nb; b += 64) v += part[(int64_t)m * LZ_MAXNB + b];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) {
+    coef[m] = v;
+    if (tol >= 0.f && fabsf(v) > tol) atomicOr(flag, 1);
+  }
+}
+
+// r -= sum_m coef[m] Q[m];  part_rr[blockIdx.x] = this block's share of |r|^2
+__global__ __launch_bounds__(256) void lz_subtract_kernel(const float* __restrict__ Q, int64_t ldq, int k, const float* __restrict__ coef,
+                                                          float* __restrict__ r, int n, float* __restrict__ part_rr) {
+  __shared__ float cs[LZ_MAXK];
+  __shared__ float sm[4];
+  for (int m = threadIdx.x; m < k; m += 256) cs[m] = coef[m];
+  __syncthreads();
+  float acc = 0.f;
+  for (int64_t i = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x); i < n; i += 4 * (int64_t)gridDim.x * 256) {
+    V4<float> x = ld4(r, i, n);
+    for (int m = 0; m < k; ++m) {
+      V4<float> q = ld4(Q + (int64_t)m * ldq, i, n);
+      const float c = cs[m];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x.v[e] -= c * q.v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += x.v[e] * x.v[e];
+    st4(r, i, n, x);
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = acc;
+}
+
+// out = r / sqrt(rr[0]);  norm_out[0] = sqrt(rr[0]);  stop[0] |= norm < tiny       (rr: one finished sum, see lz_coef_kernel)
+__global__ __launch_bounds__(256) void lz_normalize_kernel(const float* __restrict__ r, int n, const float* __restrict__ rr,
+                                                           float* __restrict__ out, float* __restrict__ norm_out, float tiny,
+                                                           int* __restrict__ stop) {
+  const float nrm = sqrtf(fmaxf(*rr, 0.f));
+  const float inv = nrm > 0.f ? 1.f / nrm : 0.f;
+  for (int64_t i = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x); i < n; i += 4 * (int64_t)gridDim.x * 256) {
+    V4<float> x = ld4(r, i, n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x.v[e] *= inv;
+    st4(out, i, n, x);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (norm_out) *norm_out = nrm;
+    if (stop && nrm < tiny) atomicOr(stop, 1);
+  }
+}
+
+}  // namespace gpamd

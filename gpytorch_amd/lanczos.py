@@ -4,8 +4,10 @@ decompositions built on it (LOVE predictive-variance cache).
 Mirrors ``linear_operator.utils.lanczos.lanczos_tridiag`` / ``lanczos_tridiag_to_diag`` and
 ``LinearOperator.root_inv_decomposition`` (third-party; restated in ``oracle/lanczos.py``,
 SURVEY.md A.7).  Reference call sites: ``gpytorch/models/exact_prediction_strategies.py:202,
-234-238,271``.  Each step is one fused K_hat*q (t = 1 -> the VALU kernel: generation-bound) plus
-O(n k) re-orthogonalisation on probe-major rows (rocBLAS GEMV through torch).
+234-238,271``.  Each step is one fused K_hat*q (t = 1: generation-bound) plus O(n k) re-orthogonalisation
+on probe-major rows.  float32 vectors run on the HIP kernels of ``csrc/lanczos_kernels.hpp`` (``gpamd_lanczos_*``:
+wave-shuffle reductions, alpha / beta / projection coefficients resident on the device, ONE host poll per step for the
+re-orthogonalisation / breakdown flags); float64 (generic path) keeps the torch formulation of the same algorithm.
 """
 from __future__ import annotations
 
@@ -17,6 +19,119 @@ from . import settings
 
 def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_t: torch.Tensor | None = None,
                     tol: float = 1e-5, generator=None, dvec=None, matvec=None, nvec=None, device=None, reduce=None, n_global=None):
+    """Dispatch: float32 -> device-resident step kernels (:func:`_lanczos_native`), float64 -> :func:`_lanczos_torch`."""
+    wd = init_vec_t.dtype if init_vec_t is not None else (x.dtype if x is not None else torch.float32)
+    fn = _lanczos_native if (wd == torch.float32 and not FORCE_TORCH and max_iter <= 512) else _lanczos_torch  # (kernels: k <= 512)
+    return fn(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec, matvec, nvec, device, reduce, n_global)
+
+
+FORCE_TORCH = False  # tests: run float32 problems through the torch formulation too
+
+
+def _lanczos_native(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec, matvec, nvec, device, reduce, n_global):
+    """The algorithm of :func:`_lanczos_torch`, vector work on the ``gpamd_lanczos_*`` kernels.  Same return convention."""
+    import ctypes as C
+
+    from ._lib import check, lib
+
+    n = x.n if nvec is None else nvec
+    dev = x.xp.device if device is None else device
+    ld = B.round_up(n, 4)
+    num_iter = min(max_iter, n if n_global is None else n_global)
+    f32 = torch.float32
+    if init_vec_t is None:
+        init_vec_t = torch.zeros(1, ld, device=dev, dtype=f32)
+        init_vec_t[:, :n] = torch.randn(1, n, device=dev, generator=generator, dtype=f32)
+    init_vec_t = init_vec_t.to(f32).contiguous()
+    L, st = lib(), B._stream(dev)
+    nb, stride = int(L.gpamd_lanczos_num_partials(n)), int(L.gpamd_lanczos_partial_stride())
+    Q = torch.zeros(num_iter, ld, device=dev, dtype=f32)
+    alpha = torch.zeros(num_iter, device=dev, dtype=f32)
+    beta = torch.zeros(num_iter, device=dev, dtype=f32)
+    part = torch.empty(max(num_iter, 1) * stride, device=dev, dtype=f32)
+    coef = torch.empty(max(num_iter, 1), device=dev, dtype=f32)
+    rr = torch.empty(1, device=dev, dtype=f32)
+    flags = torch.zeros(2, device=dev, dtype=torch.int32)  # [0]: some |<Q, r>| > tol   [1]: breakdown (beta < 1e-6)
+    r = torch.zeros(1, ld, device=dev, dtype=f32)
+    p = B._ptr
+    flag_ptr = C.c_void_p(flags.data_ptr())
+    stop_ptr = C.c_void_p(flags.data_ptr() + 4)
+
+    def fptr(t_, off=0):
+        return C.c_void_p(t_.data_ptr() + 4 * off)
+
+    def project(basis, k, out, out_off=0, tol_=-1.0):
+        """out[out_off : out_off + k] = <basis[m], r> (global when sharded); tol_ >= 0 raises the re-orthogonalisation flag."""
+        check(L.gpamd_lanczos_project_f32(p(basis), basis.stride(0), k, p(r), n, p(part), st), "lanczos_project")
+        dev_flag = tol_ >= 0 and reduce is None
+        check(L.gpamd_lanczos_coef_f32(p(part), k, nb, tol_ if dev_flag else -1.0, fptr(out, out_off), flag_ptr if dev_flag else None, st), "lanczos_coef")
+        if reduce is not None:
+            reduce(out[out_off : out_off + k])
+            if tol_ >= 0:
+                flags[0] = (out[out_off : out_off + k].abs() > tol_).any().to(torch.int32)
+
+    def subtract(basis, k, cf, cf_off=0):
+        """r -= sum_m cf[m] basis[m];  rr = |r|^2 (global when sharded)."""
+        check(L.gpamd_lanczos_subtract_f32(p(basis), basis.stride(0), k, fptr(cf, cf_off), p(r), n, p(part), st), "lanczos_subtract")
+        check(L.gpamd_lanczos_coef_f32(p(part), 1, nb, -1.0, p(rr), None, st), "lanczos_coef")
+        if reduce is not None:
+            reduce(rr)
+
+    def normalize(src, dst_row, norm_out=None, norm_off=0, watch=False):
+        check(L.gpamd_lanczos_normalize_f32(p(src), n, p(rr), p(dst_row), None if norm_out is None else fptr(norm_out, norm_off),
+                                            1e-6, stop_ptr if watch else None, st), "lanczos_normalize")
+
+    def mv(q_row):
+        if matvec is not None:
+            return matvec(q_row)
+        return B.kv(x, x, q_row, scale=scale, dscale=dscale, vd=q_row if dscale is not None else None, dvec=dvec)
+
+    # q0 = init / |init|
+    r.copy_(init_vec_t[:1])
+    zero = torch.zeros(1, device=dev, dtype=f32)
+    subtract(Q[0:1], 1, zero)                      # r unchanged, rr = |init|^2
+    normalize(r, Q[0])
+    w = mv(Q[0:1])
+    check(L.gpamd_lanczos_residual_f32(p(w), None, None, p(r), n, st), "lanczos_residual")
+    project(Q[0:1], 1, alpha, 0)                   # alpha_0 = <q0, K q0>
+    subtract(Q[0:1], 1, alpha, 0)                  # r -= alpha_0 q0, rr = |r|^2
+    m = 1
+    if num_iter > 1:
+        normalize(r, Q[1], beta, 0)                # beta_0 = |r|, q1 = r / beta_0
+        m = 2
+        for k in range(1, num_iter):
+            w = mv(Q[k : k + 1])
+            check(L.gpamd_lanczos_residual_f32(p(w), p(Q[k - 1]), fptr(beta, k - 1), p(r), n, st), "lanczos_residual")
+            project(Q[k : k + 1], 1, alpha, k)     # alpha_k = <q_k, r>
+            m = k + 1
+            if k + 1 >= num_iter:
+                break
+            subtract(Q[k : k + 1], 1, alpha, k)
+            project(Q, k + 1, coef)                # full re-orthogonalisation against q_0 .. q_k
+            subtract(Q, k + 1, coef)
+            normalize(r, r, beta, k, watch=True)   # beta_k = |r|, r /= beta_k; breakdown flag
+            ok = False
+            for _ in range(10):
+                flags[0:1].zero_()
+                project(Q, k + 1, coef, 0, tol_=tol)
+                need, stop = (int(v) for v in flags.tolist())   # the one host poll of this pass
+                if not need:
+                    ok = True
+                    break
+                subtract(Q, k + 1, coef)
+                normalize(r, r)
+            Q[k + 1].copy_(r[0])
+            if stop or not ok:
+                break
+            m = k + 2
+    a_h, b_h = alpha[:m], beta[: max(m - 1, 0)]
+    T = torch.diag(a_h)
+    if m > 1:
+        T = T + torch.diag(b_h, 1) + torch.diag(b_h, -1)
+    return Q[:m], T
+
+
+def _lanczos_torch(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec, matvec, nvec, device, reduce, n_global):
     """Returns (Qt [m, ld] with orthonormal rows, T [m, m] on device, in the dtype of the prepared points).
 
     ``matvec(q_row [1, ld]) -> [1, ld]``: optional operator override (multitask Kronecker); then ``x`` may be

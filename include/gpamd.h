@@ -147,6 +147,25 @@ int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream);
 int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
                                float* L, int64_t ldl, int64_t* pivots, float* fwork, int* iwork, void* stream);
 
+/* ---- Lanczos tridiagonalisation with full re-orthogonalisation: the vector work of one step (float32 vectors of length n,
+ * basis Q [k][ldq] probe-major).  Replaces the torch GEMV / norm chain of linear_operator.utils.lanczos.lanczos_tridiag
+ * (reached from gpytorch/models/exact_prediction_strategies.py:202,234-238,271); the operator product w = K_hat q is
+ * gpamd_kv_partials_f32 + gpamd_kv_reduce_f32 with t = 1.  All scalars stay on the device; partial sums are
+ * [k][gpamd_lanczos_partial_stride()] floats with gpamd_lanczos_num_partials(n) valid entries per row, finished in a fixed order
+ * by gpamd_lanczos_coef_f32 (row-sharded callers all-reduce `coef` between coef and subtract / normalize).
+ *   residual : r = w - beta_prev[0] * q_prev            (q_prev == NULL: r = w)
+ *   project  : part[m][b] = partial <Q[m], r>, m < k <= 512
+ *   coef     : coef[m] = sum_b part[m][b]; tol >= 0: flag[0] |= (|coef[m]| > tol)
+ *   subtract : r -= sum_m coef[m] Q[m]; part_rr[b] = partial |r|^2       (finish with gpamd_lanczos_coef_f32(part_rr, 1, ...))
+ *   normalize: out = r / sqrt(rr[0]); norm_out[0] = sqrt(rr[0]); stop[0] |= (norm < tiny) ---- */
+int gpamd_lanczos_num_partials(int n);
+int gpamd_lanczos_partial_stride(void);
+int gpamd_lanczos_residual_f32(const float* w, const float* q_prev, const float* beta_prev, float* r, int n, void* stream);
+int gpamd_lanczos_project_f32(const float* Q, int64_t ldq, int k, const float* r, int n, float* part, void* stream);
+int gpamd_lanczos_coef_f32(const float* part, int k, int nb, float tol, float* coef, int* flag, void* stream);
+int gpamd_lanczos_subtract_f32(const float* Q, int64_t ldq, int k, const float* coef, float* r, int n, float* part_rr, void* stream);
+int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* out, float* norm_out, float tiny, int* stop, void* stream);
+
 /* ---- fused bilinear derivative: out[0] = sum_ij W_ij k_ij, out[1+q] = sum_ij W_ij dk/ds_ij (z_iq - z_jq)^2,
  * W = Lt^T Rt (never formed).  Replaces LinearOperator._bilinear_derivative on the kernel operator and the
  * dense backward of gpytorch/functions/rbf_covariance.py:26-29 / matern_covariance.py:53-56 (chunked variant:
