@@ -16,16 +16,15 @@ extern thread_local char g_err[512];
 }
 
 namespace {
-// Columns per launch.  The kernel supports up to G2_MAXT = 66 (33 MFMA k-steps -> 36 padded -> LDS rows of 76 floats: 61 KB,
-// two workgroups per CU).  Default 34: LDS rows of 44 floats (36 KB, four workgroups per CU) -- with twice the resident waves the
-// per-pair VALU work (k, dk/ds, A = W dk/ds) of one wave hides under the MFMA phase of the others, which more than pays for
-// generating the pairs once per 32-column group (measured at n = 500 000, t = 65: see profiles/r02_s5_grad_timing.json).
+// Columns per launch: up to G2_MAXT = 66 (33 MFMA k-steps -> 36 padded -> LDS rows of 76 floats: 61 KB, two workgroups per CU).
+// Smaller groups raise the occupancy (34 columns: 36 KB, four workgroups per CU) but regenerate the pairs once per group, and that
+// loses: measured at n = 500 000, t = 65 (profiles/r02_s5_grad_timing_maxcols{66,34,18}.json) 349 / 396 / 494 ms for 66 / 34 / 18.
 // GPAMD_GRAD2_MAXCOLS overrides (tuning only).
 int g2_maxcols() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("GPAMD_GRAD2_MAXCOLS");
-    v = e ? atoi(e) : 34;
+    v = e ? atoi(e) : G2_MAXT;
     if (v < 4) v = 4;
     if (v > G2_MAXT) v = G2_MAXT;
     v &= ~1;

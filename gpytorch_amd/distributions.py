@@ -45,10 +45,10 @@ class MultivariateNormal:
         """multivariate_normal.py:221-252."""
         mean, covar = self.loc, self.lazy_covariance_matrix
         diff = value - mean
-        if settings.fast_computations.log_prob.off() and not hasattr(covar, "kernel_op"):
+        if settings.fast_computations.log_prob.off() and not hasattr(covar, "kernel_op") and not hasattr(covar, "ops"):
             Lc = torch.linalg.cholesky(covar.to_dense())
             sol = torch.cholesky_solve(diff.unsqueeze(-1), Lc).squeeze(-1)
-            return -0.5 * ((diff * sol).sum(-1) + 2 * Lc.diagonal().log().sum() + diff.size(-1) * math.log(2 * math.pi))
+            return -0.5 * ((diff * sol).sum(-1) + 2 * Lc.diagonal(dim1=-2, dim2=-1).log().sum(-1) + diff.size(-1) * math.log(2 * math.pi))
         covar = covar.evaluate_kernel()
         inv_quad, logdet = covar.inv_quad_logdet(inv_quad_rhs=diff.unsqueeze(-1), logdet=True)
         return -0.5 * sum([inv_quad, logdet, diff.size(-1) * math.log(2 * math.pi)])
@@ -81,10 +81,23 @@ class MultivariateNormal:
         return MultivariateNormal(self.mean + other, self._covar)
 
     def rsample(self, sample_shape=torch.Size(), base_samples=None):
-        covar = self.covariance_matrix
-        Lc = torch.linalg.cholesky(covar + settings.cholesky_jitter.value(covar.dtype) * torch.eye(covar.shape[-1], device=covar.device, dtype=covar.dtype))
+        """mu + R eps with R a root of the covariance (``multivariate_normal.py:254-320``): without ``base_samples`` through
+        ``covar.zero_mean_mvn_samples`` (Cholesky root for small operators, the matrix-free Lanczos root above
+        ``max_cholesky_size`` or under ``settings.fast_pred_samples``); with ``base_samples`` ([*sample_shape, n] or
+        [*sample_shape, rank]) they are pushed through the root, truncated to its rank if it is low-rank."""
+        covar = self.lazy_covariance_matrix
+        sample_shape = torch.Size(sample_shape)
         if base_samples is None:
-            base_samples = torch.randn(*sample_shape, self.loc.shape[-1], device=self.loc.device, dtype=self.loc.dtype)
-        return self.loc + base_samples @ Lc.mT
+            num = sample_shape.numel() or 1
+            res = covar.zero_mean_mvn_samples(num) + self.loc.unsqueeze(0)
+            return res.view(sample_shape + self.loc.shape)
+        root = covar.root_decomposition().root
+        if self.loc.shape != base_samples.shape[-self.loc.dim():] and root.shape[-1] < base_samples.shape[-1]:
+            raise RuntimeError("The size of base_samples (minus sample shape dimensions) should agree with the size of self.loc. "
+                               f"Expected ...{self.loc.shape} but got {base_samples.shape}")
+        sample_shape = base_samples.shape[: base_samples.dim() - self.loc.dim()]
+        eps = base_samples.reshape(-1, base_samples.shape[-1])[:, : root.shape[-1]]      # low-rank root: the first `rank` draws
+        res = eps @ root.mT + self.loc
+        return res.view(sample_shape + self.loc.shape)
 
     sample = rsample

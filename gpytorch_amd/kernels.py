@@ -14,7 +14,7 @@ import torch
 from . import backend as B
 from .functions import KernelSpec
 from .module import Interval, Module, Positive
-from .operators import FusedKernelLinearOperator, LinearOperator
+from .operators import BatchLinearOperator, FusedKernelLinearOperator, LinearOperator
 
 
 class Kernel(Module):
@@ -23,8 +23,6 @@ class Kernel(Module):
     def __init__(self, ard_num_dims=None, batch_shape=torch.Size([]), active_dims=None, lengthscale_prior=None,
                  lengthscale_constraint=None, eps=1e-6, **kwargs):
         super().__init__()
-        if len(batch_shape):
-            raise NotImplementedError("gpytorch_amd fused kernels are non-batched (batch_shape must be empty)")
         self._batch_shape = torch.Size(batch_shape)
         if active_dims is not None and not torch.is_tensor(active_dims):
             active_dims = torch.tensor(active_dims, dtype=torch.long)
@@ -33,7 +31,7 @@ class Kernel(Module):
         self.eps = eps
         if self.has_lengthscale:
             n_ls = 1 if ard_num_dims is None else ard_num_dims
-            self.register_parameter("raw_lengthscale", torch.nn.Parameter(torch.zeros(1, n_ls)))
+            self.register_parameter("raw_lengthscale", torch.nn.Parameter(torch.zeros(*self._batch_shape, 1, n_ls)))
             self.register_constraint("raw_lengthscale", Positive() if lengthscale_constraint is None else lengthscale_constraint)
             if lengthscale_prior is not None:
                 self.register_prior("lengthscale_prior", lengthscale_prior, lambda m: m.lengthscale, lambda m, v: m._set_lengthscale(v))
@@ -63,10 +61,12 @@ class Kernel(Module):
         raise NotImplementedError
 
     def __call__(self, x1, x2=None, diag=False, last_dim_is_batch=False, **params):
-        """``kernel.py:454-534``: select active dims, promote 1-D inputs to [n, 1], default x2 = x1."""
-        if last_dim_is_batch:
-            raise NotImplementedError("last_dim_is_batch is not supported by the fused kernels")
+        """``kernel.py:454-534``: select active dims, promote 1-D inputs to [n, 1], default x2 = x1; leading dimensions of
+        the inputs (and the kernel's ``batch_shape``) are batch dimensions (``kernel.py:163-208``)."""
         x1_, x2_ = x1, x2
+        if last_dim_is_batch:  # kernel.py:506-510: every input dimension becomes its own batch member, [..., d, n, 1]
+            x1_ = x1_.transpose(-1, -2).unsqueeze(-1)
+            x2_ = None if x2_ is None else x2_.transpose(-1, -2).unsqueeze(-1)
         if x1_.dim() == 1:
             x1_ = x1_.unsqueeze(1)
         if x2_ is not None and x2_.dim() == 1:
@@ -75,8 +75,6 @@ class Kernel(Module):
             x1_ = x1_.index_select(-1, self.active_dims)
             if x2_ is not None:
                 x2_ = x2_.index_select(-1, self.active_dims)
-        if x1_.dim() != 2:
-            raise NotImplementedError("gpytorch_amd fused kernels take 2-D inputs [n, d] (no batch dimensions)")
         if x2_ is None:
             x2_ = x1_
         elif x1_.shape[-1] != x2_.shape[-1]:
@@ -103,7 +101,22 @@ class _StationaryFused(Kernel):
 
     def forward(self, x1, x2, diag=False, **params):
         # float32 with d <= 16: fused MFMA / VALU kernels; float64 or d > 16: generic path (backend.kv_chunked)
-        op = FusedKernelLinearOperator(x1, x2, KernelSpec(self.kind, self._shift(x1)), self.lengthscale)
+        ls = self.lengthscale
+        batch = torch.broadcast_shapes(x1.shape[:-2], x2.shape[:-2], ls.shape[:-2])
+        if not batch:
+            op = FusedKernelLinearOperator(x1, x2, KernelSpec(self.kind, self._shift(x1)), ls)
+            return op.diagonal() if diag else op
+        # batch mode: one fused operator per batch member (inputs and lengthscales broadcast against each other)
+        same = x2 is x1
+        x1b = x1.expand(*batch, *x1.shape[-2:]).reshape(-1, *x1.shape[-2:])
+        x2b = x1b if same else x2.expand(*batch, *x2.shape[-2:]).reshape(-1, *x2.shape[-2:])
+        lsb = ls.expand(*batch, *ls.shape[-2:]).reshape(-1, *ls.shape[-2:])
+        ops = []
+        for b in range(x1b.shape[0]):
+            xa = x1b[b]
+            xb = xa if same else x2b[b]
+            ops.append(FusedKernelLinearOperator(xa, xb, KernelSpec(self.kind, self._shift(xa)), lsb[b]))
+        op = BatchLinearOperator(ops, batch)
         return op.diagonal() if diag else op
 
 
@@ -139,7 +152,7 @@ class ScaleKernel(Kernel):
             kwargs["active_dims"] = base_kernel.active_dims
         super().__init__(**kwargs)
         self.base_kernel = base_kernel
-        self.register_parameter("raw_outputscale", torch.nn.Parameter(torch.zeros(())))
+        self.register_parameter("raw_outputscale", torch.nn.Parameter(torch.zeros(self._batch_shape)))
         self.register_constraint("raw_outputscale", Positive() if outputscale_constraint is None else outputscale_constraint)
         if outputscale_prior is not None:
             self.register_prior("outputscale_prior", outputscale_prior, lambda m: m.outputscale, lambda m, v: m._set_outputscale(v))
@@ -167,8 +180,10 @@ class ScaleKernel(Kernel):
         orig = self.base_kernel(x1, x2, diag=diag, **params)
         os_ = self.outputscale
         if diag:
-            return orig * os_
-        return orig.mul(os_.reshape(1)) if isinstance(orig, LinearOperator) else orig * os_
+            return orig * os_.unsqueeze(-1)
+        if isinstance(orig, LinearOperator):  # scale_kernel.py:117-118: outputscale.view(*batch, 1, 1)
+            return orig.mul(os_.reshape(1) if os_.numel() == 1 and not orig.batch_shape else os_)
+        return orig * os_.reshape(*os_.shape, 1, 1)
 
     @property
     def prediction_strategy(self):

@@ -19,9 +19,9 @@ class GPInputWarning(UserWarning):
 
 
 class HomoskedasticNoise(Module):
-    def __init__(self, noise_prior=None, noise_constraint=None):
+    def __init__(self, noise_prior=None, noise_constraint=None, batch_shape=torch.Size()):
         super().__init__()
-        self.register_parameter("raw_noise", torch.nn.Parameter(torch.zeros(1)))
+        self.register_parameter("raw_noise", torch.nn.Parameter(torch.zeros(*batch_shape, 1)))
         self.register_constraint("raw_noise", GreaterThan(1e-4) if noise_constraint is None else noise_constraint)
         if noise_prior is not None:
             self.register_prior("noise_prior", noise_prior, lambda m: m.noise, lambda m, v: m._set_transformed("raw_noise", v))
@@ -62,7 +62,7 @@ class _GaussianLikelihoodBase(Module):
 
 class GaussianLikelihood(_GaussianLikelihoodBase):
     def __init__(self, noise_prior=None, noise_constraint=None, batch_shape=torch.Size(), **kwargs):
-        super().__init__(HomoskedasticNoise(noise_prior=noise_prior, noise_constraint=noise_constraint))
+        super().__init__(HomoskedasticNoise(noise_prior=noise_prior, noise_constraint=noise_constraint, batch_shape=batch_shape))
 
     @property
     def noise(self):

@@ -93,13 +93,19 @@ class Preconditioner:
         return Preconditioner(row_shard.local(self.q1t), self.sigma2, self.logdet, row_shard.local(self.lt), reduce=row_shard.allreduce)
 
     def apply_(self, rt: torch.Tensor, out: torch.Tensor):
-        # out = (R - (R Q1) Q1^T) / s2   in probe-major form: rows are vectors
-        q1t = self.q1t if self.q1t.dtype == rt.dtype else self.q1t.to(rt.dtype)
-        w = rt @ q1t.t()
+        """out = (R - (R Q1) Q1^T) / s2 in probe-major form (rows are vectors), evaluated in FLOAT64 whatever the dtype of the
+        solve.  I - Q1 Q1^T has eigenvalues s2 / (s2 + lambda): for a smooth kernel (RBF, d = 3, n = 5e5: lambda / s2 ~ 1e6) the
+        leading components of R must cancel to 6 digits, which float32 cannot deliver -- the float32 apply made preconditioned CG
+        stall at a relative residual of 4 after 2000 iterations (profiles/r02_s5_posterior_profile_precond_fp32_stalls.json).
+        Cost: two [t, n] x [n, k] float64 GEMMs per CG iteration, < 1 ms against a >= 19 ms K*V at that size."""
+        q1t = self.q1t if self.q1t.dtype == torch.float64 else self.q1t.to(torch.float64)
+        r64 = rt.to(torch.float64)
+        w = r64 @ q1t.t()
         if self.reduce is not None:
             self.reduce(w)
-        torch.addmm(rt, w, q1t, alpha=-1.0, out=out)
-        out.div_(self.sigma2.to(rt.dtype))
+        z = torch.addmm(r64, w, q1t, alpha=-1.0)
+        z.div_(self.sigma2.to(torch.float64))
+        out.copy_(z)
         return out
 
 

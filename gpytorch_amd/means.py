@@ -20,9 +20,10 @@ class ZeroMean(Mean):
 
 
 class ConstantMean(Mean):
-    def __init__(self, constant_prior=None, constant_constraint=None):
+    def __init__(self, constant_prior=None, constant_constraint=None, batch_shape=torch.Size()):
         super().__init__()
-        self.register_parameter("raw_constant", torch.nn.Parameter(torch.zeros(())))
+        self.batch_shape = torch.Size(batch_shape)
+        self.register_parameter("raw_constant", torch.nn.Parameter(torch.zeros(self.batch_shape)))
         if constant_constraint is not None:
             self.register_constraint("raw_constant", constant_constraint)
         if constant_prior is not None:
@@ -37,4 +38,5 @@ class ConstantMean(Mean):
         self._set_transformed("raw_constant", value)
 
     def forward(self, x):
-        return self.constant.unsqueeze(-1).expand(x.shape[:-1])  # constant_mean.py:111-113
+        c = self.constant.unsqueeze(-1)  # constant_mean.py:111-113
+        return c.expand(*torch.broadcast_shapes(c.shape[:-1], x.shape[:-2]), x.shape[-2])

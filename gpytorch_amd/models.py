@@ -100,9 +100,14 @@ class DefaultPredictionStrategy:
             if settings.detach_test_caches.on():
                 train_train_covar = train_train_covar.detach()
             ttc = to_dense(test_train_covar)
-            rhs = train_train_covar.solve(ttc.mT.contiguous())
+            rhs_in = ttc.mT.contiguous()
+            if rhs_in.dim() > 2 and not train_train_covar.batch_shape:  # batch of test sets against one training set
+                from .operators import BatchLinearOperator
+
+                train_train_covar = BatchLinearOperator.replicate(train_train_covar, rhs_in.shape[:-2])
+            rhs = train_train_covar.solve(rhs_in)
             if torch.is_tensor(test_test_covar):
-                return to_linear_operator(torch.addmm(test_test_covar, ttc, rhs, beta=1, alpha=-1))
+                return to_linear_operator(test_test_covar - ttc @ rhs)
             return test_test_covar + MatmulLinearOperator(DenseLinearOperator(ttc), DenseLinearOperator(rhs.mul(-1)))
         root = to_linear_operator(test_train_covar) @ self.covar_cache  # [n_test, m]
         if torch.is_tensor(test_test_covar):
@@ -190,8 +195,9 @@ class ExactGP(GP):
         conditioned on the training data PLUS (inputs, targets), without re-solving the n x n system.  With
         B = K_hat^-1 k (one mBCG solve with m right-hand sides -- the MFMA path), S = k_hat_new - k^T B (m x m, dense
         Cholesky), alpha = the current mean cache and e = (targets - mean_new) - k^T alpha, the new mean cache is
-        [alpha - B S^-1 e ; S^-1 e].  The LOVE covariance cache is rebuilt on first use (the reference updates its
-        root with a QR of the appended block).  Hyper-parameters are shared with this model, as in the reference."""
+        [alpha - B S^-1 e ; S^-1 e].  An existing LOVE covariance cache (root R of K_hat^-1) is UPDATED, not rebuilt: the
+        bordered inverse gives the root [[R, -B L_s^-T], [0, L_s^-T]] (the reference: ``cat_rows`` + ``root_inv_decomposition``).
+        Hyper-parameters are shared with this model, as in the reference."""
         import copy
 
         if self.prediction_strategy is None:
@@ -221,23 +227,39 @@ class ExactGP(GP):
             Ls = torch.linalg.cholesky(0.5 * (S + S.mT))
             w = torch.cholesky_solve(e.unsqueeze(-1), Ls).squeeze(-1).to(alpha.dtype)      # S^-1 e
             new_cache = torch.cat([alpha - Bm @ w, w], dim=-1)
+            # LOVE cache (exact_prediction_strategies.py:233-238: cat_rows + root_inv_decomposition): with R R^T ~= K_hat^-1 and the
+            # bordered inverse  [K_hat k; k^T k_new]^-1 = [R;0][R;0]^T + [-B; I] S^-1 [-B; I]^T,  S = L_s L_s^T,  a root of the new
+            # inverse is  [[R, -B L_s^-T], [0, L_s^-T]]  -- m extra columns, no new Lanczos run
+            new_covar_cache = None
+            if ps._covar_cache is not None:
+                R = ps._covar_cache                                                          # [n, r]
+                lsinv_t = torch.linalg.solve_triangular(Ls, torch.eye(m, device=Ls.device, dtype=Ls.dtype), upper=False).mT.to(R.dtype)
+                top = torch.cat([R, -(Bm.to(R.dtype) @ lsinv_t)], dim=-1)
+                bot = torch.cat([torch.zeros(m, R.shape[-1], device=R.device, dtype=R.dtype), lsinv_t], dim=-1)
+                new_covar_cache = torch.cat([top, bot], dim=-2)
         new_model = copy.copy(self)                 # shares parameters / modules (exact_gp.py:244-263 deep-copies only the caches)
         new_model.train_inputs = tuple(full_inputs)
         new_model.train_targets = full_targets
         new_model.prediction_strategy = prediction_strategy(full_inputs, full_output, full_targets, self.likelihood)
         new_model.prediction_strategy._mean_cache = new_cache.detach()
+        if new_covar_cache is not None:
+            new_model.prediction_strategy._covar_cache = new_covar_cache.detach()
         return new_model
 
     def _get_test_prior_mean_and_covariances(self, train_inputs, inputs, **kwargs):
-        """exact_gp.py:355-430: joint train u test prior, sliced lazily."""
-        full_inputs = [torch.cat([ti, inp], dim=-2) for ti, inp in zip(train_inputs, inputs)]
+        """exact_gp.py:355-430: joint train u test prior, sliced lazily.  Batch dimensions of the training and the test
+        inputs are broadcast against each other first (exact_gp.py:303-313)."""
+        full_inputs = []
+        for ti, inp in zip(train_inputs, inputs):
+            batch = torch.broadcast_shapes(ti.shape[:-2], inp.shape[:-2])
+            full_inputs.append(torch.cat([ti.expand(*batch, *ti.shape[-2:]), inp.expand(*batch, *inp.shape[-2:])], dim=-2))
         full_output = Module.__call__(self, *full_inputs, **kwargs)
         full_mean, full_covar = full_output.loc, full_output.lazy_covariance_matrix
         self._posterior_class = (full_output.__class__, tuple(full_output.event_shape[1:]))
         n = self.prediction_strategy.num_train
         test_mean = full_mean[..., n:]
-        test_test_covar = full_covar[n:, n:].evaluate_kernel()
-        test_train_covar = full_covar[n:, :n].evaluate_kernel()
+        test_test_covar = full_covar[..., n:, n:].evaluate_kernel()
+        test_train_covar = full_covar[..., n:, :n].evaluate_kernel()
         return test_mean, test_test_covar, test_train_covar
 
 

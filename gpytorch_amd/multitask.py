@@ -86,6 +86,8 @@ class KroneckerFusedLinearOperator(LinearOperator):
         return torch.kron(self.kx.to_dense(), self.ktt.to(self.dtype))
 
     def __getitem__(self, index):
+        if isinstance(index, tuple) and len(index) == 3 and index[0] is Ellipsis:
+            index = index[1:]
         r, c = index if isinstance(index, tuple) else (index, slice(None))
         T = self.T
 

@@ -115,7 +115,7 @@ class LinearOperator:
         return DenseLinearOperator(self.to_dense() * c.reshape(()))
 
     def __getitem__(self, index):
-        return DenseLinearOperator(self.to_dense()[index])
+        return DenseLinearOperator(self.to_dense()[_strip_ellipsis(index)])
 
     def detach(self):
         return self
@@ -164,8 +164,41 @@ class LinearOperator:
     def logdet(self):
         return self.inv_quad_logdet(None, True)[1]
 
-    def root_decomposition(self):
-        return RootLinearOperator(self.cholesky().to(self.dtype))
+    def root_decomposition(self, method=None):
+        """``LinearOperator.root_decomposition``: R with R R^T ~= self.  "cholesky" for small operators, "lanczos" (rank
+        ``max_root_decomposition_size``, through this operator's own matrix-free product) above ``max_cholesky_size`` or when
+        ``settings.fast_pred_samples`` asks for the low-rank LOVE-style root."""
+        n = self.shape[-1]
+        if method is None:
+            big = n > settings.max_cholesky_size.value() or settings.fast_pred_samples.on()
+            method = "lanczos" if (big and self.device is not None and torch.device(self.device).type == "cuda") else "cholesky"
+        if method == "cholesky":
+            K = self.to_dense().to(torch.float64)
+            jitter = settings.cholesky_jitter.value(self.dtype)
+            eye = torch.eye(n, device=K.device, dtype=K.dtype)
+            for k in range(4):  # psd_safe_cholesky: growing jitter
+                Lc, info = torch.linalg.cholesky_ex(K + (jitter * 10**k if k else 0.0) * eye)
+                if not bool(info.any()):
+                    break
+            return RootLinearOperator(Lc.to(self.dtype))
+        from .lanczos import lanczos_tridiag, tridiag_to_diag
+
+        def matvec(q_row):  # probe-major [1, ld] -> [1, ld]
+            out = self._matmul(q_row[:, :n].t().to(self.dtype))
+            res = torch.zeros_like(q_row)
+            res[:, :n] = out.t().to(q_row.dtype)
+            return res
+
+        Q, T = lanczos_tridiag(None, None, None, settings.max_root_decomposition_size.value(), matvec=matvec, nvec=n, device=self.device)
+        evals, evecs = tridiag_to_diag(T)
+        w = (evecs * evals.clamp_min(0).sqrt().unsqueeze(-2)).to(device=Q.device, dtype=Q.dtype)      # V Lambda^1/2
+        return RootLinearOperator((w.t() @ Q)[:, :n].t().contiguous().to(self.dtype))
+
+    def zero_mean_mvn_samples(self, num_samples: int) -> torch.Tensor:
+        """``LinearOperator.zero_mean_mvn_samples``: [num_samples, n] draws of N(0, self) through a root decomposition."""
+        root = self.root_decomposition().root
+        eps = torch.randn(root.shape[-1], num_samples, device=root.device, dtype=root.dtype)
+        return (root @ eps).t()
 
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
         Lc = self.cholesky()
@@ -239,12 +272,16 @@ class DiagLinearOperator(LinearOperator):
     def __init__(self, diag: torch.Tensor):
         self._diag = diag
 
+    @property
+    def batch_shape(self):
+        return self._diag.shape[:-1]
+
     dtype = property(lambda self: self._diag.dtype)
     device = property(lambda self: self._diag.device)
 
     def _size(self):
         n = self._diag.shape[-1]
-        return torch.Size([n, n])
+        return torch.Size([*self._diag.shape[:-1], n, n])
 
     def _matmul(self, rhs):
         return self._diag.unsqueeze(-1) * rhs
@@ -256,7 +293,7 @@ class DiagLinearOperator(LinearOperator):
         return self._diag
 
     def to_dense(self):
-        return torch.diag(self._diag)
+        return torch.diag_embed(self._diag)
 
     def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
         iq = None
@@ -277,7 +314,11 @@ class ConstantDiagLinearOperator(DiagLinearOperator):
 
     @property
     def _diag(self):
-        return self.diag_values.expand(self.diag_shape)
+        return self.diag_values.expand(*self.diag_values.shape[:-1], self.diag_shape)
+
+    @property
+    def batch_shape(self):
+        return self.diag_values.shape[:-1]
 
 
 class RootLinearOperator(LinearOperator):
@@ -412,6 +453,8 @@ class FusedKernelLinearOperator(LinearOperator):
         return FusedKernelLinearOperator(self.x2, self.x1, self.spec, self.lengthscale, self.outputscale)
 
     def _mul_constant(self, c):
+        if c.numel() > 1:  # batch of output scales over one kernel matrix
+            return BatchLinearOperator.replicate(self, c.shape if c.dim() > 0 else torch.Size([]))._mul_constant(c)
         os_ = c if self.outputscale is None else self.outputscale.reshape(()) * c.reshape(())
         return FusedKernelLinearOperator(self.x1, self.x2, self.spec, self.lengthscale, os_.reshape(1))
 
@@ -431,6 +474,7 @@ class FusedKernelLinearOperator(LinearOperator):
         return B.kernel_dense(p1, p2, self._os()).to(self.dtype)
 
     def __getitem__(self, index):
+        index = _strip_ellipsis(index)
         if not isinstance(index, tuple):
             index = (index, slice(None))
         r, c = index
@@ -445,6 +489,8 @@ class FusedKernelLinearOperator(LinearOperator):
         return B.kernel_rows(p1, idx, p2, self._os())
 
     def __add__(self, other):
+        if isinstance(other, DiagLinearOperator) and other.batch_shape:
+            return BatchLinearOperator.replicate(self, other.batch_shape) + other
         if isinstance(other, ConstantDiagLinearOperator) and self.is_square:
             return FusedKernelAddedDiagLinearOperator(self, other.diag_values)
         if isinstance(other, DiagLinearOperator) and self.is_square:
@@ -485,6 +531,13 @@ class FusedKernelLinearOperator(LinearOperator):
         Lt, piv, m = B.pivoted_cholesky(p1, self._os(), rank, tol)
         L = Lt.t().contiguous().to(self.dtype)
         return (L, piv) if return_pivots else L
+
+
+def _strip_ellipsis(index):
+    """``op[..., r, c]`` on a non-batch operator is ``op[r, c]``."""
+    if isinstance(index, tuple) and len(index) > 0 and index[0] is Ellipsis:
+        return index[1:] if len(index) > 2 else (index[1] if len(index) == 2 else slice(None))
+    return index
 
 
 def _same_index(r, c):
@@ -723,3 +776,202 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
 
     def pivoted_cholesky(self, rank, error_tol=None, return_pivots=False):
         raise NotImplementedError("pivoted_cholesky is defined on the noise-free kernel operator (self.kernel_op)")
+
+
+# =================================================================================================
+class BatchLinearOperator(LinearOperator):
+    """A batch of independent operators (leading ``batch_shape`` dimensions; the reference's batch mode,
+    ``kernels/kernel.py:163-208`` ``batch_shape`` and ``test/examples/test_batch_gp_regression.py``).
+
+    The fused kernels work on one point cloud at a time; a batch is a launch plan over its members: every method maps over
+    ``self.ops`` (row-major over ``batch_shape``) and stacks.  Members of a batch GP are each as large as a single GP, so every
+    launch still fills the chip; hyper-parameters with batch shape are sliced per member and autograd scatters the gradients
+    back into the batched parameter."""
+
+    def __init__(self, ops, batch_shape):
+        self.ops = list(ops)
+        self._batch_shape = torch.Size(batch_shape)
+        assert len(self.ops) == max(1, self._batch_shape.numel())
+
+    @classmethod
+    def replicate(cls, op, batch_shape):
+        batch_shape = torch.Size(batch_shape)
+        return cls([op] * max(1, batch_shape.numel()), batch_shape)
+
+    dtype = property(lambda self: self.ops[0].dtype)
+    device = property(lambda self: self.ops[0].device)
+
+    @property
+    def batch_shape(self):
+        return self._batch_shape
+
+    def _size(self):
+        return torch.Size([*self._batch_shape, *self.ops[0].shape[-2:]])
+
+    @property
+    def requires_grad(self):
+        return any(o.requires_grad for o in self.ops)
+
+    # ---- helpers
+    def _map(self, fn):
+        return BatchLinearOperator([fn(o) for o in self.ops], self._batch_shape)
+
+    def _stack(self, outs):
+        out = torch.stack(list(outs), dim=0)
+        return out.reshape(*self._batch_shape, *out.shape[1:])
+
+    def _split(self, t: torch.Tensor, event_dims: int):
+        """Broadcast ``t`` ([..., *event]) against the batch shape and return one slice per member."""
+        ev = t.shape[t.dim() - event_dims :]
+        tb = t.expand(*self._batch_shape, *ev) if t.shape[: t.dim() - event_dims] != self._batch_shape else t
+        return list(tb.reshape(-1, *ev).unbind(0)) if self._batch_shape else [tb]
+
+    def expand_batch(self, batch_shape):
+        """The same members seen under a larger (broadcast) batch shape."""
+        batch_shape = torch.Size(batch_shape)
+        if batch_shape == self._batch_shape:
+            return self
+        idx = torch.arange(max(1, self._batch_shape.numel())).reshape(self._batch_shape if self._batch_shape else (1,))
+        if not self._batch_shape:
+            idx = idx.reshape(())
+        idx = idx.expand(batch_shape).reshape(-1).tolist()
+        return BatchLinearOperator([self.ops[i] for i in idx], batch_shape)
+
+    # ---- protocol
+    def _matmul(self, rhs):
+        extra = torch.broadcast_shapes(rhs.shape[:-2], self._batch_shape)
+        me = self.expand_batch(extra)
+        return me._stack(o._matmul(r) for o, r in zip(me.ops, me._split(rhs, 2)))
+
+    def matmul(self, rhs):
+        if isinstance(rhs, LinearOperator):
+            return MatmulLinearOperator(self, rhs)
+        if rhs.dim() == 1:
+            return self._matmul(rhs.unsqueeze(-1)).squeeze(-1)
+        return self._matmul(rhs)
+
+    __matmul__ = matmul
+
+    def _transpose_nonbatch(self):
+        return self._map(lambda o: o._transpose_nonbatch())
+
+    def evaluate_kernel(self):
+        return self._map(lambda o: o.evaluate_kernel())
+
+    def detach(self):
+        return self._map(lambda o: o.detach())
+
+    def to_dense(self):
+        return self._stack(o.to_dense() for o in self.ops)
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return self._stack(o.diagonal() for o in self.ops)
+
+    def _mul_constant(self, c):
+        return BatchLinearOperator([o._mul_constant(ci.reshape(1)) for o, ci in zip(self.ops, self._split(c.reshape(*c.shape, 1) if c.dim() == len(self._batch_shape) else c, 1))],
+                                   self._batch_shape)
+
+    def mul(self, other):
+        if isinstance(other, (int, float)):
+            return self._map(lambda o: o.mul(other))
+        other = torch.as_tensor(other)
+        if other.dim() >= 2 and other.shape[-2:] == (1, 1):
+            other = other.reshape(other.shape[:-2])
+        bs = torch.broadcast_shapes(other.shape, self._batch_shape)
+        me = self.expand_batch(bs)
+        return BatchLinearOperator([o._mul_constant(ci.reshape(1)) for o, ci in zip(me.ops, other.expand(bs).reshape(-1).unbind(0))], bs)
+
+    __mul__ = mul
+
+    def __add__(self, other):
+        if isinstance(other, ZeroLinearOperator):
+            return self
+        if isinstance(other, ConstantDiagLinearOperator):
+            bs = torch.broadcast_shapes(other.batch_shape, self._batch_shape)
+            me = self.expand_batch(bs)
+            vals = other.diag_values.expand(*bs, 1).reshape(-1, 1).unbind(0) if bs else [other.diag_values]
+            return BatchLinearOperator([o + ConstantDiagLinearOperator(v, other.diag_shape) for o, v in zip(me.ops, vals)], bs)
+        if isinstance(other, DiagLinearOperator):
+            bs = torch.broadcast_shapes(other.batch_shape, self._batch_shape)
+            me = self.expand_batch(bs)
+            return BatchLinearOperator([o + DiagLinearOperator(v) for o, v in zip(me.ops, me._split(other._diag, 1))], bs)
+        if isinstance(other, BatchLinearOperator):
+            bs = torch.broadcast_shapes(other.batch_shape, self._batch_shape)
+            a, b = self.expand_batch(bs), other.expand_batch(bs)
+            return BatchLinearOperator([x + y for x, y in zip(a.ops, b.ops)], bs)
+        if isinstance(other, torch.Tensor):
+            return BatchLinearOperator([o + v for o, v in zip(self.ops, self._split(other, 2))], self._batch_shape)
+        return super().__add__(other)
+
+    def add_jitter(self, jitter_val=1e-3):
+        return self._map(lambda o: o.add_jitter(jitter_val))
+
+    def __getitem__(self, index):
+        """``op[..., rows, cols]`` slices every member; a leading integer / slice (without Ellipsis) indexes the batch."""
+        if isinstance(index, tuple) and len(index) > 0 and index[0] is Ellipsis:
+            inner = _strip_ellipsis(index)
+            return self._map(lambda o: o[inner])
+        if not isinstance(index, tuple):
+            index = (index,)
+        nb = len(self._batch_shape)
+        if len(index) == nb + 2:
+            batch_idx, inner = index[:nb], index[nb:]
+        else:
+            batch_idx, inner = index, None
+        ids = torch.arange(len(self.ops)).reshape(self._batch_shape)[batch_idx]
+        pick = [self.ops[i] for i in ids.reshape(-1).tolist()]
+        pick = [o[inner] for o in pick] if inner is not None else pick
+        if ids.dim() == 0:
+            return pick[0]
+        return BatchLinearOperator(pick, ids.shape)
+
+    def sum(self, dim=None):
+        if dim is None:
+            return self._stack(o.sum() for o in self.ops).sum()
+        return self._stack(o.sum(dim) for o in self.ops)
+
+    # ---- BBMM entry points: per member, stacked
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        rs = [None] * len(self.ops) if inv_quad_rhs is None else self._split(inv_quad_rhs if inv_quad_rhs.dim() > len(self._batch_shape) + 1
+                                                                              else inv_quad_rhs.unsqueeze(-1), 2)
+        res = [o.inv_quad_logdet(r, logdet, reduce_inv_quad) for o, r in zip(self.ops, rs)]
+        iq = None if inv_quad_rhs is None else self._stack(r[0] for r in res)
+        ld = self._stack(r[1] for r in res) if logdet else None
+        return iq, ld
+
+    def inv_quad(self, inv_quad_rhs, reduce_inv_quad=True):
+        return self.inv_quad_logdet(inv_quad_rhs, False, reduce_inv_quad)[0]
+
+    def logdet(self):
+        return self.inv_quad_logdet(None, True)[1]
+
+    def solve(self, rhs, lhs=None):
+        squeeze = rhs.dim() == len(self._batch_shape) + 1 or rhs.dim() == 1
+        r = rhs.unsqueeze(-1) if squeeze else rhs
+        extra = torch.broadcast_shapes(r.shape[:-2], self._batch_shape)
+        me = self.expand_batch(extra)
+        sol = me._stack(o.solve(ri) for o, ri in zip(me.ops, me._split(r, 2)))
+        if lhs is not None:
+            sol = lhs @ sol
+        return sol.squeeze(-1) if squeeze else sol
+
+    def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
+        return self._map(lambda o: o.root_inv_decomposition(method=method))
+
+    def root_decomposition(self):
+        return self._map(lambda o: o.root_decomposition())
+
+    @property
+    def root(self):
+        """Stacked roots of a batch of RootLinearOperators (ranks padded with zero columns to the largest)."""
+        roots = [o.root for o in self.ops]
+        k = max(r.shape[-1] for r in roots)
+        roots = [torch.nn.functional.pad(r, (0, k - r.shape[-1])) for r in roots]
+        return self._stack(roots)
+
+    def pivoted_cholesky(self, rank, error_tol=None, return_pivots=False):
+        outs = [o.pivoted_cholesky(rank, error_tol, return_pivots) for o in self.ops]
+        if return_pivots:
+            return self._stack(o[0] for o in outs), self._stack(o[1] for o in outs)
+        k = max(o.shape[-1] for o in outs)
+        return self._stack(torch.nn.functional.pad(o, (0, k - o.shape[-1])) for o in outs)

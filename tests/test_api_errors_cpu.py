@@ -46,8 +46,8 @@ def test_kernel_and_likelihood_argument_errors():
     k = g.kernels.RBFKernel(ard_num_dims=3)
     with pytest.raises(RuntimeError, match="Expected the input to have 3 dimensionality"):
         k(torch.zeros(4, 2))
-    with pytest.raises(NotImplementedError):
-        g.kernels.RBFKernel(batch_shape=torch.Size([2]))
+    assert g.kernels.RBFKernel(batch_shape=torch.Size([2])).raw_lengthscale.shape == (2, 1, 1)   # kernel.py:163-208
+    assert g.kernels.ScaleKernel(g.kernels.RBFKernel(), batch_shape=torch.Size([3])).raw_outputscale.shape == (3,)
     with pytest.raises(RuntimeError, match="larger than the number of tasks"):
         g.kernels.IndexKernel(num_tasks=2, rank=3)
     with pytest.raises(RuntimeError, match="expects a MultivariateNormal"):

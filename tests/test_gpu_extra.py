@@ -449,3 +449,58 @@ def test_fantasy_model_matches_retrained_posterior(dev):
     mu_ref, _ = OG.dense_posterior("rbf", torch.cat([Xt, Xf]), torch.cat([yt, yf]), Xs, 0.3, 1.2, 0.05, mean=0.1)
     assert rel_err(mu_f, mu_full) < 1e-3
     assert rel_err(mu_f, mu_ref) < 1e-3
+
+
+def test_fantasy_model_updates_love_cache_and_sampling(dev):
+    """SURVEY.md 8f rank 2, remainder: (i) ``get_fantasy_model`` UPDATES an existing LOVE covariance cache through the bordered
+    inverse (exact_prediction_strategies.py:137-265) -- the fantasy model's ``fast_pred_var`` variances equal the dense
+    float64 posterior variances of the enlarged data set within the reference's own LOVE tolerance (5 %,
+    test_simple_gp_regression.py:396-442); (ii) ``MultivariateNormal.rsample`` (multivariate_normal.py:254-320) through the
+    matrix-free Lanczos root of the predictive covariance (``fast_pred_samples``, settings.py:225-243): sample mean / variance
+    match the predictive mean / variance."""
+    import gpytorch_amd as g
+
+    n, m, ns, d = 900, 30, 150, 2
+    X, y = make_data(n + m + ns, d, seed=12)
+    Xt, yt, Xf, yf, Xs = X[:n], y[:n], X[n : n + m], y[n : n + m], X[n + m :]
+
+    class GPModel(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ConstantMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel())
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood()
+    mdl = GPModel(Xt.float().to(dev), yt.float().to(dev), lik).to(dev)
+    mdl.covar_module.base_kernel.lengthscale = 0.3
+    mdl.covar_module.outputscale = 1.2
+    lik.noise = 0.3
+    mdl.eval()
+    lik.eval()
+    S = g.settings
+    torch.manual_seed(5)
+    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-5), S.fast_pred_var(), S.max_root_decomposition_size(400):
+        _ = mdl(Xs.float().to(dev)).variance                      # builds mean + LOVE caches
+        r_old = mdl.prediction_strategy._covar_cache
+        assert r_old is not None
+        fant = mdl.get_fantasy_model(Xf.float().to(dev), yf.float().to(dev))
+        r_new = fant.prediction_strategy._covar_cache
+        assert r_new is not None and r_new.shape == (n + m, r_old.shape[-1] + m)   # updated, not rebuilt
+        pred = fant(Xs.float().to(dev))
+        mu_f, var_f = pred.mean, pred.variance
+    mu_ref, var_ref = OG.dense_posterior("rbf", torch.cat([Xt, Xf]), torch.cat([yt, yf]), Xs, 0.3, 1.2, 0.3, mean=0.0, noise=False)
+    assert rel_err(mu_f, mu_ref) < 1e-3
+    assert float(((var_f.double().cpu() - var_ref).abs() / var_ref).max()) < 0.05
+    # (ii) sampling from the predictive distribution of the original model
+    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-5), S.fast_pred_samples(), S.max_root_decomposition_size(150):
+        pred = mdl(Xs.float().to(dev))
+        torch.manual_seed(0)
+        smp = pred.rsample(torch.Size([4000]))
+        assert smp.shape == (4000, ns)
+        mu, var = pred.mean, pred.variance
+    assert float((smp.mean(0) - mu).abs().max()) < 0.06 * float(var.max().sqrt()) + 0.02
+    rel_var = (smp.var(0) - var).abs() / var
+    assert float(rel_var.mean()) < 0.06 and float(rel_var.max()) < 0.25
