@@ -1,0 +1,318 @@
+"""Sums of fused kernel operators: ``AdditiveKernel`` (``gpytorch/kernels/kernel.py:592-632``) on the matrix-free path.
+
+``K = sum_i theta_i k_i(x, x)`` stays a list of :class:`~gpytorch_amd.operators.FusedKernelLinearOperator` members; products,
+mBCG solves, SLQ log-determinants and Lanczos decompositions use the members' fused K*V launches summed per product (the
+``kv_partials`` hook of :func:`gpytorch_amd.linear_cg.linear_cg`), and the A.6 backward runs one fused bilinear derivative per
+member.  No preconditioner (the pivoted-Cholesky kernel works on one stationary kernel).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import backend as B
+from . import settings
+from .bbmm import deterministic_probe_matrix, slq_logdet
+from .functions import hyper_grads
+from .linear_cg import linear_cg
+from .operators import (
+    ConstantDiagLinearOperator,
+    DiagLinearOperator,
+    FusedKernelLinearOperator,
+    LinearOperator,
+    RootLinearOperator,
+    ZeroLinearOperator,
+)
+
+
+class SumFusedLinearOperator(LinearOperator):
+    """sum_i members[i], every member a (scaled) fused kernel operator over the same pair of point clouds."""
+
+    def __init__(self, ops):
+        self.ops = list(ops)
+
+    @classmethod
+    def of(cls, terms):
+        flat = []
+        for t in terms:
+            flat.extend(t.ops if isinstance(t, SumFusedLinearOperator) else [t])
+        if len(flat) == 1:
+            return flat[0]
+        if not all(isinstance(t, FusedKernelLinearOperator) for t in flat):
+            from .operators import SumLinearOperator
+
+            return SumLinearOperator(*flat)  # generic (dense-capable) sum
+        return cls(flat)
+
+    dtype = property(lambda self: self.ops[0].dtype)
+    device = property(lambda self: self.ops[0].device)
+
+    @property
+    def requires_grad(self):
+        return any(o.requires_grad for o in self.ops)
+
+    def _size(self):
+        return self.ops[0].shape
+
+    def _matmul(self, rhs):
+        out = self.ops[0]._matmul(rhs)
+        for o in self.ops[1:]:
+            out = out + o._matmul(rhs)
+        return out
+
+    def _transpose_nonbatch(self):
+        return SumFusedLinearOperator([o._transpose_nonbatch() for o in self.ops])
+
+    def _mul_constant(self, c):
+        return SumFusedLinearOperator([o._mul_constant(c) for o in self.ops])
+
+    def to_dense(self):
+        return sum((o.to_dense() for o in self.ops[1:]), self.ops[0].to_dense())
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return sum((o.diagonal() for o in self.ops[1:]), self.ops[0].diagonal())
+
+    def __getitem__(self, index):
+        parts = [o[index] for o in self.ops]
+        if all(isinstance(p, FusedKernelLinearOperator) for p in parts):
+            return SumFusedLinearOperator(parts)
+        return sum(parts[1:], parts[0])
+
+    def detach(self):
+        return SumFusedLinearOperator([o.detach() for o in self.ops])
+
+    def __add__(self, other):
+        if isinstance(other, ZeroLinearOperator):
+            return self
+        if isinstance(other, (FusedKernelLinearOperator, SumFusedLinearOperator)):
+            return SumFusedLinearOperator.of([self, other])
+        if isinstance(other, ConstantDiagLinearOperator) and self.is_square and not other.batch_shape:
+            return SumFusedAddedDiagLinearOperator(self, other.diag_values)
+        if isinstance(other, DiagLinearOperator) and self.is_square and not other.batch_shape:
+            zero = torch.zeros(1, device=self.device, dtype=self.dtype)
+            return SumFusedAddedDiagLinearOperator(self, zero, noise_vec=other._diag)
+        return super().__add__(other)
+
+    __radd__ = __add__
+
+
+class SumFusedAddedDiagLinearOperator(LinearOperator):
+    """(sum_i theta_i k_i(x, x)) + noise I (+ diag(noise_vec)): the operator the MLL and the prediction caches solve with."""
+
+    def __init__(self, kernel_sum: SumFusedLinearOperator, noise: torch.Tensor, noise_vec=None, bbmm_opts=None):
+        self.kernel_sum = kernel_sum
+        self.noise = noise.reshape(-1)[:1]
+        self.noise_vec = noise_vec
+        self.bbmm_opts = {} if bbmm_opts is None else bbmm_opts
+
+    dtype = property(lambda self: self.kernel_sum.dtype)
+    device = property(lambda self: self.kernel_sum.device)
+
+    @property
+    def requires_grad(self):
+        return self.kernel_sum.requires_grad or self.noise.requires_grad
+
+    def _size(self):
+        return self.kernel_sum._size()
+
+    def _diag_total(self):
+        n = self.shape[-1]
+        d = self.noise.reshape(()).expand(n)
+        return d if self.noise_vec is None else d + self.noise_vec
+
+    def _matmul(self, rhs):
+        return self.kernel_sum._matmul(rhs) + self._diag_total().unsqueeze(-1) * rhs
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return self.kernel_sum.diagonal() + self._diag_total()
+
+    def to_dense(self):
+        return self.kernel_sum.to_dense() + torch.diag(self._diag_total().to(self.dtype))
+
+    def detach(self):
+        return SumFusedAddedDiagLinearOperator(self.kernel_sum.detach(), self.noise.detach(), self.noise_vec, self.bbmm_opts)
+
+    def __add__(self, other):
+        if isinstance(other, ConstantDiagLinearOperator) and not other.batch_shape:
+            return SumFusedAddedDiagLinearOperator(self.kernel_sum, self.noise + other.diag_values.reshape(-1)[:1], self.noise_vec, self.bbmm_opts)
+        if isinstance(other, DiagLinearOperator) and not other.batch_shape:
+            nv = other._diag if self.noise_vec is None else self.noise_vec + other._diag
+            return SumFusedAddedDiagLinearOperator(self.kernel_sum, self.noise, nv, self.bbmm_opts)
+        return super().__add__(other)
+
+    def restrict(self, idx):
+        nv = None if self.noise_vec is None else self.noise_vec[idx]
+        return SumFusedAddedDiagLinearOperator(self.kernel_sum[idx, idx], self.noise, nv, self.bbmm_opts)
+
+    # ---- matrix-free machinery shared by the three entry points
+    def _use_cholesky(self, flag) -> bool:
+        return flag.off() or self.shape[-1] <= settings.max_cholesky_size.value()
+
+    def _prepared(self):
+        return [(o.prepared()[0], o._os()) for o in self.kernel_sum.ops]
+
+    def _dvec(self, wd):
+        if self.noise_vec is None:
+            return None
+        n = self.shape[-1]
+        dv = torch.zeros(B.round_up(n, 4), device=self.device, dtype=wd)
+        dv[:n] = self.noise_vec.detach().to(wd)
+        return dv
+
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        n = self.shape[-1]
+        if inv_quad_rhs is None:
+            inv_quad_rhs = torch.zeros(n, 0, device=self.device, dtype=self.dtype)
+        rhs = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
+        if self._use_cholesky(settings.fast_computations.log_prob):
+            # small problems: K_hat is formed from the members' differentiable dense kernels; torch differentiates the rest
+            Kh = self.to_dense().to(torch.float64)
+            Lc = torch.linalg.cholesky(Kh)
+            sol = torch.cholesky_solve(rhs.to(torch.float64), Lc)
+            iq = (sol * rhs.to(torch.float64)).sum(-2).to(rhs.dtype)
+            ld = (2.0 * Lc.diagonal().log().sum()).to(rhs.dtype)
+        else:
+            drop = rhs.shape[-1] == 0
+            if drop:
+                rhs = torch.zeros(n, 1, device=self.device, dtype=self.dtype)
+            flat = []
+            for o in self.kernel_sum.ops:
+                flat += [o.x1, o.lengthscale, o.outputscale if o.outputscale is not None else torch.empty(0, device=self.device)]
+            specs = [o.spec for o in self.kernel_sum.ops]
+            iq, ld = SumInvQuadLogdetFn.apply(self.noise, rhs, specs, self._dvec(B.work_dtype(self.kernel_sum.ops[0].x1)), self.bbmm_opts, *flat)
+            if drop:
+                iq = iq[:0]
+        if reduce_inv_quad:
+            iq = iq.sum(-1)
+        return iq, (ld if logdet else None)
+
+    def inv_quad(self, inv_quad_rhs, reduce_inv_quad=True):
+        return self.inv_quad_logdet(inv_quad_rhs, False, reduce_inv_quad)[0]
+
+    def logdet(self):
+        return self.inv_quad_logdet(None, True)[1]
+
+    def _partials(self):
+        prepared = self._prepared()
+
+        def partials(dt):
+            out = None
+            for xp, os_ in prepared:
+                q = B.kv(xp, xp, dt, scale=os_)
+                out = q.clone() if out is None else out.add_(q)
+            return out, 1, out.stride(0)
+
+        return partials, prepared[0][0].dtype
+
+    def solve(self, rhs, lhs=None):
+        squeeze = rhs.dim() == 1
+        r = rhs.unsqueeze(-1) if squeeze else rhs
+        if self._use_cholesky(settings.fast_computations.solves):
+            sol = torch.cholesky_solve(r.detach().to(torch.float64), torch.linalg.cholesky(self.to_dense().detach().to(torch.float64))).to(rhs.dtype)
+        else:
+            partials, wd = self._partials()
+            nz = self.noise.detach().reshape(-1)[:1].to(wd).contiguous()
+            sol_t, _ = linear_cg(None, None, nz, B.to_probe_major(r.detach(), wd), n_tridiag=0, tolerance=settings.cg_tolerance.value(),
+                                 kv_partials=partials, dvec=self._dvec(wd), nvec=self.shape[-1])
+            sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
+        if lhs is not None:
+            sol = lhs @ sol
+        return sol.squeeze(-1) if squeeze else sol
+
+    def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
+        from .lanczos import root_inv_decomposition
+
+        if self._use_cholesky(settings.fast_computations.covar_root_decomposition):
+            return super().root_inv_decomposition()
+        n = self.shape[-1]
+        partials, wd = self._partials()
+        nz = self.noise.detach().reshape(()).to(wd)
+        dv = self._dvec(wd)
+
+        def mv(q_row):
+            out, _, _ = partials(q_row)
+            out = out + nz * q_row
+            return out if dv is None else out + dv.unsqueeze(0) * q_row
+
+        rt = root_inv_decomposition(None, None, None, matvec=mv, nvec=n, device=self.device, generator=self.bbmm_opts.get("generator"))
+        return RootLinearOperator(B.from_probe_major(rt, n).to(self.dtype))
+
+
+class SumInvQuadLogdetFn(torch.autograd.Function):
+    """(inv_quad[c], logdet) of sum_i theta_i k_i(x_i, x_i) + noise I by mBCG + SLQ; backward: one fused bilinear derivative
+    per member with the shared left / right vectors of A.6."""
+
+    @staticmethod
+    def forward(ctx, noise, rhs, specs, dvec, opts, *flat):
+        members = [(flat[3 * i], flat[3 * i + 1], flat[3 * i + 2] if flat[3 * i + 2].numel() else None) for i in range(len(specs))]
+        n = members[0][0].shape[-2]
+        dev = rhs.device
+        prepared = []
+        for (x, ls, os_), spec in zip(members, specs):
+            xp = B.prep_points(spec.kind, x, ls, spec.shift)
+            prepared.append((xp, None if os_ is None else os_.detach().reshape(-1)[:1].to(xp.dtype).contiguous()))
+        wd = prepared[0][0].dtype
+        t = opts.get("num_probes") or settings.num_trace_samples.value()
+        ld = B.round_up(n, 4)
+        probes = opts.get("probes")
+        if probes is None:
+            probes = deterministic_probe_matrix(n, t, dev, wd)
+        if probes is not None:
+            t = probes.shape[-1]
+        zt = torch.zeros(t, ld, device=dev, dtype=wd)
+        if probes is not None:
+            zt[:, :n] = probes.to(device=dev, dtype=wd).t()
+        else:
+            zt[:, :n] = torch.randint(0, 2, (t, n), device=dev, generator=opts.get("generator"), dtype=torch.int8).to(wd) * 2 - 1
+        znorm = B.coldot(zt, zt, n).sqrt()
+        zt.div_(znorm.unsqueeze(-1))
+        rhs_t = B.to_probe_major(rhs, wd)
+
+        def partials(dt):
+            out = None
+            for xp, os_ in prepared:
+                q = B.kv(xp, xp, dt, scale=os_)
+                out = q.clone() if out is None else out.add_(q)
+            return out, 1, out.stride(0)
+
+        nz = noise.detach().reshape(-1)[:1].to(wd).contiguous()
+        solves_t, info = linear_cg(None, None, nz, torch.cat([zt, rhs_t], 0).contiguous(), n_tridiag=t, tolerance=opts.get("tolerance"),
+                                   max_iter=opts.get("max_iter"), kv_partials=partials, dvec=dvec, nvec=n)
+        logdet = slq_logdet(info.t_mats, n).to(device=dev, dtype=wd)
+        c = rhs_t.shape[0]
+        inv_quad = B.coldot(solves_t[t : t + c], rhs_t, n)
+        ctx.prepared, ctx.n, ctx.t = prepared, n, t
+        ctx.solves_t, ctx.zt, ctx.znorm = solves_t, zt, znorm
+        ctx.members = members
+        ctx.save_for_backward(noise, rhs)
+        opts["_last_info"] = info
+        return inv_quad.to(rhs.dtype), logdet.to(rhs.dtype)
+
+    @staticmethod
+    def backward(ctx, g_iq, g_ld):
+        noise, rhs = ctx.saved_tensors
+        n, t = ctx.n, ctx.t
+        wd = ctx.prepared[0][0].dtype
+        c = ctx.solves_t.shape[0] - t
+        g_iq = g_iq.to(wd).reshape(c, 1)
+        g_ld = g_ld.to(wd).reshape(())
+        s_z = ctx.solves_t[:t] * ctx.znorm.unsqueeze(-1)
+        s_y = ctx.solves_t[t:]
+        zr = ctx.zt * ctx.znorm.unsqueeze(-1)
+        left = torch.cat([s_z * (g_ld / t), -s_y * g_iq], 0).contiguous()
+        right = torch.cat([zr, s_y], 0).contiguous()
+        grads = []
+        for i, ((x, ls, os_), (xp, _)) in enumerate(zip(ctx.members, ctx.prepared)):
+            need_x = ctx.needs_input_grad[5 + 3 * i]
+            if need_x:
+                d_ls, d_os, gx1, gx2 = hyper_grads(xp, xp, ls, os_, left, right, want_x1=True, want_x2=True)
+                d_x = (gx1 + gx2).to(x.dtype)
+            else:
+                d_ls, d_os = hyper_grads(xp, xp, ls, os_, left, right)
+                d_x = None
+            grads += [d_x, d_ls if ls.requires_grad else None, d_os]
+        d_noise = B.coldot(left, right, n).sum().reshape(noise.shape).to(noise.dtype)
+        d_rhs = (2.0 * B.from_probe_major(s_y, n) * g_iq.reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[1] else None
+        return (d_noise, d_rhs, None, None, None, *grads)

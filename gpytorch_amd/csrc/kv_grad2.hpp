@@ -186,23 +186,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const float* lrow = Ls + l31 * RS + h * TH4;
     const float* r0row = Rs + (size_t)l31 * RS + h * TH4;
     const float* r1row = Rs + (size_t)(32 + l31) * RS + h * TH4;
-    // operands of the NEXT four k-steps are fetched from LDS before the eight MFMAs of the current ones issue
-    f32x4 lb = *reinterpret_cast<const f32x4*>(lrow);
-    f32x4 ra = *reinterpret_cast<const f32x4*>(r0row);
-    f32x4 rbv = *reinterpret_cast<const f32x4*>(r1row);
+    // (fetching the operands of the next four k-steps ahead of the eight MFMAs was measured SLOWER: 368 vs 349 ms,
+    // profiles/r02_s6_grad_timing_operand_prefetch_slower.json -- the second resident wave already covers the LDS latency)
     for (int c4 = 0; c4 < TH4; c4 += 4) {
-      const int cn = c4 + 4 < TH4 ? c4 + 4 : c4;
-      const f32x4 lbn = *reinterpret_cast<const f32x4*>(lrow + cn);
-      const f32x4 ran = *reinterpret_cast<const f32x4*>(r0row + cn);
-      const f32x4 rbn = *reinterpret_cast<const f32x4*>(r1row + cn);
-      __builtin_amdgcn_s_setprio(1);
+      const f32x4 lb = *reinterpret_cast<const f32x4*>(lrow + c4);
+      const f32x4 ra = *reinterpret_cast<const f32x4*>(r0row + c4);
+      const f32x4 rbv = *reinterpret_cast<const f32x4*>(r1row + c4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         w0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[e], lb[e], w0, 0, 0, 0);
         w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(rbv[e], lb[e], w1, 0, 0, 0);
       }
-      __builtin_amdgcn_s_setprio(0);
-      lb = lbn; ra = ran; rbv = rbn;
     }
     // ---- squared distances of the same two blocks (Gram form)
     f32x16 s0, s1;

@@ -63,7 +63,7 @@ class Kernel(Module):
     def __call__(self, x1, x2=None, diag=False, last_dim_is_batch=False, **params):
         """``kernel.py:454-534``: select active dims, promote 1-D inputs to [n, 1], default x2 = x1; leading dimensions of
         the inputs (and the kernel's ``batch_shape``) are batch dimensions (``kernel.py:163-208``)."""
-        x1_, x2_ = x1, x2
+        x1_, x2_ = x1, (None if x2 is x1 else x2)
         if last_dim_is_batch:  # kernel.py:506-510: every input dimension becomes its own batch member, [..., d, n, 1]
             x1_ = x1_.transpose(-1, -2).unsqueeze(-1)
             x2_ = None if x2_ is None else x2_.transpose(-1, -2).unsqueeze(-1)
@@ -88,6 +88,28 @@ class Kernel(Module):
         from .models import DefaultPredictionStrategy
 
         return DefaultPredictionStrategy
+
+    # ---- composition (kernels/kernel.py:563-589: ``+`` -> AdditiveKernel, ``*`` -> ProductKernel)
+    def __add__(self, other):
+        kernels = list(self.kernels) if isinstance(self, AdditiveKernel) else [self]
+        kernels += list(other.kernels) if isinstance(other, AdditiveKernel) else [other]
+        return AdditiveKernel(*kernels)
+
+    def __mul__(self, other):
+        kernels = list(self.kernels) if isinstance(self, ProductKernel) else [self]
+        kernels += list(other.kernels) if isinstance(other, ProductKernel) else [other]
+        return ProductKernel(*kernels)
+
+    def _select(self, x):
+        """Promote 1-D inputs and apply ``active_dims`` (the input handling of ``__call__``)."""
+        x = x.unsqueeze(1) if x.dim() == 1 else x
+        return x if self.active_dims is None else x.index_select(-1, self.active_dims)
+
+    def rbf_features(self, x):
+        """phi(x) with  k(x, x') = exp(-1/2 |phi(x) - phi(x')|^2)  for kernels of the squared-exponential family (RBF: x / l;
+        Periodic: (cos, sin)(2 pi x / p) / sqrt(l); their products: concatenation), or None.  It lets compositions run on the
+        fused RBF kernels: hyper-parameters reach the objective through phi, whose gradient is the fused input gradient."""
+        return None
 
 
 class _StationaryFused(Kernel):
@@ -124,6 +146,70 @@ class RBFKernel(_StationaryFused):
     r"""k(x, x') = exp(-1/2 (x - x')^T Theta^-2 (x - x'))  (``gpytorch/kernels/rbf_kernel.py:14-85``)."""
 
     kind = "rbf"
+
+    def rbf_features(self, x):
+        return self._select(x) / self.lengthscale
+
+
+def _unit_lengthscale(x):
+    return torch.ones(1, 1, device=x.device, dtype=x.dtype)
+
+
+def _feature_operator(f1, f2, same):
+    """exp(-1/2 |f1_i - f2_j|^2) as a fused RBF operator with unit lengthscale over feature clouds (batch-aware)."""
+    if f1.dim() == 2:
+        f2 = f1 if same else f2
+        return FusedKernelLinearOperator(f1, f2, KernelSpec("rbf", f1.detach().mean(dim=-2)), _unit_lengthscale(f1))
+    batch = torch.broadcast_shapes(f1.shape[:-2], f2.shape[:-2])
+    f1b = f1.expand(*batch, *f1.shape[-2:]).reshape(-1, *f1.shape[-2:])
+    f2b = f1b if same else f2.expand(*batch, *f2.shape[-2:]).reshape(-1, *f2.shape[-2:])
+    ops = [_feature_operator(f1b[b], f1b[b] if same else f2b[b], same) for b in range(f1b.shape[0])]
+    return BatchLinearOperator(ops, batch)
+
+
+class PeriodicKernel(Kernel):
+    r"""k(x, x') = exp(-2 sum_q sin^2(pi (x_q - x'_q) / p_q) / l_q)   (``gpytorch/kernels/periodic_kernel.py:14-142``, the
+    KeOps twin ``kernels/keops/periodic_kernel.py``).  Since sin^2(a - b) = (1 - cos 2(a - b)) / 2, the exponent is
+    -1/2 |phi(x) - phi(x')|^2 with phi_q = (cos, sin)(2 pi x_q / p_q) / sqrt(l_q): a fused RBF operator over 2 d features
+    (d <= 8 on the fused float32 kernels)."""
+
+    has_lengthscale = True
+
+    def __init__(self, period_length_prior=None, period_length_constraint=None, **kwargs):
+        super().__init__(**kwargs)
+        n_p = 1 if self.ard_num_dims is None else self.ard_num_dims
+        self.register_parameter("raw_period_length", torch.nn.Parameter(torch.zeros(*self._batch_shape, 1, n_p)))
+        self.register_constraint("raw_period_length", Positive() if period_length_constraint is None else period_length_constraint)
+        if period_length_prior is not None:
+            self.register_prior("period_length_prior", period_length_prior, lambda m: m.period_length, lambda m, v: m._set_period_length(v))
+
+    @property
+    def period_length(self):
+        return self._get_transformed("raw_period_length")
+
+    @period_length.setter
+    def period_length(self, value):
+        self._set_period_length(value)
+
+    def _set_period_length(self, value):
+        self._set_transformed("raw_period_length", value)
+
+    def rbf_features(self, x):
+        x = self._select(x)
+        a = x * (2.0 * math.pi / self.period_length)
+        return torch.cat([a.cos(), a.sin()], dim=-1) / torch.cat([self.lengthscale.sqrt().expand_as(a[..., :1, :])] * 2, dim=-1)
+
+    def forward(self, x1, x2, diag=False, **params):
+        if diag:
+            return torch.ones(x1.shape[:-1], device=x1.device, dtype=x1.dtype)
+        same = x2 is x1
+        f1 = self.rbf_features(x1)
+        return _feature_operator(f1, f1 if same else self.rbf_features(x2), same)
+
+    def __call__(self, x1, x2=None, diag=False, **params):
+        # active_dims are applied inside rbf_features (so that products can concatenate members with different active_dims)
+        x2 = x1 if x2 is None else x2
+        return self.forward(x1, x2, diag=diag, **params)
 
 
 class MaternKernel(_StationaryFused):
@@ -190,5 +276,90 @@ class ScaleKernel(Kernel):
         return self.base_kernel.prediction_strategy
 
 
-__all__ = ["Kernel", "RBFKernel", "MaternKernel", "ScaleKernel"]
+class AdditiveKernel(Kernel):
+    """K = sum_i K_i (``kernels/kernel.py:592-632``): the members stay matrix-free; their sum is a
+    :class:`~gpytorch_amd.operators.SumFusedLinearOperator` whose products, solves and log-determinants add the members'
+    fused products."""
+
+    def __init__(self, *kernels):
+        super().__init__()
+        self.kernels = torch.nn.ModuleList(kernels)
+
+    @property
+    def is_stationary(self):
+        return all(k.is_stationary for k in self.kernels)
+
+    def __call__(self, x1, x2=None, diag=False, **params):
+        return self.forward(x1, x1 if x2 is None else x2, diag=diag, **params)
+
+    def forward(self, x1, x2, diag=False, **params):
+        from .composite import SumFusedLinearOperator
+
+        terms = [k(x1, x2, diag=diag, **params) for k in self.kernels]
+        if diag:
+            return sum(terms[1:], terms[0])
+        return SumFusedLinearOperator.of(terms)
+
+
+def _se_family(kernel):
+    """(feature function, outputscale or None) if ``kernel`` is a product of squared-exponential-family members, else None."""
+    if isinstance(kernel, ScaleKernel):
+        inner = _se_family(kernel.base_kernel)
+        if inner is None:
+            return None
+        return inner[0], (kernel.outputscale if inner[1] is None else kernel.outputscale * inner[1])
+    if isinstance(kernel, ProductKernel):
+        parts = [_se_family(k) for k in kernel.kernels]
+        if any(p is None for p in parts):
+            return None
+        scale = None
+        for _, sc in parts:
+            if sc is not None:
+                scale = sc if scale is None else scale * sc
+        return (lambda x, parts=parts: torch.cat([f(x) for f, _ in parts], dim=-1)), scale
+    if kernel.rbf_features.__func__ is not Kernel.rbf_features:
+        return kernel.rbf_features, None
+    return None
+
+
+class ProductKernel(Kernel):
+    """K = prod_i K_i elementwise (``kernels/kernel.py:634-688``).  Products of squared-exponential-family members (RBF,
+    Periodic, their ScaleKernels) are ONE fused RBF operator over the concatenated feature maps -- exact, matrix-free, at most 16
+    feature dimensions.  Any other product is formed densely (the reference, too, densifies whenever x1 != x2) and is meant
+    for small problems."""
+
+    def __init__(self, *kernels):
+        super().__init__()
+        self.kernels = torch.nn.ModuleList(kernels)
+
+    @property
+    def is_stationary(self):
+        return all(k.is_stationary for k in self.kernels)
+
+    def __call__(self, x1, x2=None, diag=False, **params):
+        return self.forward(x1, x1 if x2 is None else x2, diag=diag, **params)
+
+    def forward(self, x1, x2, diag=False, **params):
+        fam = _se_family(self)
+        if fam is not None:
+            feat, scale = fam
+            if diag:
+                one = torch.ones(x1.shape[:-1] if x1.dim() > 1 else x1.shape, device=x1.device, dtype=x1.dtype)
+                return one if scale is None else one * scale.unsqueeze(-1)
+            same = x2 is x1
+            f1 = feat(x1)
+            if f1.shape[-1] <= B.MAX_INPUT_DIM or f1.dtype == torch.float64:
+                op = _feature_operator(f1, f1 if same else feat(x2), same)
+                return op if scale is None else op.mul(scale.reshape(1) if scale.numel() == 1 and not op.batch_shape else scale)
+        from .operators import DenseLinearOperator, to_dense
+
+        res = None
+        for k in self.kernels:
+            term = k(x1, x2, diag=diag, **params)
+            term = term if diag else to_dense(term)
+            res = term if res is None else res * term
+        return res if diag else DenseLinearOperator(res)
+
+
+__all__ = ["Kernel", "RBFKernel", "MaternKernel", "PeriodicKernel", "ScaleKernel", "AdditiveKernel", "ProductKernel"]
 _ = (math, Interval)

@@ -28,14 +28,15 @@ def lanczos_tridiag(x: B.PreparedPoints, scale, dscale, max_iter: int, init_vec_
 FORCE_TORCH = False  # tests: run float32 problems through the torch formulation too
 
 
-def _lanczos_native(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec, matvec, nvec, device, reduce, n_global):
-    """The algorithm of :func:`_lanczos_torch`, vector work on the ``gpamd_lanczos_*`` kernels.  Same return convention."""
+def lanczos_steps(n, dev, max_iter, init_vec_t=None, tol=1e-5, generator=None, reduce=None, n_global=None):
+    """The algorithm of :func:`_lanczos_torch` as a COROUTINE, vector work on the ``gpamd_lanczos_*`` kernels: yields the
+    probe-major row q_k ([1, ld]) whose product w = A q_k it needs next and receives w through ``send``; finally returns
+    (Qt [m, ld], T [m, m]) as the StopIteration value.  The caller owns the operator product -- which lets the predictive
+    posterior fuse it with the mean-cache CG product into one two-column launch (:func:`gpytorch_amd.models.fused_caches`)."""
     import ctypes as C
 
     from ._lib import check, lib
 
-    n = x.n if nvec is None else nvec
-    dev = x.xp.device if device is None else device
     ld = B.round_up(n, 4)
     num_iter = min(max_iter, n if n_global is None else n_global)
     f32 = torch.float32
@@ -81,17 +82,12 @@ def _lanczos_native(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec
         check(L.gpamd_lanczos_normalize_f32(p(src), n, p(rr), p(dst_row), None if norm_out is None else fptr(norm_out, norm_off),
                                             1e-6, stop_ptr if watch else None, st), "lanczos_normalize")
 
-    def mv(q_row):
-        if matvec is not None:
-            return matvec(q_row)
-        return B.kv(x, x, q_row, scale=scale, dscale=dscale, vd=q_row if dscale is not None else None, dvec=dvec)
-
     # q0 = init / |init|
     r.copy_(init_vec_t[:1])
     zero = torch.zeros(1, device=dev, dtype=f32)
     subtract(Q[0:1], 1, zero)                      # r unchanged, rr = |init|^2
     normalize(r, Q[0])
-    w = mv(Q[0:1])
+    w = yield Q[0:1]
     check(L.gpamd_lanczos_residual_f32(p(w), None, None, p(r), n, st), "lanczos_residual")
     project(Q[0:1], 1, alpha, 0)                   # alpha_0 = <q0, K q0>
     subtract(Q[0:1], 1, alpha, 0)                  # r -= alpha_0 q0, rr = |r|^2
@@ -100,7 +96,7 @@ def _lanczos_native(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec
         normalize(r, Q[1], beta, 0)                # beta_0 = |r|, q1 = r / beta_0
         m = 2
         for k in range(1, num_iter):
-            w = mv(Q[k : k + 1])
+            w = yield Q[k : k + 1]
             check(L.gpamd_lanczos_residual_f32(p(w), p(Q[k - 1]), fptr(beta, k - 1), p(r), n, st), "lanczos_residual")
             project(Q[k : k + 1], 1, alpha, k)     # alpha_k = <q_k, r>
             m = k + 1
@@ -129,6 +125,25 @@ def _lanczos_native(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec
     if m > 1:
         T = T + torch.diag(b_h, 1) + torch.diag(b_h, -1)
     return Q[:m], T
+
+
+def _lanczos_native(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec, matvec, nvec, device, reduce, n_global):
+    """Drives :func:`lanczos_steps` with this operator's own product.  Same return convention as :func:`_lanczos_torch`."""
+    n = x.n if nvec is None else nvec
+    dev = x.xp.device if device is None else device
+
+    def mv(q_row):
+        if matvec is not None:
+            return matvec(q_row)
+        return B.kv(x, x, q_row, scale=scale, dscale=dscale, vd=q_row if dscale is not None else None, dvec=dvec)
+
+    steps = lanczos_steps(n, dev, max_iter, init_vec_t, tol, generator, reduce, n_global)
+    try:
+        q = next(steps)
+        while True:
+            q = steps.send(mv(q))
+    except StopIteration as done:
+        return done.value
 
 
 def _lanczos_torch(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec, matvec, nvec, device, reduce, n_global):

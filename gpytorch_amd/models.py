@@ -56,7 +56,16 @@ class DefaultPredictionStrategy:
             mvn = self.likelihood(self.train_prior_dist, self.train_inputs)
             train_mean, train_train_covar = mvn.loc, mvn.lazy_covariance_matrix
             offset = (self.train_labels - train_mean).unsqueeze(-1)
-            mc = train_train_covar.evaluate_kernel().solve(offset).squeeze(-1)
+            op = train_train_covar.evaluate_kernel()
+            if (settings.fast_pred_var.on() and self._covar_cache is None and self._inv_root is None and offset.dim() == 2
+                    and hasattr(op, "can_fuse_caches") and op.can_fuse_caches()):
+                # LOVE is on and both caches are missing: one sequence of two-column products serves the mean-cache CG and the
+                # Lanczos run together (FusedKernelAddedDiagLinearOperator.solve_and_root_inv)
+                mc, root = (op.detach() if settings.detach_test_caches.on() else op).solve_and_root_inv(offset)
+                mc = mc.squeeze(-1)
+                self._covar_cache = root.root.detach() if settings.detach_test_caches.on() else root.root
+            else:
+                mc = op.solve(offset).squeeze(-1)
             if settings.detach_test_caches.on():
                 mc = mc.detach()
             self._mean_cache = mc

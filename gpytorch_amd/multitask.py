@@ -346,6 +346,17 @@ class IndexKernel(Kernel):
     def covar_matrix(self):
         return self.covar_factor @ self.covar_factor.mT + torch.diag(self.var)  # index_kernel.py:91-99
 
+    def __call__(self, i1, i2=None, diag=False, **params):
+        return self.forward(i1, i1 if i2 is None else i2, diag=diag, **params)
+
+    def forward(self, i1, i2, diag=False, **params):
+        """index_kernel.py:101-112: the task covariance looked up at the task indices of the points (Hadamard multitask GPs:
+        ``covar_x.mul(covar_i)``, see :mod:`gpytorch_amd.hadamard`)."""
+        from .hadamard import IndexedTaskCovar
+
+        op = IndexedTaskCovar(self.covar_matrix, i1, i2)
+        return op.diagonal() if diag else op
+
 
 class MultitaskKernel(Kernel):
     """``gpytorch/kernels/multitask_kernel.py:46-61``."""

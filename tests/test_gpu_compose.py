@@ -1,0 +1,171 @@
+"""GPU parity: SURVEY.md 8(f) rank 3 -- other stationary kernels and kernel composition on the fused path.
+
+  * PeriodicKernel values / diagonal / ARD            gpytorch/kernels/periodic_kernel.py:125-142 (KeOps twin: kernels/keops/periodic_kernel.py)
+  * ProductKernel of squared-exponential members      gpytorch/kernels/kernel.py:634-688 -- one fused operator over concatenated features
+  * AdditiveKernel                                     gpytorch/kernels/kernel.py:592-632 -- matrix-free sum, mBCG / SLQ / backward per member
+Ground truth: float64 restatement of the reference formulas + torch autograd (dense Cholesky for the MLL).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import exact_gp as OG
+from oracle import kernels as OK
+from tests.util import make_data, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def periodic_ref(x1, x2, ls, period):
+    """periodic_kernel.py:125-142: exp(-2 sum_q sin^2(pi (x1_q - x2_q) / p_q) / l_q)."""
+    diff = math.pi * (x1.unsqueeze(-2) - x2.unsqueeze(-3)) / period
+    return torch.exp(-2.0 * (diff.sin().pow(2) / ls).sum(-1))
+
+
+@pytest.mark.parametrize("ard", [False, True])
+def test_periodic_kernel_values_matmul_and_grads(ard, dev):
+    import gpytorch_amd as g
+
+    gen = torch.Generator().manual_seed(0)
+    n, m, d = 300, 210, 3
+    x1 = torch.rand(n, d, generator=gen) * 3
+    x2 = torch.rand(m, d, generator=gen) * 3
+    kern = g.kernels.PeriodicKernel(ard_num_dims=d if ard else None).to(dev)
+    ls = torch.tensor([[0.9, 1.4, 2.0]]) if ard else torch.tensor([[1.3]])
+    per = torch.tensor([[1.1, 0.7, 1.9]]) if ard else torch.tensor([[0.8]])
+    kern.lengthscale = ls
+    kern.period_length = per
+    K = kern(x1.to(dev), x2.to(dev)).to_dense()
+    Kref = periodic_ref(x1.double(), x2.double(), ls.double(), per.double())
+    assert rel_err(K, Kref) < 1e-5
+    assert torch.equal(kern(x1.to(dev), diag=True).cpu(), torch.ones(n))
+    # matrix-free product and hyper-parameter gradients through the fused input gradient
+    V = torch.randn(n, 7, generator=gen)
+    op = kern(x1.to(dev))
+    out = op @ V.to(dev)
+    out.pow(2).sum().backward()
+    ls64 = ls.double().requires_grad_(True)
+    p64 = per.double().requires_grad_(True)
+    ref = periodic_ref(x1.double(), x1.double(), ls64, p64) @ V.double()
+    assert rel_err(out, ref) < 2e-5
+    ref.pow(2).sum().backward()
+    sig = lambda raw: torch.sigmoid(raw.detach().double().cpu())  # noqa: E731  (softplus chain rule)
+    assert torch.allclose(kern.raw_lengthscale.grad.double().cpu(), ls64.grad * sig(kern.raw_lengthscale), rtol=2e-3, atol=1e-6 * float(ls64.grad.abs().max()))
+    assert torch.allclose(kern.raw_period_length.grad.double().cpu(), p64.grad * sig(kern.raw_period_length), rtol=2e-3, atol=1e-6 * float(p64.grad.abs().max()))
+
+
+def test_product_of_rbf_and_periodic_is_one_fused_operator(dev):
+    import gpytorch_amd as g
+    from gpytorch_amd.operators import FusedKernelLinearOperator
+
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(400, 3, generator=gen) * 2
+    k1 = g.kernels.ScaleKernel(g.kernels.RBFKernel(active_dims=[0, 2]))
+    k2 = g.kernels.PeriodicKernel(active_dims=[1])
+    kern = (k1 * k2).to(dev)
+    k1.base_kernel.lengthscale = 0.6
+    k1.outputscale = 1.7
+    k2.lengthscale = 1.2
+    k2.period_length = 0.5
+    op = kern(x.to(dev))
+    assert isinstance(op, FusedKernelLinearOperator)            # matrix-free: 2 + 2 feature dimensions
+    xd = x.double()
+    Kref = 1.7 * OK.rbf(xd[:, [0, 2]], xd[:, [0, 2]], 0.6, x1_eq_x2=True, direct=True) * periodic_ref(xd[:, [1]], xd[:, [1]], torch.tensor([[1.2]]), torch.tensor([[0.5]]))
+    assert rel_err(op.to_dense(), Kref) < 1e-5
+    V = torch.randn(400, 20, generator=gen)
+    assert rel_err(op @ V.to(dev), Kref @ V.double()) < 2e-5
+    # a product with a Matern member falls back to the dense elementwise product (the reference densifies as well)
+    mixed = (g.kernels.RBFKernel() * g.kernels.MaternKernel(nu=1.5)).to(dev)
+    Kd = mixed(x.to(dev)).to_dense()
+    l0 = math.log(2.0)  # default raw parameter 0 -> softplus = ln 2
+    assert rel_err(Kd, OK.rbf(xd, xd, l0, x1_eq_x2=True, direct=True) * OK.matern(xd, xd, l0, 1.5, x1_eq_x2=True, direct=True)) < 1e-5
+
+
+@pytest.mark.parametrize("branch", ["cholesky", "bbmm"])
+def test_additive_kernel_mll_and_grads(branch, dev):
+    """ScaleKernel(RBF) + ScaleKernel(Matern-5/2): MLL value and every hyper-parameter gradient against dense float64 autograd
+    (BBMM branch: probes shared with the oracle through deterministic_probes; log-det terms compared at the SLQ accuracy)."""
+    import gpytorch_amd as g
+
+    n, d = (500, 2) if branch == "cholesky" else (1800, 2)
+    X, y = make_data(n, d)
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ZeroMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel()) + g.kernels.ScaleKernel(g.kernels.MaternKernel(nu=2.5))
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood().to(dev)
+    m = M(X.float().to(dev), y.float().to(dev), lik).to(dev)
+    ka, kb = m.covar_module.kernels
+    ka.base_kernel.lengthscale, ka.outputscale = 0.25, 1.1
+    kb.base_kernel.lengthscale, kb.outputscale = 0.9, 0.4
+    lik.noise = 0.1
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    m.train()
+    lik.train()
+    S = g.settings
+    with S.max_cholesky_size(10_000 if branch == "cholesky" else 0), S.cg_tolerance(1e-5), S.num_trace_samples(400), S.max_preconditioner_size(0):
+        torch.manual_seed(0)
+        val = mll(m(m.train_inputs[0]), m.train_targets)
+        val.backward()
+    p = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (0.25, 1.1, 0.9, 0.4, 0.1)]
+    Kh = p[1] * OK.rbf(X, X, p[0], x1_eq_x2=True, direct=True) + p[3] * OK.matern(X, X, p[2], 2.5, x1_eq_x2=True, direct=True) + p[4] * torch.eye(n, dtype=torch.float64)
+    ref = OG.dense_log_prob(Kh, y) / n
+    gref = torch.autograd.grad(ref, p)
+    tol_v, tol_g = (2e-4, 3e-3) if branch == "cholesky" else (5e-3, 0.12)
+    assert abs(float(val) - float(ref)) < tol_v * max(1.0, abs(float(ref)))
+    sp = lambda v: 1.0 - math.exp(-v)  # noqa: E731
+    got = [ka.base_kernel.raw_lengthscale.grad, ka.raw_outputscale.grad, kb.base_kernel.raw_lengthscale.grad, kb.raw_outputscale.grad, lik.noise_covar.raw_noise.grad]
+    chain = [sp(0.25), sp(1.1), sp(0.9), sp(0.4), sp(0.1 - 1e-4)]
+    for gg, rr, cc in zip(got, gref, chain):
+        assert gg is not None
+        assert abs(float(gg.sum()) - float(rr) * cc) < tol_g * abs(float(rr) * cc) + 1e-5, (float(gg.sum()), float(rr) * cc)
+
+
+def test_additive_kernel_posterior_with_cg(dev):
+    """Predictive mean / variance of an additive-kernel GP with CG + Lanczos forced, against the dense float64 posterior."""
+    import gpytorch_amd as g
+
+    n, ns, d = 1500, 100, 2
+    X, y = make_data(n + ns, d)
+    Xt, yt, Xs = X[:n], y[:n], X[n:]
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ZeroMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel()) + g.kernels.ScaleKernel(g.kernels.PeriodicKernel())
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood().to(dev)
+    m = M(Xt.float().to(dev), yt.float().to(dev), lik).to(dev)
+    ka, kb = m.covar_module.kernels
+    ka.base_kernel.lengthscale, ka.outputscale = 0.3, 1.0
+    kb.base_kernel.lengthscale, kb.base_kernel.period_length, kb.outputscale = 1.5, 0.7, 0.5
+    lik.noise = 0.2
+    m.eval()
+    lik.eval()
+    S = g.settings
+    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-5):
+        pred = m(Xs.float().to(dev))
+        mu, var = pred.mean, pred.variance
+
+    def kfun(a, b, same):
+        return 1.0 * OK.rbf(a, b, 0.3, x1_eq_x2=same, direct=True) + 0.5 * periodic_ref(a, b, torch.tensor([[1.5]]), torch.tensor([[0.7]]))
+
+    Kh = kfun(Xt, Xt, True) + 0.2 * torch.eye(n, dtype=torch.float64)
+    Ks = kfun(Xs, Xt, False)
+    Lc = torch.linalg.cholesky(Kh)
+    mu_ref = Ks @ torch.cholesky_solve(yt.unsqueeze(-1), Lc).squeeze(-1)
+    w = torch.linalg.solve_triangular(Lc, Ks.t(), upper=False)
+    var_ref = 1.5 - w.pow(2).sum(0)
+    assert rel_err(mu, mu_ref) < 1e-3
+    assert float((var.double().cpu() - var_ref).abs().max()) < 2e-3
