@@ -69,8 +69,15 @@ def solve(input, rhs, lhs=None):
     return to_linear_operator(input).solve(rhs, lhs)
 
 
+def sqrt_inv_matmul(input, rhs, lhs=None):
+    """gpytorch/__init__.py:252-278: K^{-1/2} rhs by contour-integral quadrature + msMINRES (:mod:`gpytorch_amd.ciq`)."""
+    from .ciq import sqrt_inv_matmul as _f
+
+    return _f(to_linear_operator(input), rhs, lhs)
+
+
 __all__ = [
     "ExactMarginalLogLikelihood", "Module", "add_diagonal", "add_jitter", "distributed", "distributions", "inv_quad", "inv_quad_logdet",
     "kernels", "likelihoods", "logdet", "means", "mlls", "models", "operators", "pivoted_cholesky", "priors", "root_decomposition",
-    "root_inv_decomposition", "settings", "solve", "to_dense",
+    "root_inv_decomposition", "settings", "solve", "sqrt_inv_matmul", "to_dense",
 ]

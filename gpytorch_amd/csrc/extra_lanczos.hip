@@ -67,4 +67,34 @@ int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* o
   return lz_check("lanczos_normalize");
 }
 
+// ---- preconditioner coefficients W = R Q1^T in mixed precision (lanczos_kernels.hpp: pc_coef_kernel) ----
+int64_t gpamd_precond_coef_workspace_doubles(int n, int t, int k) {
+  if (n <= 0 || t <= 0 || k <= 0) return 0;
+  long nb = ((long)n + 2047) / 2048;
+  if (nb > 256) nb = 256;
+  return (int64_t)nb * t * k;
+}
+
+int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* Q, int64_t ldq, int k, int n, double* W,
+                              double* workspace, int64_t workspace_doubles, void* stream) {
+  if (!R || !Q || !W || !workspace || n <= 0 || t <= 0 || k <= 0 || ldr < n || ldq < n) return lz_fail("precond_coef: bad arguments");
+  if (k > 16 * PC_MT) return lz_fail("precond_coef: rank > 128");
+  long nb = ((long)n + 2047) / 2048;
+  if (nb > 256) nb = 256;
+  if (workspace_doubles < (int64_t)nb * t * k) return GPAMD_EWORKSPACE;
+  const int slice = (int)(((long)n + nb - 1) / nb + PC_CHUNK - 1) / PC_CHUNK * PC_CHUNK;
+  nb = ((long)n + slice - 1) / slice;
+  hipStream_t st = (hipStream_t)stream;
+  for (int c0 = 0; c0 < t; c0 += 80) {   // column groups of <= 80 (16 x 5 register tile)
+    const int tg = t - c0 < 80 ? t - c0 : 80;
+    double* part = workspace;             // reused per group: the sum kernel of a group runs before the next group's partials
+    if (tg <= 16)
+      hipLaunchKernelGGL((pc_coef_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
+    else
+      hipLaunchKernelGGL((pc_coef_kernel<5>), dim3((unsigned)nb), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
+    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((tg * k + 255) / 256), dim3(256), 0, st, (const double*)part, (int)nb, tg * k, W + (int64_t)c0 * k);
+  }
+  return lz_check("precond_coef");
+}
+
 }  // extern "C"

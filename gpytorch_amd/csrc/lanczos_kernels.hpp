@@ -108,3 +108,72 @@ __global__ __launch_bounds__(256) void lz_normalize_kernel(const float* __restri
 }
 
 }  // namespace gpamd
+
+namespace gpamd {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Preconditioner coefficients in mixed precision:  W[c][m] = sum_i R[c][i] * Q1[m][i]   (R float32 [t][ldr], Q1 float64 [k][ldq],
+// float64 accumulation).  P^-1 R = (R - W Q1) / s2 needs the leading components of R to cancel to ~6 digits (linear_cg.py,
+// Preconditioner.apply_), hence float64; rocBLAS' float64 GEMM for these tall-skinny shapes takes 80 ms for some (t, k)
+// (profiles/r02_s7_precond_apply_rocblas_f64_shapes.txt: k = 15), 4x a whole K*V at n = 500 000.
+// Work split: block b owns a slice of i; threads form a 16 x 16 grid over (column, basis vector) with a CT x MT register tile each;
+// 32-element chunks of R and Q1 are staged in LDS.  Partials [b][t][k] are summed in a fixed order by pc_coef_sum_kernel.
+constexpr int PC_CHUNK = 32;
+constexpr int PC_MT = 8;      // k <= 128
+
+template <int CT>  // t <= 16 * CT
+__global__ __launch_bounds__(256) void pc_coef_kernel(const float* __restrict__ R, int64_t ldr, int t, const double* __restrict__ Q,
+                                                      int64_t ldq, int k, int n, int slice, double* __restrict__ part) {
+  __shared__ float Rs[16 * CT][PC_CHUNK + 1];
+  __shared__ double Qs[16 * PC_MT][PC_CHUNK + 1];
+  const int tid = threadIdx.x, tc = tid >> 4, tm = tid & 15;
+  const int i0 = blockIdx.x * slice, i1 = min(n, i0 + slice);
+  double acc[CT][PC_MT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < PC_MT; ++b) acc[a][b] = 0.0;
+  for (int ib = i0; ib < i1; ib += PC_CHUNK) {
+    __syncthreads();
+    for (int e = tid; e < 16 * CT * PC_CHUNK; e += 256) {
+      const int c = e / PC_CHUNK, ii = e % PC_CHUNK;
+      Rs[c][ii] = (c < t && ib + ii < i1) ? R[(int64_t)c * ldr + ib + ii] : 0.f;
+    }
+    for (int e = tid; e < 16 * PC_MT * PC_CHUNK; e += 256) {
+      const int m = e / PC_CHUNK, ii = e % PC_CHUNK;
+      Qs[m][ii] = (m < k && ib + ii < i1) ? Q[(int64_t)m * ldq + ib + ii] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int ii = 0; ii < PC_CHUNK; ++ii) {
+      double rv[CT], qv[PC_MT];
+#pragma unroll
+      for (int a = 0; a < CT; ++a) rv[a] = (double)Rs[tc + 16 * a][ii];
+#pragma unroll
+      for (int b = 0; b < PC_MT; ++b) qv[b] = Qs[tm + 16 * b][ii];
+#pragma unroll
+      for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int b = 0; b < PC_MT; ++b) acc[a][b] = fma(rv[a], qv[b], acc[a][b]);
+    }
+  }
+  double* out = part + (int64_t)blockIdx.x * t * k;
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < PC_MT; ++b) {
+      const int c = tc + 16 * a, m = tm + 16 * b;
+      if (c < t && m < k) out[(int64_t)c * k + m] = acc[a][b];
+    }
+}
+
+// W[e] = sum_b part[b][e]     (e < t * k)
+__global__ void pc_coef_sum_kernel(const double* __restrict__ part, int nb, int tk, double* __restrict__ W) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= tk) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * tk + e];
+  W[e] = s;
+}
+
+}  // namespace gpamd

@@ -100,7 +100,18 @@ class Preconditioner:
         Cost: two [t, n] x [n, k] float64 GEMMs per CG iteration, < 1 ms against a >= 19 ms K*V at that size."""
         q1t = self.q1t if self.q1t.dtype == torch.float64 else self.q1t.to(torch.float64)
         r64 = rt.to(torch.float64)
-        w = r64 @ q1t.t()
+        k = q1t.shape[0]
+        if rt.dtype == torch.float32 and rt.is_cuda and k <= 128 and rt.stride(1) == 1 and q1t.stride(1) == 1:
+            # W = R Q1^T: own mixed-precision reduction kernel (rocBLAS' float64 GEMM takes 80 ms for some tall-skinny shapes)
+            t, n = rt.shape[0], min(rt.shape[1], q1t.shape[1])
+            L = lib()
+            nws = int(L.gpamd_precond_coef_workspace_doubles(n, t, k))
+            ws = torch.empty(nws, device=rt.device, dtype=torch.float64)
+            w = torch.empty(t, k, device=rt.device, dtype=torch.float64)
+            check(L.gpamd_precond_coef_f32f64(B._ptr(rt), rt.stride(0), t, B._ptr(q1t), q1t.stride(0), k, n, B._ptr(w), B._ptr(ws), nws,
+                                              B._stream(rt.device)), "precond_coef")
+        else:
+            w = r64 @ q1t.t()
         if self.reduce is not None:
             self.reduce(w)
         z = torch.addmm(r64, w, q1t, alpha=-1.0)

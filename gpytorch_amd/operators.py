@@ -199,7 +199,13 @@ class LinearOperator:
         return RootLinearOperator((w.t() @ Q)[:, :n].t().contiguous().to(self.dtype))
 
     def zero_mean_mvn_samples(self, num_samples: int) -> torch.Tensor:
-        """``LinearOperator.zero_mean_mvn_samples``: [num_samples, n] draws of N(0, self) through a root decomposition."""
+        """``LinearOperator.zero_mean_mvn_samples``: [num_samples, n] draws of N(0, self) through a root decomposition, or --
+        ``settings.ciq_samples`` -- as K^{1/2} eps by contour-integral quadrature (no root is ever formed)."""
+        if settings.ciq_samples.on():
+            from .ciq import sqrt_matmul
+
+            eps = torch.randn(self.shape[-1], num_samples, device=self.device, dtype=self.dtype)
+            return sqrt_matmul(self, eps).t()
         root = self.root_decomposition().root
         eps = torch.randn(root.shape[-1], num_samples, device=root.device, dtype=root.dtype)
         return (root @ eps).t()

@@ -221,6 +221,16 @@ class fast_pred_samples(_feature_flag):
     _default = False
 
 
+class num_contour_quadrature(_value_context):
+    """``linear_operator.settings.num_contour_quadrature``: quadrature points of the CIQ rule (default 15)."""
+    _global_value = 15
+
+
+class ciq_samples(_feature_flag):
+    """``gpytorch/settings.py`` ciq_samples: draw MVN samples as mu + K^{1/2} eps through contour-integral quadrature."""
+    _default = False
+
+
 class cholesky_jitter(_dtype_value_context):
     _global_float_value = 1e-6
     _global_double_value = 1e-8

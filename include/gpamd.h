@@ -166,6 +166,14 @@ int gpamd_lanczos_coef_f32(const float* part, int k, int nb, float tol, float* c
 int gpamd_lanczos_subtract_f32(const float* Q, int64_t ldq, int k, const float* coef, float* r, int n, float* part_rr, void* stream);
 int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* out, float* norm_out, float tiny, int* stop, void* stream);
 
+/* ---- pivoted-Cholesky preconditioner apply, first half:  W[c][m] = sum_i R[c][i] * Q1[m][i]  with R float32 [t][ldr] (the CG
+ * residuals), Q1 float64 [k][ldq] (k <= 128), W float64 [t][k], float64 accumulation -- the k x t coefficients of
+ * AddedDiagLinearOperator._preconditioner's closure  P^-1 R = (R - Q1 Q1^T R) / sigma^2, whose cancellation float32 cannot carry
+ * (gpytorch_amd/linear_cg.py).  workspace: double[gpamd_precond_coef_workspace_doubles(n, t, k)]. ---- */
+int64_t gpamd_precond_coef_workspace_doubles(int n, int t, int k);
+int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* Q, int64_t ldq, int k, int n, double* W,
+                              double* workspace, int64_t workspace_doubles, void* stream);
+
 /* ---- fused bilinear derivative: out[0] = sum_ij W_ij k_ij, out[1+q] = sum_ij W_ij dk/ds_ij (z_iq - z_jq)^2,
  * W = Lt^T Rt (never formed).  Replaces LinearOperator._bilinear_derivative on the kernel operator and the
  * dense backward of gpytorch/functions/rbf_covariance.py:26-29 / matern_covariance.py:53-56 (chunked variant:

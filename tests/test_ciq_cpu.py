@@ -1,0 +1,50 @@
+"""CPU: contour-integral quadrature + multi-shift MINRES (gpytorch_amd.ciq; reference entry gpytorch/__init__.py:252-278,
+algorithm of the third-party linear_operator.utils.contour_integral_quad / minres).  The host logic is device-agnostic: here it
+runs on dense float64 matrices and is pinned to eigendecompositions."""
+import torch
+
+from gpytorch_amd.ciq import ciq_weights_shifts, contour_integral_quad, msminres
+
+
+def _spd(n, seed=0, floor=0.05):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(n, n, generator=g, dtype=torch.float64)
+    return A @ A.t() / n + floor * torch.eye(n, dtype=torch.float64)
+
+
+def test_quadrature_rule_reproduces_inverse_square_root():
+    K = _spd(120)
+    ev, U = torch.linalg.eigh(K)
+    ref = U @ torch.diag(ev.rsqrt()) @ U.t()
+    eye = torch.eye(120, dtype=torch.float64)
+    for Q, tol in ((8, 1e-6), (15, 1e-12)):
+        w, s = ciq_weights_shifts(float(ev[0]), float(ev[-1]), Q)
+        assert bool((s > 0).all()) and bool((w > 0).all())
+        approx = sum(wq * torch.linalg.inv(K + sq * eye) for wq, sq in zip(w, s))
+        assert float((approx - ref).norm() / ref.norm()) < tol
+
+
+def test_msminres_solves_every_shifted_system():
+    n = 150
+    K = _spd(n, 1)
+    b = torch.randn(4, n, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    shifts = torch.tensor([0.0, 0.01, 0.3, 5.0, 80.0], dtype=torch.float64)
+    X, it = msminres(lambda v: v @ K, b, shifts, n, tol=1e-10, max_iter=500)
+    eye = torch.eye(n, dtype=torch.float64)
+    for q, sq in enumerate(shifts):
+        ref = torch.linalg.solve(K + sq * eye, b.t()).t()
+        assert float((X[q] - ref).norm() / ref.norm()) < 1e-8
+    assert it <= n + 5
+
+
+def test_contour_integral_quad_with_estimated_bounds():
+    n = 200
+    K = _spd(n, 3)
+    ev, U = torch.linalg.eigh(K)
+    b = torch.randn(3, n, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    res, info = contour_integral_quad(lambda v: v @ K, b, n, tol=1e-9)
+    ref = b @ (U @ torch.diag(ev.rsqrt()) @ U.t())
+    assert float((res - ref).norm() / ref.norm()) < 1e-6, info
+    res2, _ = contour_integral_quad(lambda v: v @ K, b, n, inverse=False, tol=1e-9)
+    ref2 = b @ (U @ torch.diag(ev.sqrt()) @ U.t())
+    assert float((res2 - ref2).norm() / ref2.norm()) < 1e-6

@@ -504,3 +504,34 @@ def test_fantasy_model_updates_love_cache_and_sampling(dev):
     assert float((smp.mean(0) - mu).abs().max()) < 0.06 * float(var.max().sqrt()) + 0.02
     rel_var = (smp.var(0) - var).abs() / var
     assert float(rel_var.mean()) < 0.06 and float(rel_var.max()) < 0.25
+
+
+def test_sqrt_inv_matmul_ciq_on_the_fused_operator(dev):
+    """``gpytorch.sqrt_inv_matmul`` (gpytorch/__init__.py:252-278) = contour-integral quadrature + msMINRES
+    over the fused K*V, against the dense float64 eigendecomposition; and MVN sampling through K^{1/2} eps (``ciq_samples``)."""
+    import gpytorch_amd as g
+
+    n, d = 1500, 2
+    X, y = make_data(n, d)
+    kern = g.kernels.ScaleKernel(g.kernels.RBFKernel()).to(dev)
+    kern.base_kernel.lengthscale = 0.3
+    kern.outputscale = 1.3
+    op = kern(X.float().to(dev)).add_jitter(0.2)
+    Kh = 1.3 * OK.rbf(X, X, 0.3, x1_eq_x2=True, direct=True) + 0.2 * torch.eye(n, dtype=torch.float64)
+    ev, U = torch.linalg.eigh(Kh)
+    rhs = torch.randn(n, 3, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    with g.settings.max_cholesky_size(0):
+        out = g.sqrt_inv_matmul(op, rhs.float().to(dev))
+    ref = (U @ torch.diag(ev.rsqrt()) @ U.t()) @ rhs
+    assert rel_err(out, ref) < 2e-3
+    lhs = torch.randn(5, n, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    res, iq = g.sqrt_inv_matmul(op, rhs.float().to(dev), lhs.float().to(dev))
+    assert rel_err(res, lhs @ ref) < 3e-3
+    assert rel_err(iq, (lhs @ (U @ torch.diag(1.0 / ev) @ U.t()) * lhs).sum(-1)) < 5e-3
+    mvn = g.distributions.MultivariateNormal(torch.zeros(n, device=dev), op)
+    with g.settings.ciq_samples():
+        torch.manual_seed(0)
+        smp = mvn.rsample(torch.Size([3000]))
+    emp = (smp.double().cpu().t() @ smp.double().cpu()) / 3000
+    assert float((emp.diagonal() - Kh.diagonal()).abs().max() / Kh.diagonal().max()) < 0.15
+    assert float((emp - Kh).norm() / Kh.norm()) < 0.12

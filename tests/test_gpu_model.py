@@ -212,3 +212,44 @@ def test_kernel_matmul_autograd(dev):
     c_ls, c_os = 1 - math.exp(-0.3), 1 - math.exp(-1.4)
     assert abs(float(k.base_kernel.raw_lengthscale.grad) - float(ls.grad) * c_ls) < 1e-3 * abs(float(ls.grad) * c_ls)
     assert abs(float(k.raw_outputscale.grad) - float(os_.grad) * c_os) < 1e-3 * abs(float(os_.grad) * c_os)
+
+
+def test_fused_prediction_caches_equal_separate_caches(dev):
+    """fast_pred_var with both caches missing: the mean-cache CG and the LOVE Lanczos run share two-column kernel products
+    (FusedKernelAddedDiagLinearOperator.solve_and_root_inv).  Same mean cache (same algorithm, same iteration count) and the
+    same predictive variances as the separately computed caches, and both within the reference's LOVE tolerance of the dense
+    posterior (exact_prediction_strategies.py:267-321; 5 %: test_simple_gp_regression.py:396-442)."""
+    kind, n, d, ls = "rbf", 3000, 3, 0.25
+    X, y = make_data(n + 200, d)
+    Xt, yt, Xs = X[:n], y[:n], X[n:]
+    S_ = None
+    out = {}
+    for mode in ("fused", "separate"):
+        g, m, lik = _model(kind, Xt, yt, ls, 1.0, 0.2, dev)
+        S_ = g.settings
+        m.eval()
+        lik.eval()
+        torch.manual_seed(3)
+        with torch.no_grad(), S_.max_cholesky_size(0), S_.fast_pred_var(), S_.eval_cg_tolerance(1e-4), S_.max_preconditioner_size(15), \
+                S_.min_preconditioning_size(100), S_.max_root_decomposition_size(300):
+            if mode == "separate":
+                from gpytorch_amd import linear_cg as LCG
+
+                with S_.fast_pred_var(False), S_.skip_posterior_variances():
+                    _ = m(Xs.float().to(dev)).mean                   # builds the mean cache alone (plain one-column solve)
+                out["separate_iters"] = LCG.LAST_INFO.iterations
+                assert m.prediction_strategy._covar_cache is None     # the LOVE cache follows from its own Lanczos run below
+            pred = m(Xs.float().to(dev))
+            out[mode] = (pred.mean.double().cpu(), pred.variance.double().cpu(), m.prediction_strategy._mean_cache.double().cpu())
+            if mode == "fused":
+                from gpytorch_amd import linear_cg as LCG
+
+                out["fused_iters"] = LCG.LAST_INFO.iterations
+                assert m.prediction_strategy._covar_cache is not None
+    assert abs(out["fused_iters"] - out["separate_iters"]) <= 2
+    assert rel_err(out["fused"][2], out["separate"][2]) < 1e-4
+    assert rel_err(out["fused"][0], out["separate"][0]) < 1e-4
+    mu_ref, var_ref = OG.dense_posterior(kind, Xt, yt, Xs, ls, 1.0, 0.2, mean=0.0, noise=False)
+    for mode in ("fused", "separate"):
+        assert rel_err(out[mode][0], mu_ref) < 1e-3
+        assert float(((out[mode][1] - var_ref).abs() / var_ref).max()) < 0.05, mode
