@@ -793,7 +793,8 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         kernels, CG branch for both, no row sharding."""
         p1, _ = self.kernel_op.prepared()
         return (p1.fused and not self._use_cholesky(settings.fast_computations.solves)
-                and not self._use_cholesky(settings.fast_computations.covar_root_decomposition) and self._row_shard() is None)
+                and not self._use_cholesky(settings.fast_computations.covar_root_decomposition) and self._row_shard() is None
+                and settings.max_root_decomposition_size.value() <= 512)  # (gpamd_lanczos_* kernels: k <= 512)
 
     def solve_and_root_inv(self, rhs: torch.Tensor):
         """(K_hat^-1 rhs, root of K_hat^-1) -- the mean cache and the LOVE covariance cache of

@@ -247,8 +247,9 @@ def test_fused_prediction_caches_equal_separate_caches(dev):
                 out["fused_iters"] = LCG.LAST_INFO.iterations
                 assert m.prediction_strategy._covar_cache is not None
     assert abs(out["fused_iters"] - out["separate_iters"]) <= 2
-    assert rel_err(out["fused"][2], out["separate"][2]) < 1e-4
-    assert rel_err(out["fused"][0], out["separate"][0]) < 1e-4
+    # (both are eval_cg_tolerance = 1e-4 solutions of the same system from different product kernels: t = 2 vs t = 1)
+    assert rel_err(out["fused"][2], out["separate"][2]) < 5e-4
+    assert rel_err(out["fused"][0], out["separate"][0]) < 5e-4
     mu_ref, var_ref = OG.dense_posterior(kind, Xt, yt, Xs, ls, 1.0, 0.2, mean=0.0, noise=False)
     for mode in ("fused", "separate"):
         assert rel_err(out[mode][0], mu_ref) < 1e-3
