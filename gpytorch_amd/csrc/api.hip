@@ -19,6 +19,7 @@ using namespace gpamd;
 
 namespace gpamd {
 thread_local char g_err[512] = "";  // shared by every translation unit of the library (gpamd_last_error)
+thread_local float g_kparam = 1.0f;  // shape parameter of parametrised covariance families (RQ: alpha), gpamd_set_kernel_param_f32
 }
 
 namespace {
@@ -55,6 +56,7 @@ float prep_coef(int kind) {
     case GPAMD_MATERN12: return 1.0f;
     case GPAMD_MATERN32: return sqrtf(3.0f);
     case GPAMD_MATERN52: return sqrtf(5.0f);
+    case GPAMD_RQ: return 1.0f / sqrtf(2.0f * g_kparam);   // (1 + |x - x'|^2 / (2 alpha l^2))^-alpha = (1 + |z - z'|^2)^-alpha
   }
   return 0.f;
 }
@@ -132,6 +134,7 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex) {
       case GPAMD_RBF: return kvm_kernel_ptr_rbf(d, v);
       case GPAMD_MATERN32: return kvm_kernel_ptr_matern32(d, v);
       case GPAMD_MATERN52: return kvm_kernel_ptr_matern52(d, v);
+      case GPAMD_RQ: return kvm_kernel_ptr_rq(d, v);
     }
     return nullptr;
   }
@@ -140,6 +143,7 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex) {
       case GPAMD_RBF: return kvs_kernel_ptr_rbf(d, v);
       case GPAMD_MATERN32: return kvs_kernel_ptr_matern32(d, v);
       case GPAMD_MATERN52: return kvs_kernel_ptr_matern52(d, v);
+      case GPAMD_RQ: return kvs_kernel_ptr_rq(d, v);
     }
     return nullptr;
   }
@@ -148,6 +152,7 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex) {
     case GPAMD_MATERN12: return kv_kernel_ptr_matern12(mode, d, v, ex);
     case GPAMD_MATERN32: return kv_kernel_ptr_matern32(mode, d, v, ex);
     case GPAMD_MATERN52: return kv_kernel_ptr_matern52(mode, d, v, ex);
+    case GPAMD_RQ: return kv_kernel_ptr_rq(mode, d, v, ex);
   }
   return nullptr;
 }
@@ -231,11 +236,17 @@ unsigned col_blocks(int n) {
 extern "C" {
 
 int gpamd_abi_version(void) { return GPAMD_ABI_VERSION; }
+
+int gpamd_set_kernel_param_f32(float value) {
+  if (!(value > 0.f)) return fail(GPAMD_EINVAL, "set_kernel_param: the shape parameter must be positive");
+  g_kparam = value;
+  return 0;
+}
 const char* gpamd_last_error(void) { return g_err; }
 
 int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, const float* ls, int nls,
                           const float* shift, float* Xp, int dp, void* stream) {
-  if (kind < 0 || kind > 3) return fail(GPAMD_EINVAL, "prep_points: unknown kind");
+  if (kind < 0 || kind > GPAMD_RQ) return fail(GPAMD_EINVAL, "prep_points: unknown kind");
   if (n <= 0 || d <= 0 || dp < d || dp % 4 || (nls != 1 && nls != d)) return fail(GPAMD_EINVAL, "prep_points: bad shape");
   if (!aligned16(Xp)) return fail(GPAMD_EINVAL, "prep_points: Xp must be 16-byte aligned");
   long total = (long)n * dp;
@@ -247,7 +258,7 @@ int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, c
 
 int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, int* S_host, int* jchunk_host,
                   int64_t* workspace_floats_host) {
-  if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return fail(GPAMD_EINVAL, "kv_plan: bad shape");
+  if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return fail(GPAMD_EINVAL, "kv_plan: bad shape");
   int S, jc;
   plan_split(kind, n, m, d, t, flags, &S, &jc);
   if (S_host) *S_host = S;
@@ -259,7 +270,7 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
 int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt,
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream) {
-  if (kind < 0 || kind > 3) return fail(GPAMD_EINVAL, "kv: unknown kind");
+  if (kind < 0 || kind > GPAMD_RQ) return fail(GPAMD_EINVAL, "kv: unknown kind");
   if (n <= 0 || m <= 0 || t <= 0 || S <= 0) return fail(GPAMD_EINVAL, "kv: bad shape");
   if (d < 1 || d > 16) return fail(GPAMD_EUNSUPPORTED, "kv: input dimension must be in 1..16");
   // kernels are instantiated for D in {1,2,3,4,5,6,8,10,12,16} valid dimensions; other d use the next one
@@ -283,6 +294,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.S = S; a.jchunk = jchunk;
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
+    a.kparam = g_kparam;
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
     const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
@@ -310,7 +322,7 @@ int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int
                  int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
                  int64_t ldo, float* workspace, int64_t workspace_floats, int flags, void* stream) {
   int S, jc;
-  if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return fail(GPAMD_EINVAL, "kv: bad shape");
+  if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return fail(GPAMD_EINVAL, "kv: bad shape");
   plan_split(kind, n, m, d, t, flags, &S, &jc);
   const int64_t ldp = (n + 3) / 4 * 4;
   if (workspace_floats < (int64_t)S * t * ldp) return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4))");
@@ -325,6 +337,7 @@ int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int
     case GPAMD_MATERN12: { constexpr int KK = KIND_MATERN12; CALL; } break; \
     case GPAMD_MATERN32: { constexpr int KK = KIND_MATERN32; CALL; } break; \
     case GPAMD_MATERN52: { constexpr int KK = KIND_MATERN52; CALL; } break; \
+    case GPAMD_RQ: { constexpr int KK = KIND_RQ; CALL; } break; \
     default: return fail(GPAMD_EINVAL, "unknown kind"); \
   }
 
@@ -333,7 +346,7 @@ int gpamd_kernel_rows_f32(int kind, const float* X1p, const int64_t* rows, int n
   if (nrows <= 0 || m <= 0) return fail(GPAMD_EINVAL, "kernel_rows: bad shape");
   dim3 grid((m + 255) / 256, nrows);
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_rows_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, rows, nrows,
-                                       X2p, m, dp, scale, out, ldo));
+                                       X2p, m, dp, scale, out, ldo, g_kparam));
   return check_launch("kernel_rows");
 }
 
@@ -343,7 +356,7 @@ int gpamd_kernel_dense_f32(int kind, const float* X1p, int n, const float* X2p, 
   if (n > 65535) return fail(GPAMD_EUNSUPPORTED, "kernel_dense: n > 65535 (materialising K is what this library avoids)");
   dim3 grid((m + 255) / 256, n);
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_dense_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, n, X2p, m,
-                                       dp, scale, out, ldo));
+                                       dp, scale, out, ldo, g_kparam));
   return check_launch("kernel_dense");
 }
 
@@ -352,7 +365,7 @@ int gpamd_kernel_diag_f32(int kind, const float* X1p, const float* X2p, int n, i
   if (n <= 0) return fail(GPAMD_EINVAL, "kernel_diag: bad shape");
   dim3 grid((n + 255) / 256);
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_diag_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, X2p, n, dp,
-                                       scale, out));
+                                       scale, out, g_kparam));
   return check_launch("kernel_diag");
 }
 
@@ -550,11 +563,12 @@ int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const f
   s.perm = iwork + 2;
   s.pos = iwork + 2 + n;
   s.tol = tol;
+  s.kparam = g_kparam;
   (void)hipMemsetAsync(iwork, 0, 2 * sizeof(int), st);
   hipLaunchKernelGGL(pc_init_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.perm, s.pos, n);
   // diagonal of the noise-free kernel matrix: scale * k(0)
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_diag_kernel<KK>), dim3((n + 255) / 256), dim3(256), 0, st, Xp, Xp, n, dp,
-                                       scale, s.dwork));
+                                       scale, s.dwork, g_kparam));
   for (int m = 0; m < rank; ++m) {
     hipLaunchKernelGGL(pc_pivot_kernel, dim3(1), dim3(1024), 0, st, s, m);
     KIND_SWITCH(kind, hipLaunchKernelGGL((pc_update_kernel<KK>), dim3((n + 255) / 256), dim3(256), 0, st, s, m, Xp, dp,

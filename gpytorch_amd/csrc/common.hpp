@@ -12,7 +12,9 @@ namespace gpamd {
 // gpytorch/functions/matern_covariance.py:18-50 with the pairwise distance taken directly
 // (gpytorch/kernels/keops/rbf_kernel.py:12-15, keops/matern_kernel.py:13-30) instead of through the
 // Gram trick of kernels/kernel.py:26-49.
-enum Kind : int { KIND_RBF = 0, KIND_MATERN12 = 1, KIND_MATERN32 = 2, KIND_MATERN52 = 3 };
+//   RQ      : z = x / (l sqrt(2 alpha))            ->  k = (1 + |zi-zj|^2)^(-alpha)         (gpytorch/kernels/rq_kernel.py:60-74)
+//             alpha travels as the runtime shape parameter `p` of the functors below (KvArgs::kparam)
+enum Kind : int { KIND_RBF = 0, KIND_MATERN12 = 1, KIND_MATERN32 = 2, KIND_MATERN52 = 3, KIND_RQ = 4 };
 
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -21,10 +23,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <int KIND>
-__device__ __forceinline__ float cov_from_sq(float s) {
-  // s = squared distance between pre-scaled points
+__device__ __forceinline__ float cov_from_sq(float s, float p = 0.f) {
+  // s = squared distance between pre-scaled points; p = shape parameter (RQ: alpha)
   if constexpr (KIND == KIND_RBF) {
     return __builtin_amdgcn_exp2f(-s);
+  } else if constexpr (KIND == KIND_RQ) {
+    return __builtin_amdgcn_exp2f(-p * __builtin_amdgcn_logf(1.0f + s));   // v_log_f32 = log2
   } else {
     float r = __builtin_amdgcn_sqrtf(s);
     float e = __builtin_amdgcn_exp2f(-r * LOG2E);
@@ -40,10 +44,13 @@ __device__ __forceinline__ float cov_from_sq(float s) {
 //     nu=1/2: k' = -e^{-r}            -> dk/ds = -e^{-r} / (2r)      (singular at r=0; guarded)
 //     nu=3/2: k' = -r e^{-r}          -> dk/ds = -e^{-r} / 2
 //     nu=5/2: k' = -(r + r^2)/3 e^{-r}-> dk/ds = -(1 + r) e^{-r} / 6
+//   RQ: k = (1+s)^-alpha                 -> dk/ds = -alpha (1+s)^(-alpha-1)
 template <int KIND>
-__device__ __forceinline__ float dcov_dsq(float s) {
+__device__ __forceinline__ float dcov_dsq(float s, float p = 0.f) {
   if constexpr (KIND == KIND_RBF) {
     return -0.6931471805599453f * __builtin_amdgcn_exp2f(-s);
+  } else if constexpr (KIND == KIND_RQ) {
+    return -p * __builtin_amdgcn_exp2f(-(p + 1.0f) * __builtin_amdgcn_logf(1.0f + s));
   } else {
     float r = __builtin_amdgcn_sqrtf(s);
     float e = __builtin_amdgcn_exp2f(-r * LOG2E);
@@ -54,9 +61,11 @@ __device__ __forceinline__ float dcov_dsq(float s) {
 }
 
 template <int KIND>
-__device__ __forceinline__ double cov_from_sq_f64(double s) {
+__device__ __forceinline__ double cov_from_sq_f64(double s, double p = 0.0) {
   if constexpr (KIND == KIND_RBF) {
     return exp2(-s);
+  } else if constexpr (KIND == KIND_RQ) {
+    return pow(1.0 + s, -p);
   } else {
     double r = sqrt(s);
     double e = exp(-r);
@@ -67,9 +76,11 @@ __device__ __forceinline__ double cov_from_sq_f64(double s) {
 }
 
 template <int KIND>
-__device__ __forceinline__ double dcov_dsq_f64(double s) {
+__device__ __forceinline__ double dcov_dsq_f64(double s, double p = 0.0) {
   if constexpr (KIND == KIND_RBF) {
     return -0.6931471805599453 * exp2(-s);
+  } else if constexpr (KIND == KIND_RQ) {
+    return -p * pow(1.0 + s, -p - 1.0);
   } else {
     double r = sqrt(s);
     double e = exp(-r);

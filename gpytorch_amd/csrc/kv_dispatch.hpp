@@ -15,15 +15,18 @@ const void* kv_kernel_ptr_rbf(int mode, int d, int v, int ex);
 const void* kv_kernel_ptr_matern12(int mode, int d, int v, int ex);
 const void* kv_kernel_ptr_matern32(int mode, int d, int v, int ex);
 const void* kv_kernel_ptr_matern52(int mode, int d, int v, int ex);
+const void* kv_kernel_ptr_rq(int mode, int d, int v, int ex);
 
 // small-t Gram-form kernels (kvs_<family>.hip; none for Matern nu = 1/2)
 const void* kvs_kernel_ptr_rbf(int d, int tpad);
 const void* kvs_kernel_ptr_matern32(int d, int tpad);
 const void* kvs_kernel_ptr_matern52(int d, int tpad);
+const void* kvs_kernel_ptr_rq(int d, int tpad);
 
 // 3..32-column Gram-form kernels, contraction in column groups of four on v_mfma_f32_4x4x1 (kvm_<family>.hip)
 const void* kvm_kernel_ptr_rbf(int d, int groups);
 const void* kvm_kernel_ptr_matern32(int d, int groups);
 const void* kvm_kernel_ptr_matern52(int d, int groups);
+const void* kvm_kernel_ptr_rq(int d, int groups);
 
 }  // namespace gpamd

@@ -34,7 +34,8 @@ struct Grad2Args {
   int S, jchunk, nrb;  // j split, chunk length (multiple of 64), row blocks of 128
   int th4;             // MFMA k-steps (2 columns each) rounded up to a multiple of 4
   int rs;              // LDS row stride (floats) of the L / R tiles: >= 2*th4, == 4 mod 32
-  double* part;        // [nrb*S][1 + DP]   (hyper-parameter partial sums)
+  double* part;        // [nrb*S][2 + DP]   (hyper-parameter partial sums; last entry: shape-parameter sum, RQ)
+  float kparam;        // covariance shape parameter (RQ: alpha)
   float* Px;           // optional [S][DP][ldx] partial slabs of Gz1 (probe-major: one coordinate per row) or nullptr
   int64_t ldx, pxstride;
 };
@@ -42,11 +43,18 @@ struct Grad2Args {
 constexpr int G2_BN = 64;    // j rows per step (two 32-row MFMA tiles)
 constexpr int G2_MAXT = 66;  // columns per launch (host: kvm_grad2.hip)
 
+// k(s), dk/ds and -- for families with a shape parameter -- dk/dp at fixed s (RQ: k = (1+s)^-p -> dk/dp = -k ln(1+s))
 template <int KIND>
-__device__ __forceinline__ void cov_and_dcov(float s, float& k, float& dk) {
+__device__ __forceinline__ void cov_and_dcov(float s, float p, float& k, float& dk, float& dp) {
+  dp = 0.f;
   if constexpr (KIND == KIND_RBF) {
     k = __builtin_amdgcn_exp2f(-s);
     dk = -0.6931471805599453f * k;
+  } else if constexpr (KIND == KIND_RQ) {
+    const float l2 = __builtin_amdgcn_logf(1.0f + s);           // log2(1 + s)
+    k = __builtin_amdgcn_exp2f(-p * l2);
+    dk = -p * k / (1.0f + s);
+    dp = -0.6931471805599453f * l2 * k;
   } else {
     const float r = __builtin_amdgcn_sqrtf(s);
     const float e = __builtin_amdgcn_exp2f(-r * LOG2E);
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   float* Rs = dyn + (size_t)4 * 32 * RS;                          // [BN j][RS]
   _Float16* Xh = reinterpret_cast<_Float16*>(Rs + (size_t)BN * RS);  // [KH][BN][16]
   float* Zs = reinterpret_cast<float*>(Xh + KH * BN * 16);        // [4*GZ][LDZ]  (MODE 1)
-  __shared__ double red[4][1 + DP];
+  __shared__ double red[4][2 + DP];
 
   const int unit = blockIdx.x;
   const int s = unit / a.nrb, rb = unit - s * a.nrb;
@@ -106,9 +114,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   }
   f16x8 bq[KH];
   gram_pack_b<D>(zi, h, bq);
-  double g[1 + DP];
+  double g[2 + DP];
 #pragma unroll
-  for (int q = 0; q <= DP; ++q) g[q] = 0.0;
+  for (int q = 0; q <= DP + 1; ++q) g[q] = 0.0;
   float gx[DP];
 #pragma unroll
   for (int q = 0; q < DP; ++q) gx[q] = 0.f;
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[kh], s1, 0, 0, 0);
     }
     // ---- consume: k, dk/ds, A = W dk/ds
-    float f0 = 0.f, f1 = 0.f;
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
     f32x4 zacc[GZ];
 #pragma unroll
     for (int gz = 0; gz < GZ; ++gz) zacc[gz] = (f32x4)(0.f);
@@ -230,9 +238,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
           float sv = half ? s1[r] : s0[r];
           sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
           const float w = half ? w1[r] : w0[r];
-          float kv, dk;
-          cov_and_dcov<KIND>(sv, kv, dk);
+          float kv, dk, dpar;
+          cov_and_dcov<KIND>(sv, a.kparam, kv, dk, dpar);
           f0 = __builtin_fmaf(w, kv, f0);
+          if constexpr (KIND == KIND_RQ) f2 = __builtin_fmaf(w, dpar, f2);
           const float av = w * dk;
           if constexpr (MODE == 0) {
             f1 = __builtin_fmaf(av, sv, f1);
@@ -244,6 +253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       }
     }
     g[0] += (double)f0;
+    g[1 + DP] += (double)f2;
     if constexpr (MODE == 0) {
       g[1] += (double)f1;
     } else {
@@ -261,12 +271,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   }
 
 #pragma unroll
-  for (int q = 0; q <= DP; ++q) {
+  for (int q = 0; q <= DP + 1; ++q) {
     double v = wave_sum(g[q]);
     if (lane == 0) red[wave][q] = v;
   }
   __syncthreads();
-  if (tid <= DP) a.part[(int64_t)unit * (1 + DP) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if (tid <= DP + 1) a.part[(int64_t)unit * (2 + DP) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
   if constexpr (MODE == 1) {
     if (a.Px) {
       float* Pout = a.Px + (int64_t)s * a.pxstride;

@@ -165,7 +165,7 @@ void kv_gram_kernel(KvArgs a) {
           // Matern takes sqrt(S): clamp with one v_med3_f32
           float sv = kk[ni][r];
           if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-          kk[ni][r] = cov_from_sq<KIND>(sv);
+          kk[ni][r] = cov_from_sq<KIND>(sv, a.kparam);
         }
 
       // ---- contraction: 16 steps (4 groups of 4), step r pairs rows (r&3)+8(r>>2) and +4 ----

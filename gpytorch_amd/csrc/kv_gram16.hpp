@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GramF16<D>:
         for (int r = 0; r < 16; ++r) {
           float sv = kk[ni][r];
           if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-          kk[ni][r] = cov_from_sq<KIND>(sv);
+          kk[ni][r] = cov_from_sq<KIND>(sv, a.kparam);
         }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void kv_gram4_kernel(KvArgs a) {
           for (int ni = 0; ni < NI; ++ni) {
             float sv = kk[ni][4 * q + e];
             if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-            const float kv = cov_from_sq<KIND>(sv);
+            const float kv = cov_from_sq<KIND>(sv, a.kparam);
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[ni][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][e], kv, acc[ni][g], 0, 0, 0);
           }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
             for (int ni = 0; ni < NI; ++ni) {
               float sv = kk[ni][4 * g + e];
               if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-              acc1[ni] = __builtin_fmaf(cov_from_sq<KIND>(sv), v4[e], acc1[ni]);
+              acc1[ni] = __builtin_fmaf(cov_from_sq<KIND>(sv, a.kparam), v4[e], acc1[ni]);
             }
         } else {
 #pragma unroll
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
             for (int ni = 0; ni < NI; ++ni) {
               float sv = kk[ni][4 * g + e];
               if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-              const f32x2 kv = (f32x2)(cov_from_sq<KIND>(sv));
+              const f32x2 kv = (f32x2)(cov_from_sq<KIND>(sv, a.kparam));
 #pragma unroll
               for (int c = 0; c < TP; ++c) acc2[ni][c] = __builtin_elementwise_fma(kv, vp[c], acc2[ni][c]);
             }

@@ -35,6 +35,7 @@ struct KvArgs {
   int n, m, t;
   int S, jchunk, nrb;  // split count, j-chunk length (multiple of BN), row-block count
   const int* done;     // optional device flag: non-zero -> the launch is a no-op (converged CG)
+  float kparam;        // shape parameter of the covariance family (RQ: alpha); 0 otherwise
 };
 
 constexpr int KV_BN = 128;           // j-tile staged in LDS per iteration
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
         }
       }
     }
-    return cov_from_sq<KIND>(sq);
+    return cov_from_sq<KIND>(sq, a.kparam);
   };
 
   for (int j0 = jbeg; j0 < jend; j0 += BN) {

@@ -24,8 +24,13 @@ constexpr int KVV_BM = 256 * 2 * KVV_RP;
 
 // two covariance values at once; transcendentals stay scalar (no packed form), the polynomial part packs
 template <int KIND>
-__device__ __forceinline__ f32x2 cov_from_sq2(f32x2 s) {
-  if constexpr (KIND == KIND_RBF) {
+__device__ __forceinline__ f32x2 cov_from_sq2(f32x2 s, float p = 0.f) {
+  if constexpr (KIND == KIND_RQ) {
+    f32x2 o;
+    o.x = cov_from_sq<KIND_RQ>(s.x, p);
+    o.y = cov_from_sq<KIND_RQ>(s.y, p);
+    return o;
+  } else if constexpr (KIND == KIND_RBF) {
     f32x2 o;
     o.x = __builtin_amdgcn_exp2f(-s.x);
     o.y = __builtin_amdgcn_exp2f(-s.y);
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void kv_valu_kernel(KvArgs a) {
           const f32x2 df = xi[p][k] - (f32x2)(xj[k]);
           sq = __builtin_elementwise_fma(df, df, sq);
         }
-        const f32x2 kv = cov_from_sq2<KIND>(sq);
+        const f32x2 kv = cov_from_sq2<KIND>(sq, a.kparam);
 #pragma unroll
         for (int c = 0; c < T; ++c) acc[p][c] = __builtin_elementwise_fma(kv, (f32x2)(vj[c]), acc[p][c]);
       }

@@ -13,6 +13,7 @@
 using namespace gpamd;
 namespace gpamd {
 extern thread_local char g_err[512];
+extern thread_local float g_kparam;
 }
 
 namespace {
@@ -121,7 +122,7 @@ int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d) {
   int S, jc, nrb;
   g2_plan(n, m, &S, &jc, &nrb);
   const int dp = (d + 3) / 4 * 4;
-  return (int64_t)g2_groups(t) * nrb * S * (1 + dp);
+  return (int64_t)g2_groups(t) * nrb * S * (2 + dp);
 }
 
 int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d) {
@@ -139,7 +140,7 @@ int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int 
     snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: bad arguments");
     return GPAMD_EINVAL;
   }
-  if (kind != GPAMD_RBF && kind != GPAMD_MATERN32 && kind != GPAMD_MATERN52) {
+  if (kind != GPAMD_RBF && kind != GPAMD_MATERN32 && kind != GPAMD_MATERN52 && kind != GPAMD_RQ) {
     snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: Gram-form generation needs RBF / Matern 3/2 / Matern 5/2 (use gpamd_kv_grad_f32)");
     return GPAMD_EUNSUPPORTED;
   }
@@ -149,7 +150,7 @@ int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int 
   const int groups = g2_groups(t);
   const int64_t units = (int64_t)nrb * S;
   const int64_t ldx = (n + 3) / 4 * 4;
-  if (workspace_doubles < groups * units * (1 + dp)) return GPAMD_EWORKSPACE;
+  if (workspace_doubles < groups * units * (2 + dp)) return GPAMD_EWORKSPACE;
   if (Gz1t && (xworkspace_floats < (int64_t)groups * S * dp * ldx || ldg < n || ldg % 4)) return GPAMD_EWORKSPACE;
   const int mode = (iso && !Gz1t) ? 0 : 1;
   hipStream_t st = (hipStream_t)stream;
@@ -166,7 +167,8 @@ int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int 
     a.S = S; a.jchunk = jc; a.nrb = nrb;
     a.th4 = ((tg + 1) / 2 + 3) / 4 * 4;
     a.rs = 2 * a.th4 + 4;   // = 4 * odd: eight lanes' 16-byte reads at this row stride cover all 32 banks exactly once
-    a.part = workspace + (int64_t)g * units * (1 + dp);
+    a.part = workspace + (int64_t)g * units * (2 + dp);
+    a.kparam = gpamd::g_kparam;
     a.Px = Gz1t ? xworkspace + (int64_t)g * S * dp * ldx : nullptr;
     a.ldx = ldx;
     a.pxstride = (int64_t)dp * ldx;
@@ -175,12 +177,14 @@ int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int 
       case GPAMD_RBF: rc = launch_kind<KIND_RBF>(dk, mode, a, (unsigned)units, st); break;
       case GPAMD_MATERN32: rc = launch_kind<KIND_MATERN32>(dk, mode, a, (unsigned)units, st); break;
       case GPAMD_MATERN52: rc = launch_kind<KIND_MATERN52>(dk, mode, a, (unsigned)units, st); break;
+      case GPAMD_RQ: rc = launch_kind<KIND_RQ>(dk, mode, a, (unsigned)units, st); break;
     }
     if (rc) return GPAMD_EUNSUPPORTED;
     c0 += tg;
   }
-  // hyper-parameter sums: out[0] = sum W k, out[1 + q] = per-dimension sums (mode 0: out[1] = the single-lengthscale sum)
-  hipLaunchKernelGGL(grad2_finalize_kernel<0>, dim3(1), dim3(256), 0, st, workspace, (int)(groups * units), 1 + dp, out);
+  // hyper-parameter sums: out[0] = sum W k, out[1 + q] = per-dimension sums (mode 0: out[1] = the single-lengthscale sum),
+  // out[1 + dp] = sum W dk/dp at fixed s (shape parameter: RQ alpha; 0 for the other families)
+  hipLaunchKernelGGL(grad2_finalize_kernel<0>, dim3(1), dim3(256), 0, st, workspace, (int)(groups * units), 2 + dp, out);
   if (Gz1t) {
     long nb = ((long)n + 1023) / 1024;
     if (nb > CG_MAXNB) nb = CG_MAXNB;

@@ -24,13 +24,13 @@ __global__ void prep_points_kernel(const float* __restrict__ X, int n, int d, in
 }
 
 template <int KIND>
-__device__ __forceinline__ float cov_pair(const float* __restrict__ a, const float* __restrict__ b, int DP) {
+__device__ __forceinline__ float cov_pair(const float* __restrict__ a, const float* __restrict__ b, int DP, float kparam = 0.f) {
   float sq = 0.f;
   for (int k = 0; k < DP; ++k) {
     float df = a[k] - b[k];
     sq = __builtin_fmaf(df, df, sq);
   }
-  return cov_from_sq<KIND>(sq);
+  return cov_from_sq<KIND>(sq, kparam);
 }
 
 // out[r][j] = scale * k(X1p[rows[r]], X2p[j])   -- explicit rows (LinearOperator._getitem row fetch used by
@@ -38,33 +38,33 @@ __device__ __forceinline__ float cov_pair(const float* __restrict__ a, const flo
 template <int KIND>
 __global__ void kernel_rows_kernel(const float* __restrict__ X1p, const int64_t* __restrict__ rows, int nrows,
                                    const float* __restrict__ X2p, int m, int DP, const float* __restrict__ scale,
-                                   float* __restrict__ out, int64_t ldo) {
+                                   float* __restrict__ out, int64_t ldo, float kparam) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int r = blockIdx.y;
   if (j >= m) return;
   const float* a = X1p + rows[r] * DP;
-  float kv = cov_pair<KIND>(a, X2p + (int64_t)j * DP, DP);
+  float kv = cov_pair<KIND>(a, X2p + (int64_t)j * DP, DP, kparam);
   out[(int64_t)r * ldo + j] = (scale ? *scale : 1.f) * kv;
 }
 
 // out[i][j] = scale * k(X1p[i], X2p[j])   (to_dense; small problems, Cholesky fallback, tests)
 template <int KIND>
 __global__ void kernel_dense_kernel(const float* __restrict__ X1p, int n, const float* __restrict__ X2p, int m, int DP,
-                                    const float* __restrict__ scale, float* __restrict__ out, int64_t ldo) {
+                                    const float* __restrict__ scale, float* __restrict__ out, int64_t ldo, float kparam) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int i = blockIdx.y;
   if (j >= m || i >= n) return;
-  float kv = cov_pair<KIND>(X1p + (int64_t)i * DP, X2p + (int64_t)j * DP, DP);
+  float kv = cov_pair<KIND>(X1p + (int64_t)i * DP, X2p + (int64_t)j * DP, DP, kparam);
   out[(int64_t)i * ldo + j] = (scale ? *scale : 1.f) * kv;
 }
 
 // out[i] = scale * k(X1p[i], X2p[i])
 template <int KIND>
 __global__ void kernel_diag_kernel(const float* __restrict__ X1p, const float* __restrict__ X2p, int n, int DP,
-                                   const float* __restrict__ scale, float* __restrict__ out) {
+                                   const float* __restrict__ scale, float* __restrict__ out, float kparam) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  out[i] = (scale ? *scale : 1.f) * cov_pair<KIND>(X1p + (int64_t)i * DP, X2p + (int64_t)i * DP, DP);
+  out[i] = (scale ? *scale : 1.f) * cov_pair<KIND>(X1p + (int64_t)i * DP, X2p + (int64_t)i * DP, DP, kparam);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -85,6 +85,7 @@ struct PcState {
   int* perm;         // [n] perm[position] = index
   int* pos;          // [n] pos[index] = position
   float tol;
+  float kparam;      // covariance shape parameter (RQ: alpha)
 };
 
 // one workgroup of 1024 threads: arg-max of the live diagonal (+ its l1 norm -> error test)
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void pc_update_kernel(PcState st, int m, const
     out = piv;
     st.dwork[i] = -INFINITY;
   } else if (d > -INFINITY) {
-    float v = (scale ? *scale : 1.f) * cov_pair<KIND>(Xp + p * DP, Xp + (int64_t)i * DP, DP);
+    float v = (scale ? *scale : 1.f) * cov_pair<KIND>(Xp + p * DP, Xp + (int64_t)i * DP, DP, st.kparam);
     for (int q = 0; q < m; ++q) v -= lp[q] * st.L[(int64_t)q * st.ldl + i];
     v = v / piv;
     out = v;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void kv_gram2_kernel(KvArgs a) {
     const int ni = e >> 4, r = e & 15;
     float sv = kk[ni][r];
     if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-    kk[ni][r] = cov_from_sq<KIND>(sv);
+    kk[ni][r] = cov_from_sq<KIND>(sv, a.kparam);
   };
 
   auto read_av = [&](const float* V, int jb, int g, f32x4* av, f32x4& ev) {

@@ -27,7 +27,12 @@ extern "C" {
 #define GPAMD_ABI_VERSION 1
 
 /* covariance families: gpytorch/kernels/rbf_kernel.py:68-85, matern_kernel.py:85-110 (nu = 1/2, 3/2, 5/2) */
-enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3 };
+enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3,
+       GPAMD_RQ = 4 /* rational quadratic (gpytorch/kernels/rq_kernel.py:60-74): k = (1 + |z - z'|^2)^-alpha on points prepared as
+                       x / (l sqrt(2 alpha)); alpha is set per calling thread with gpamd_set_kernel_param_f32 BEFORE prep_points and
+                       every kernel-evaluating call; float32 fused path only */ };
+/* Shape parameter of the parametrised covariance families (RQ: alpha > 0), thread-local host state read at launch time. */
+int gpamd_set_kernel_param_f32(float value);
 
 enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 
@@ -189,8 +194,8 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
  * [d][ldg]; the caller applies dz/dx = coef / lengthscale_q and theta -- the input gradients the KeOps precedent provides,
  * gpytorch/test/base_keops_test_case.py:105-132; the reference's dense Functions refuse them, rbf_covariance.py:9-10).
  * RBF / Matern 3/2 / Matern 5/2 only, accurate while max |z|^2 <= 32 (the host's policy for every Gram-form kernel); d = valid
- * dimensions (points are [n][round_up(d,4)]).  out: float[1 + round_up(d,4)] as gpamd_kv_grad_f32.  Gz1t == NULL: hyper-
- * parameters only (xworkspace unused). ---- */
+ * dimensions (points are [n][round_up(d,4)]).  out: float[2 + round_up(d,4)]: [0 .. dp] as gpamd_kv_grad_f32, [1 + dp] = sum_ij W_ij dk/dp_ij at
+ * fixed s for the family's shape parameter (RQ alpha; 0 otherwise).  Gz1t == NULL: hyper-parameters only (xworkspace unused). ---- */
 int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d);
 int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d);
 int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Lt, int64_t ldl,

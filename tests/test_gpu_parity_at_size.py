@@ -99,7 +99,7 @@ def _true_residual(xp, sc, s2, sol_t, rhs_t):
 def test_c3_end_to_end_preconditioned_mll(dev):
     """BASELINE C3: Matern-5/2, n = 500 000, d = 10, rank-100 pivoted-Cholesky preconditioner, 16 probes + y.
     The reference's training tolerance (cg_tolerance = 1) is reached, the solver's reported residuals are the true
-    ones, the preconditioner does not change the solution of the y column and costs no more than 10 % extra iterations."""
+    ones, the preconditioner does not change the solution of the y column and reduces the iteration counts."""
     import json
     import os
 
@@ -149,9 +149,11 @@ def test_c3_end_to_end_preconditioned_mll(dev):
     with open("gpurun_out/c3_end_to_end.json", "w") as f:
         json.dump(log, f, indent=1)
     assert abs(q["precond100"] - q["noprecond"]) < 2e-3 * abs(q["noprecond"]), q
-    # d = 10 Matern: the spectrum of K decays slowly, a rank-100 pivoted-Cholesky factor captures little of it -- the
-    # preconditioner must not HURT (measured: 465 vs 449 iterations for the y column at tolerance 0.01)
-    assert log["precond100"]["y_solve_iterations_tol0.01"] <= 1.1 * log["noprecond"]["y_solve_iterations_tol0.01"]
+    # the preconditioner pays (float64 apply, linear_cg.Preconditioner.apply_): measured 44 vs 184 iterations for the 17-column MLL
+    # solve, 244 vs 449 for the y column at tolerance 0.01 (profiles/r02_s9_c3_end_to_end.json); with the float32 apply of round 1
+    # it did not (465 vs 449)
+    assert log["precond100"]["y_solve_iterations_tol0.01"] <= log["noprecond"]["y_solve_iterations_tol0.01"]
+    assert log["precond100"]["iterations"] <= log["noprecond"]["iterations"]
 
 
 def test_c3_miniature_vs_dense_cholesky(dev):
@@ -173,3 +175,86 @@ def test_c3_miniature_vs_dense_cholesky(dev):
     iq = float((sol.squeeze(-1) * y.double()).sum())
     assert abs(float(res.inv_quad.sum()) - iq) < 1e-3 * abs(iq)
     assert abs(float(res.logdet) - float(ld)) < 0.02 * abs(float(ld))
+
+
+def test_c4_single_gpu_share_end_to_end(dev):
+    """BASELINE C4 as ONE of its 8 ranks sees it: n = 1 000 000, d = 3, RBF, 32 of the 256 probes + the y column (rank 0's share;
+    `bench.py --config c4`), no preconditioner, reference-default training tolerance.  The solve reaches the tolerance, the
+    recurrence residuals are the true ones (one more fused product), the operator is symmetric on the solution vectors."""
+    import json
+    import os
+
+    from gpytorch_amd import backend as B
+    from gpytorch_amd.bbmm import LOG_2PI, inv_quad_logdet_forward
+
+    n, d, t = 1_000_000, 3, 32
+    X, y = synth(n, d)
+    Xd, yd = X.to(dev), y.to(dev)
+    xp = B.prep_points("rbf", Xd, torch.tensor([0.25]), Xd.mean(0))
+    sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
+    rhs_t = B.to_probe_major(yd.unsqueeze(-1))
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    res = inv_quad_logdet_forward(xp, sc, s2, rhs_t, num_probes=t, precond=None, generator=gen, t_total=256)
+    assert res.info.tolerance_reached
+    full = torch.cat([res.zt, rhs_t], 0)
+    rel = _true_residual(xp, sc, s2, res.solves_t, full)
+    rep = res.info.residual_norms
+    assert float((rel - rep).abs().max()) < 0.05 * max(1.0, float(rep.max()))
+    assert float(rel.mean()) < 1.0
+    # u^T (K_hat v) == v^T (K_hat u) on the first two solution vectors
+    u, v = res.solves_t[0:1], res.solves_t[1:2]
+    ku = B.kv(xp, xp, u, scale=sc, dscale=s2, vd=u)
+    kv_ = B.kv(xp, xp, v, scale=sc, dscale=s2, vd=v)
+    a, b = float((v.double() * ku.double()).sum()), float((u.double() * kv_.double()).sum())
+    assert abs(a - b) < 2e-5 * float((v.double().abs() * ku.double().abs()).sum())
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/c4_share_end_to_end.json", "w") as f:
+        json.dump(dict(n=n, columns=t + 1, iterations=res.info.iterations, mean_true_rel_residual=float(rel.mean()),
+                       inv_quad=float(res.inv_quad.sum()), logdet_share=float(res.logdet_pinvk),
+                       mll_share=-0.5 * (float(res.inv_quad.sum()) + float(res.logdet) + n * LOG_2PI) / n), f, indent=1)
+
+
+def test_c5_multitask_end_to_end(dev):
+    """BASELINE C5 on one GPU: multitask ExactGP, 4 tasks, RBF (x) index kernel, n = 200 000, d = 6 (800 000 rows), batched CG over
+    the Kronecker MVM with 16 probes + y.  The solve reaches the tolerance; the TRUE residual of the y solve, recomputed through the
+    Kronecker operator, is at the requested tolerance; the operator is symmetric."""
+    import json
+    import os
+
+    from gpytorch_amd import backend as B
+    from gpytorch_amd.multitask import kron_matvec
+    from gpytorch_amd.linear_cg import linear_cg
+
+    n, d, T, ls = 200_000, 6, 4, 0.5
+    X, _ = synth(n, d)
+    g = torch.Generator().manual_seed(2)
+    Bf = torch.randn(T, 1, generator=g)
+    ktt = (Bf @ Bf.t() + 0.5 * torch.eye(T)).to(dev)
+    Y = torch.stack([torch.sin((k + 1.0) * X[:, 0] * 3) + 0.1 * torch.randn(n, generator=g) for k in range(T)], -1).reshape(-1)   # interleaved i*T + tau
+    Xd = X.to(dev)
+    xp = B.prep_points("rbf", Xd, torch.tensor([ls]), Xd.mean(0))
+    N = n * T
+    ld = B.round_up(N, 4)
+    dv = torch.full((ld,), 0.1, device=dev)
+    dv[N:] = 0
+
+    def partials(dt):
+        out = kron_matvec(xp, xp, ktt, dt, None)
+        return out, 1, out.stride(0)
+
+    t = 16
+    rhs = torch.zeros(t + 1, ld, device=dev)
+    rhs[:t, :N] = torch.randint(0, 2, (t, N), generator=g).float().to(dev) * 2 - 1
+    rhs[t, :N] = Y.to(dev)
+    sol, info = linear_cg(None, None, None, rhs, n_tridiag=t, tolerance=0.01, max_iter=1000, kv_partials=partials, dvec=dv, nvec=N)
+    assert info.tolerance_reached, info.iterations
+    khx = kron_matvec(xp, xp, ktt, sol, None)[:, :N] + 0.1 * sol[:, :N]
+    rel = (khx - rhs[:, :N]).norm(dim=-1) / rhs[:, :N].norm(dim=-1)
+    assert float(rel.mean()) < 0.012, rel.tolist()
+    u, v = sol[0:1], sol[t : t + 1]
+    a = float((v[:, :N].double() * kron_matvec(xp, xp, ktt, u, None)[:, :N].double()).sum())
+    b = float((u[:, :N].double() * kron_matvec(xp, xp, ktt, v, None)[:, :N].double()).sum())
+    assert abs(a - b) < 1e-4 * max(abs(a), abs(b))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/c5_end_to_end.json", "w") as f:
+        json.dump(dict(n=n, tasks=T, rows=N, columns=t + 1, iterations=info.iterations, mean_true_rel_residual=float(rel.mean())), f, indent=1)
