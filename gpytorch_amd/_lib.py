@@ -22,6 +22,7 @@ _f = C.c_float
 SIGNATURES = {
     "gpamd_abi_version": (_i, []),
     "gpamd_last_error": (C.c_char_p, []),
+    "gpamd_set_kernel_param_f32": (_i, [_f]),
     "gpamd_prep_points_f32": (_i, [_i, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
     "gpamd_kv_plan": (_i, [_i, _i, _i, _i, _i, _i, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
     "gpamd_kv_partials_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _p]),

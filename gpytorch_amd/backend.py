@@ -12,7 +12,7 @@ import torch
 
 from ._lib import check, lib
 
-KIND_IDS = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
+KIND_IDS = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3, "rq": 4}
 NU_TO_KIND = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}
 MAX_INPUT_DIM = 16
 
@@ -56,11 +56,12 @@ FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or
 class PreparedPoints:
     """A point cloud converted for the fused kernels: float32 [n, dp], scaled by 1/lengthscale."""
 
-    __slots__ = ("xp", "n", "d", "dp", "kind", "_zmax2")
+    __slots__ = ("xp", "n", "d", "dp", "kind", "_zmax2", "param")
 
-    def __init__(self, xp, n, d, dp, kind):
+    def __init__(self, xp, n, d, dp, kind, param=None):
         self.xp, self.n, self.d, self.dp, self.kind = xp, n, d, dp, kind
         self._zmax2 = None
+        self.param = param   # shape parameter of the covariance family (RQ: alpha, a Python float) or None
 
     @property
     def dtype(self):
@@ -80,6 +81,14 @@ class PreparedPoints:
         return self._zmax2
 
 
+def kind_id(xp: PreparedPoints) -> int:
+    """Integer id of the covariance family of ``xp`` for the C ABI; for parametrised families (RQ) the shape parameter is
+    handed to the library first (``gpamd_set_kernel_param_f32``: thread-local host state read at launch time)."""
+    if xp.param is not None:
+        check(lib().gpamd_set_kernel_param_f32(float(xp.param)), "set_kernel_param")
+    return kind_id(xp)
+
+
 def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
     """Select the Gram-form generation kernel when it is both applicable and accurate (see kv_gram.hpp)."""
     if not (x1.fused and x2.fused):
@@ -91,9 +100,18 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
     return KV_GRAM if max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) <= GRAM_MAX_SQNORM else 0
 
 
-def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: torch.Tensor | None = None) -> PreparedPoints:
-    """x: [n, d]; lengthscale: 1 or d values (any shape); shift: d values or None."""
+def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: torch.Tensor | None = None, param=None) -> PreparedPoints:
+    """x: [n, d]; lengthscale: 1 or d values (any shape); shift: d values or None; param: shape parameter (RQ: alpha)."""
     _require_gpu(x, "x")
+    if kind == "rq":
+        if param is None:
+            raise ValueError("the rational-quadratic family needs its shape parameter alpha")
+        param = float(param)
+        if work_dtype(x) != torch.float32 or x.shape[-1] > MAX_INPUT_DIM:
+            raise NotImplementedError("RQKernel runs on the fused float32 kernels only (float32 inputs, d <= 16)")
+        check(lib().gpamd_set_kernel_param_f32(param), "set_kernel_param")
+    else:
+        param = None
     n, d = x.shape[-2], x.shape[-1]
     dp = padded_dim(d)
     wd = work_dtype(x)
@@ -105,7 +123,7 @@ def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: to
     xp = torch.empty(n, dp, device=x.device, dtype=wd)
     fn = lib().gpamd_prep_points_f64 if wd == torch.float64 else lib().gpamd_prep_points_f32
     check(fn(KIND_IDS[kind], _ptr(x), n, d, x.stride(0), _ptr(ls), ls.numel(), _ptr(sh), _ptr(xp), dp, _stream(x.device)), "prep_points")
-    return PreparedPoints(xp, n, d, dp, kind)
+    return PreparedPoints(xp, n, d, dp, kind, param)
 
 
 def to_probe_major(rhs: torch.Tensor, dtype: torch.dtype | None = None) -> torch.Tensor:
@@ -167,7 +185,7 @@ def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dsc
     L = lib()
     check(
         L.gpamd_kv_partials_f32(
-            KIND_IDS[x1.kind], _ptr(x1.xp), n, _ptr(x2.xp), m, x1.d, _ptr(vt), ldv, t, _ptr(ws), ldo, S, jc,
+            kind_id(x1), _ptr(x1.xp), n, _ptr(x2.xp), m, x1.d, _ptr(vt), ldv, t, _ptr(ws), ldo, S, jc,
             flags, None, st
         ),
         "kv_partials",
@@ -188,11 +206,11 @@ def kernel_row_block(x1: PreparedPoints, r0: int, nrows: int, x2: PreparedPoints
     st = _stream(out.device)
     if x1.dtype == torch.float64:
         sc = None if scale is None else scale.to(torch.float64)
-        check(lib().gpamd_kernel_rows_f64(KIND_IDS[x1.kind], _ptr(x1.xp), None, r0, nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(sc),
+        check(lib().gpamd_kernel_rows_f64(kind_id(x1), _ptr(x1.xp), None, r0, nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(sc),
                                           _ptr(out), out.stride(0), st), "kernel_rows_f64")
     else:
         blk = x1.xp[r0 : r0 + nrows]
-        check(lib().gpamd_kernel_dense_f32(KIND_IDS[x1.kind], _ptr(blk), nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
+        check(lib().gpamd_kernel_dense_f32(kind_id(x1), _ptr(blk), nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
                                            out.stride(0), st), "kernel_dense")
     return out
 
@@ -218,7 +236,7 @@ def kv_partials_f64(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, do
     if buf is None or buf.numel() < ws.value:
         buf = torch.empty(max(ws.value, 1 << 18), device=vt.device, dtype=torch.float64)
         _ws_cache[key] = buf
-    check(lib().gpamd_kv_partials_f64(KIND_IDS[x1.kind], _ptr(x1.xp), n, _ptr(x2.xp), m, x1.dp, _ptr(vt), vt.stride(0), t, _ptr(buf),
+    check(lib().gpamd_kv_partials_f64(kind_id(x1), _ptr(x1.xp), n, _ptr(x2.xp), m, x1.dp, _ptr(vt), vt.stride(0), t, _ptr(buf),
                                       ldo, S.value, jc.value, done_ptr, _stream(vt.device)), "kv_partials_f64")
     return buf, S.value, ldo
 
@@ -274,7 +292,7 @@ def kernel_dense(x1: PreparedPoints, x2: PreparedPoints, scale=None) -> torch.Te
     out = torch.empty(x1.n, x2.n, device=x1.xp.device, dtype=torch.float32)
     check(
         lib().gpamd_kernel_dense_f32(
-            KIND_IDS[x1.kind], _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out), out.stride(0),
+            kind_id(x1), _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out), out.stride(0),
             _stream(out.device),
         ),
         "kernel_dense",
@@ -287,13 +305,13 @@ def kernel_rows(x1: PreparedPoints, rows: torch.Tensor, x2: PreparedPoints, scal
     if x1.dtype == torch.float64:
         out = torch.empty(rows.numel(), x2.n, device=x1.xp.device, dtype=torch.float64)
         sc = None if scale is None else scale.to(torch.float64)
-        check(lib().gpamd_kernel_rows_f64(KIND_IDS[x1.kind], _ptr(x1.xp), _ptr(rows), 0, rows.numel(), _ptr(x2.xp), x2.n, x1.dp,
+        check(lib().gpamd_kernel_rows_f64(kind_id(x1), _ptr(x1.xp), _ptr(rows), 0, rows.numel(), _ptr(x2.xp), x2.n, x1.dp,
                                           _ptr(sc), _ptr(out), out.stride(0), _stream(out.device)), "kernel_rows_f64")
         return out
     out = torch.empty(rows.numel(), x2.n, device=x1.xp.device, dtype=torch.float32)
     check(
         lib().gpamd_kernel_rows_f32(
-            KIND_IDS[x1.kind], _ptr(x1.xp), _ptr(rows), rows.numel(), _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
+            kind_id(x1), _ptr(x1.xp), _ptr(rows), rows.numel(), _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
             out.stride(0), _stream(out.device),
         ),
         "kernel_rows",
@@ -306,13 +324,13 @@ def kernel_diag(x1: PreparedPoints, x2: PreparedPoints, scale=None) -> torch.Ten
     if x1.dtype == torch.float64:
         out = torch.empty(x1.n, device=x1.xp.device, dtype=torch.float64)
         sc = None if scale is None else scale.to(torch.float64)
-        check(lib().gpamd_kernel_diag_f64(KIND_IDS[x1.kind], _ptr(x1.xp), _ptr(x2.xp), x1.n, x1.dp, _ptr(sc), _ptr(out),
+        check(lib().gpamd_kernel_diag_f64(kind_id(x1), _ptr(x1.xp), _ptr(x2.xp), x1.n, x1.dp, _ptr(sc), _ptr(out),
                                           _stream(out.device)), "kernel_diag_f64")
         return out
     out = torch.empty(x1.n, device=x1.xp.device, dtype=torch.float32)
     check(
         lib().gpamd_kernel_diag_f32(
-            KIND_IDS[x1.kind], _ptr(x1.xp), _ptr(x2.xp), x1.n, x1.dp, _ptr(scale), _ptr(out), _stream(out.device)
+            kind_id(x1), _ptr(x1.xp), _ptr(x2.xp), x1.n, x1.dp, _ptr(scale), _ptr(out), _stream(out.device)
         ),
         "kernel_diag",
     )
@@ -340,7 +358,7 @@ def pivoted_cholesky(xp: PreparedPoints, scale, rank: int, tol: float):
         # float64 models: the greedy factor is built from a float32 copy of the prepared points.  Any SPD
         # P = L L^T + s2 I is a valid preconditioner; everything derived from this L (Q1, log|P|, the probe
         # covariance) is then computed in float64 by the caller, so the float64 solve loses nothing.
-        xp32 = PreparedPoints(xp.xp.to(torch.float32), n, xp.d, xp.dp, xp.kind)
+        xp32 = PreparedPoints(xp.xp.to(torch.float32), n, xp.d, xp.dp, xp.kind, xp.param)
         L32, piv, m = pivoted_cholesky(xp32, None if scale is None else scale.to(torch.float32), rank, tol)
         return L32.to(xp.dtype), piv, m
     ldl = round_up(n, 4)
@@ -350,7 +368,7 @@ def pivoted_cholesky(xp: PreparedPoints, scale, rank: int, tol: float):
     iwork = torch.zeros(2 + 2 * n, device=dev, dtype=torch.int32)
     check(
         lib().gpamd_pivoted_cholesky_f32(
-            KIND_IDS[xp.kind], _ptr(xp.xp), n, xp.dp, _ptr(scale), rank, float(tol), _ptr(L), ldl, _ptr(piv), _ptr(fwork),
+            kind_id(xp), _ptr(xp.xp), n, xp.dp, _ptr(scale), rank, float(tol), _ptr(L), ldl, _ptr(piv), _ptr(fwork),
             _ptr(iwork), _stream(dev),
         ),
         "pivoted_cholesky",
@@ -375,7 +393,7 @@ def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.
     out = torch.empty(1 + x1.dp, device=dev, dtype=torch.float32)
     check(
         lib().gpamd_kv_grad_f32(
-            KIND_IDS[x1.kind], _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.dp, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0),
+            kind_id(x1), _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.dp, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0),
             t, 1 if iso else 0, _ptr(out), _ptr(ws), nd, _stream(dev),
         ),
         "kv_grad",
@@ -388,7 +406,7 @@ FORCE_GRAD_DIRECT = False  # tests: keep the bilinear derivative on the direct-d
 
 def grad_gram_ok(x1: PreparedPoints, x2: PreparedPoints) -> bool:
     """The Gram-form derivative kernel (kv_grad2.hpp) applies: fused float32 clouds, not Matern-1/2, max |z|^2 <= 32."""
-    if FORCE_GRAD_DIRECT or not (x1.fused and x2.fused) or x1.kind == "matern12":
+    if not (x1.fused and x2.fused) or x1.kind == "matern12" or (FORCE_GRAD_DIRECT and x1.kind != "rq"):
         return False
     return max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) <= GRAM_MAX_SQNORM
 
@@ -403,7 +421,7 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
     t, dev, L = lt.shape[0], lt.device, lib()
     nd = int(L.gpamd_kv_grad2_workspace_doubles(x1.n, x2.n, t, x1.d))
     ws = torch.empty(nd, device=dev, dtype=torch.float64)
-    out = torch.empty(1 + x1.dp, device=dev, dtype=torch.float32)
+    out = torch.empty(2 + x1.dp, device=dev, dtype=torch.float32)   # [1 + dp]: shape-parameter sum (RQ)
     gzt = xws = None
     nx = 0
     ldg = round_up(x1.n, 4)
@@ -413,19 +431,24 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
         gzt = torch.empty(x1.d, ldg, device=dev, dtype=torch.float32)
     check(
         L.gpamd_kv_grad2_f32(
-            KIND_IDS[x1.kind], _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.d, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
+            kind_id(x1), _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.d, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
             1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, _stream(dev),
         ),
         "kv_grad2",
     )
     if iso and want_gz1:  # the kernel ran in per-dimension mode: fold to the single-lengthscale convention of kv_grad
-        out = torch.cat([out[:1], out[1 : 1 + x1.d].sum().reshape(1), torch.zeros(x1.dp - 1, device=dev)])
+        out = torch.cat([out[:1], out[1 : 1 + x1.d].sum().reshape(1), torch.zeros(x1.dp - 1, device=dev), out[1 + x1.dp :]])
     return out, (None if gzt is None else gzt[:, : x1.n].t().contiguous())
 
 
 def prep_coef(kind: str) -> float:
     """z = coef * (x - shift) / lengthscale (prep_points): sqrt(log2(e)/2) for RBF, sqrt(2 nu) for Matern."""
     return {"rbf": RBF_PREP_COEF, "matern12": 1.0, "matern32": math.sqrt(3.0), "matern52": math.sqrt(5.0)}[kind]
+
+
+def prep_coef_of(xp: PreparedPoints) -> float:
+    """The same for a prepared cloud (RQ: 1 / sqrt(2 alpha))."""
+    return 1.0 / math.sqrt(2.0 * xp.param) if xp.kind == "rq" else prep_coef(xp.kind)
 
 
 def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor) -> torch.Tensor:
@@ -449,7 +472,7 @@ def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt
     for r0 in range(0, n, rows):
         nr = min(rows, n - r0)
         w = (lt[:, r0 : r0 + nr].to(dt).t() @ r_all).contiguous()
-        check(fn(KIND_IDS[x1.kind], _ptr(x1.xp), r0, nr, _ptr(x2.xp), m, dp, _ptr(w), w.stride(0), _ptr(acc), st), "kernel_grad_block")
+        check(fn(kind_id(x1), _ptr(x1.xp), r0, nr, _ptr(x2.xp), m, dp, _ptr(w), w.stride(0), _ptr(acc), st), "kernel_grad_block")
         a = w.to(torch.float64)
         zb = z1[r0 : r0 + nr]
         gq += (zb.pow(2) * a.sum(1, keepdim=True)).sum(0) - 2.0 * (zb * (a @ z2)).sum(0)

@@ -116,10 +116,10 @@ class RowShard:
         self.n_loc = self.r1 - self.r0
         self.np_all = self.world * self.n_pad
         xp = xp_full.xp
-        self.x_loc = B.PreparedPoints(xp[self.r0 : self.r1], self.n_loc, xp_full.d, xp_full.dp, xp_full.kind)
+        self.x_loc = B.PreparedPoints(xp[self.r0 : self.r1], self.n_loc, xp_full.d, xp_full.dp, xp_full.kind, xp_full.param)
         if self.np_all > n:
             xp = torch.cat([xp, xp[-1:].expand(self.np_all - n, xp.shape[1])], dim=0).contiguous()
-        self.x_all = B.PreparedPoints(xp, self.np_all, xp_full.d, xp_full.dp, xp_full.kind)
+        self.x_all = B.PreparedPoints(xp, self.np_all, xp_full.d, xp_full.dp, xp_full.kind, xp_full.param)
         self.x_all._zmax2 = xp_full.zmax2
         self.x_loc._zmax2 = xp_full.zmax2
 

@@ -21,20 +21,30 @@ from .bbmm import inv_quad_logdet_forward
 class KernelSpec:
     """Non-tensor description of a stationary kernel operator (kind, centring shift, probe options)."""
 
-    def __init__(self, kind: str, shift=None, dvec=None):
+    def __init__(self, kind: str, shift=None, dvec=None, param=None):
         self.kind = kind
         self.shift = shift
         self.dvec = dvec  # optional fixed (non-learnable) per-point noise diagonal, float32 [n] on the device
+        self.param = param  # shape parameter of the covariance family as a (possibly learnable) tensor: RQ alpha; else None
 
     def with_dvec(self, dvec):
-        return KernelSpec(self.kind, self.shift, dvec)
+        return KernelSpec(self.kind, self.shift, dvec, self.param)
+
+    def param_value(self):
+        """The shape parameter as a Python float for the C ABI (one host read per evaluation), or None."""
+        return None if self.param is None else float(self.param.detach().reshape(-1)[0])
 
 
-def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t, want_x1=False, want_x2=False):
+def _prep(spec: "KernelSpec", x, lengthscale):
+    return B.prep_points(spec.kind, x, lengthscale, spec.shift, spec.param_value())
+
+
+def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t, want_x1=False, want_x2=False, kparam=None):
     """d/d(lengthscale), d/d(outputscale) of  sum_c left[c]^T (outputscale * k(x1, x2)) right[c]  and, on request, its
     gradients with respect to the input locations x1 / x2 ([n, d] / [m, d], in the units of the ORIGINAL points).
 
-    Returns (d_ls, d_os) or, with ``want_x1`` / ``want_x2``, (d_ls, d_os, d_x1, d_x2)."""
+    Returns (d_ls, d_os) or, with ``want_x1`` / ``want_x2``, (d_ls, d_os, d_x1, d_x2); with ``kparam`` (the learnable shape
+    parameter tensor of the family: RQ alpha) the gradient with respect to it is appended as the LAST element."""
     wd = xp1.dtype
     ls = lengthscale.detach().to(wd).reshape(-1)
     iso = ls.numel() == 1
@@ -62,19 +72,28 @@ def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t, want_x1=Fal
         d_ls = (theta * (-2.0) / ls * gq).reshape(lengthscale.shape)
     d_os = None if outputscale is None else g[0].reshape(outputscale.shape)
     d_ls, d_os = d_ls.to(lengthscale.dtype), (None if d_os is None else d_os.to(outputscale.dtype))
+    extra = ()
+    if kparam is not None:
+        # RQ: s = |dx|^2 / (2 alpha l^2)  ->  dK/dalpha = dk/dalpha|_s + dk/ds * (-s / alpha); the kernel delivers
+        # g[1 + dp] = sum W dk/dalpha|_s and sum_q g[1 + q] = sum W dk/ds * s
+        if g.numel() < 2 + xp1.dp:
+            raise RuntimeError("the shape-parameter gradient needs the Gram-form derivative kernel")
+        d_par = theta * (g[1 + xp1.dp] - gq.sum() / xp1.param)
+        extra = (d_par.reshape(kparam.shape).to(kparam.dtype),)
     if not (want_x1 or want_x2):
-        return d_ls, d_os
-    chain = theta * B.prep_coef(xp1.kind) / ls  # dz/dx per dimension (1 or d values), times the outputscale
-    return d_ls, d_os, (None if gz1 is None else gz1 * chain), (None if gz2 is None else gz2 * chain)
+        return (d_ls, d_os) + extra
+    chain = theta * B.prep_coef_of(xp1) / ls  # dz/dx per dimension (1 or d values), times the outputscale
+    return (d_ls, d_os, (None if gz1 is None else gz1 * chain), (None if gz2 is None else gz2 * chain)) + extra
 
 
 class InvQuadLogdetFn(torch.autograd.Function):
     """(inv_quad[c], logdet) of K_hat = outputscale * k(x, x; lengthscale) + noise * I on the BBMM path."""
 
     @staticmethod
-    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec, opts: dict):
+    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec, opts: dict, kparam=None):
         n = x.shape[-2]
-        xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
+        xp = _prep(spec, x, lengthscale)
+        ctx.kparam = kparam
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
         nz = noise.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
         rhs_t = B.to_probe_major(rhs, xp.dtype)
@@ -113,12 +132,19 @@ class InvQuadLogdetFn(torch.autograd.Function):
         else:  # sharded: the rhs block is differentiated by its owner only; the all-reduce below adds it once
             left = (s_z * (g_ld / ctx.t_total)).contiguous()
             right = zr.contiguous()
-        d_x = None
+        d_x = d_par = None
+        kp = ctx.kparam if (ctx.kparam is not None and ctx.needs_input_grad[7]) else None
         if ctx.needs_input_grad[0]:
-            d_ls, d_os, gx1, gx2 = hyper_grads(xp, xp, lengthscale, outputscale, left, right, want_x1=True, want_x2=True)
+            out = hyper_grads(xp, xp, lengthscale, outputscale, left, right, want_x1=True, want_x2=True, kparam=kp)
+            d_ls, d_os, gx1, gx2 = out[:4]
             d_x = (gx1 + gx2).to(ctx.x_dtype)
         else:
-            d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, left, right)
+            out = hyper_grads(xp, xp, lengthscale, outputscale, left, right, kparam=kp)
+            d_ls, d_os = out[:2]
+        if kp is not None:
+            d_par = out[-1]
+            if ctx.group is not None:
+                allreduce_sum_(d_par, ctx.group)
         d_noise = B.coldot(left, right, n).sum().reshape(noise.shape).to(noise.dtype)
         if ctx.group is not None:
             pack = torch.cat([d_ls.reshape(-1).to(xp.dtype), d_noise.reshape(-1).to(xp.dtype)] + ([d_os.reshape(-1).to(xp.dtype)] if d_os is not None else []))
@@ -133,7 +159,7 @@ class InvQuadLogdetFn(torch.autograd.Function):
             d_rhs = (2.0 * B.from_probe_major(s_y, n) * g_iq.reshape(1, c)).to(rhs.dtype)
         if d_x is not None and ctx.group is not None:
             allreduce_sum_(d_x, ctx.group)
-        return d_x, d_ls, d_os, d_noise, d_rhs, None, None
+        return d_x, d_ls, d_os, d_noise, d_rhs, None, None, d_par
 
 
 class CholeskyInvQuadLogdetFn(torch.autograd.Function):
@@ -141,9 +167,10 @@ class CholeskyInvQuadLogdetFn(torch.autograd.Function):
     the HIP dense kernel, factorised by rocSOLVER through torch; exact inv_quad / logdet."""
 
     @staticmethod
-    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec):
+    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec, kparam=None):
         n = x.shape[-2]
-        xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
+        xp = _prep(spec, x, lengthscale)
+        ctx.kparam = kparam
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
         K = B.kernel_dense(xp, xp, os_).to(torch.float64)
         K.diagonal().add_(noise.detach().reshape(()).to(torch.float64))
@@ -173,25 +200,31 @@ class CholeskyInvQuadLogdetFn(torch.autograd.Function):
         rt = torch.zeros(n + c, ld, device=sol.device, dtype=xp.dtype)
         lt[:, :n] = left
         rt[:, :n] = right
-        d_x = None
+        d_x = d_par = None
+        kp = ctx.kparam if (ctx.kparam is not None and ctx.needs_input_grad[6]) else None
         if ctx.needs_input_grad[0]:
-            d_ls, d_os, gx1, gx2 = hyper_grads(xp, xp, lengthscale, outputscale, lt, rt, want_x1=True, want_x2=True)
+            out = hyper_grads(xp, xp, lengthscale, outputscale, lt, rt, want_x1=True, want_x2=True, kparam=kp)
+            d_ls, d_os, gx1, gx2 = out[:4]
             d_x = gx1 + gx2
         else:
-            d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, lt, rt)
+            out = hyper_grads(xp, xp, lengthscale, outputscale, lt, rt, kparam=kp)
+            d_ls, d_os = out[:2]
+        if kp is not None:
+            d_par = out[-1]
         d_noise = (left * right).sum().reshape(noise.shape).to(noise.dtype)
         d_rhs = (2.0 * sol * g_iq.to(torch.float64).reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[4] else None
-        return d_x, d_ls, d_os, d_noise, d_rhs, None
+        return d_x, d_ls, d_os, d_noise, d_rhs, None, d_par
 
 
 class KernelMatmulFn(torch.autograd.Function):
     """(outputscale * k(x1, x2)) @ rhs (+ noise * rhs when square and noise is given)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, lengthscale, outputscale, noise, rhs, spec: KernelSpec):
+    def forward(ctx, x1, x2, lengthscale, outputscale, noise, rhs, spec: KernelSpec, kparam=None):
         ctx.same_x = x2 is x1
-        xp1 = B.prep_points(spec.kind, x1, lengthscale, spec.shift)
-        xp2 = xp1 if x2 is x1 else B.prep_points(spec.kind, x2.to(x1.dtype), lengthscale, spec.shift)
+        ctx.kparam = kparam
+        xp1 = _prep(spec, x1, lengthscale)
+        xp2 = xp1 if x2 is x1 else _prep(spec, x2.to(x1.dtype), lengthscale)
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp1.dtype).contiguous()
         nz = None if noise is None else noise.detach().reshape(-1)[:1].to(xp1.dtype).contiguous()
         vt = B.to_probe_major(rhs, xp1.dtype)
@@ -211,12 +244,17 @@ class KernelMatmulFn(torch.autograd.Function):
         wd = ctx.xp1.dtype
         gt = B.to_probe_major(g, wd)
         rt = B.to_probe_major(rhs, wd)
-        d_ls = d_os = d_noise = d_rhs = d_x1 = d_x2 = None
+        d_ls = d_os = d_noise = d_rhs = d_x1 = d_x2 = d_par = None
+        kp = ctx.kparam if (ctx.kparam is not None and ctx.needs_input_grad[7]) else None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            d_ls, d_os, d_x1, d_x2 = hyper_grads(ctx.xp1, ctx.xp2, lengthscale, outputscale, gt, rt,
-                                                 want_x1=ctx.needs_input_grad[0], want_x2=ctx.needs_input_grad[1])
-        elif ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            d_ls, d_os = hyper_grads(ctx.xp1, ctx.xp2, lengthscale, outputscale, gt, rt)
+            out = hyper_grads(ctx.xp1, ctx.xp2, lengthscale, outputscale, gt, rt, want_x1=ctx.needs_input_grad[0],
+                              want_x2=ctx.needs_input_grad[1], kparam=kp)
+            d_ls, d_os, d_x1, d_x2 = out[:4]
+        elif ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or kp is not None:
+            out = hyper_grads(ctx.xp1, ctx.xp2, lengthscale, outputscale, gt, rt, kparam=kp)
+            d_ls, d_os = out[:2]
+        if kp is not None:
+            d_par = out[-1]
         if noise is not None and ctx.needs_input_grad[4]:
             d_noise = (g * rhs).sum().reshape(noise.shape).to(noise.dtype)
         if ctx.needs_input_grad[5]:
@@ -224,7 +262,7 @@ class KernelMatmulFn(torch.autograd.Function):
             nz = None if noise is None else noise.detach().reshape(-1)[:1].to(wd).contiguous()
             out_t = B.kv(ctx.xp2, ctx.xp1, gt, scale=os_, dscale=nz, vd=gt if nz is not None else None, dvec=ctx.dvec)
             d_rhs = B.from_probe_major(out_t, ctx.xp2.n).to(rhs.dtype)
-        return d_x1, d_x2, d_ls, d_os, d_noise, d_rhs, None
+        return d_x1, d_x2, d_ls, d_os, d_noise, d_rhs, None, d_par
 
 
 class KernelDenseFn(torch.autograd.Function):
@@ -233,9 +271,10 @@ class KernelDenseFn(torch.autograd.Function):
     Backward: sum_ij G_ij dK_ij/dtheta = the fused bilinear derivative with left = I, right = G."""
 
     @staticmethod
-    def forward(ctx, x1, x2, lengthscale, outputscale, spec: KernelSpec):
-        xp1 = B.prep_points(spec.kind, x1, lengthscale, spec.shift)
-        xp2 = xp1 if x2 is x1 else B.prep_points(spec.kind, x2.to(x1.dtype), lengthscale, spec.shift)
+    def forward(ctx, x1, x2, lengthscale, outputscale, spec: KernelSpec, kparam=None):
+        ctx.kparam = kparam
+        xp1 = _prep(spec, x1, lengthscale)
+        xp2 = xp1 if x2 is x1 else _prep(spec, x2.to(x1.dtype), lengthscale)
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp1.dtype).contiguous()
         ctx.xp1, ctx.xp2 = xp1, xp2
         ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0))
@@ -253,12 +292,13 @@ class KernelDenseFn(torch.autograd.Function):
         lt[:, :n] = torch.eye(n, device=g.device, dtype=wd)
         rt = torch.zeros(n, B.round_up(m, 4), device=g.device, dtype=wd)
         rt[:, :m] = g.to(wd)
+        kp = ctx.kparam if (ctx.kparam is not None and ctx.needs_input_grad[5]) else None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            d_ls, d_os, d_x1, d_x2 = hyper_grads(xp1, xp2, lengthscale, outputscale, lt, rt, want_x1=ctx.needs_input_grad[0],
-                                                 want_x2=ctx.needs_input_grad[1])
-            return d_x1, d_x2, d_ls, d_os, None
-        d_ls, d_os = hyper_grads(xp1, xp2, lengthscale, outputscale, lt, rt)
-        return None, None, d_ls, d_os, None
+            out = hyper_grads(xp1, xp2, lengthscale, outputscale, lt, rt, want_x1=ctx.needs_input_grad[0],
+                              want_x2=ctx.needs_input_grad[1], kparam=kp)
+            return out[2], out[3], out[0], out[1], None, (out[-1] if kp is not None else None)
+        out = hyper_grads(xp1, xp2, lengthscale, outputscale, lt, rt, kparam=kp)
+        return None, None, out[0], out[1], None, (out[-1] if kp is not None else None)
 
 
 class SolveFn(torch.autograd.Function):
@@ -267,10 +307,11 @@ class SolveFn(torch.autograd.Function):
     d/dB = Y and d/dtheta = -sum_c Y_c^T (dK_hat/dtheta) X_c -- ONE more mBCG solve and ONE fused bilinear derivative."""
 
     @staticmethod
-    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec, precond, tolerance):
+    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec: KernelSpec, precond, tolerance, kparam=None):
         from .linear_cg import linear_cg
 
-        xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
+        ctx.kparam = kparam
+        xp = _prep(spec, x, lengthscale)
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
         nz = noise.detach().reshape(-1)[:1].to(xp.dtype).contiguous()
         sol_t, info = linear_cg(xp, os_, nz, B.to_probe_major(rhs.detach(), xp.dtype), n_tridiag=0, tolerance=tolerance,
@@ -292,14 +333,19 @@ class SolveFn(torch.autograd.Function):
         y_t, _ = linear_cg(xp, ctx.os_, ctx.nz, B.to_probe_major(g, xp.dtype), n_tridiag=0, tolerance=ctx.tol,
                            preconditioner=ctx.precond, dvec=ctx.spec.dvec)
         left = -y_t
-        d_ls = d_os = d_noise = d_rhs = d_x = None
+        d_ls = d_os = d_noise = d_rhs = d_x = d_par = None
+        kp = ctx.kparam if (ctx.kparam is not None and ctx.needs_input_grad[8]) else None
         if ctx.needs_input_grad[0]:
-            d_ls, d_os, gx1, gx2 = hyper_grads(xp, xp, lengthscale, outputscale, left.contiguous(), ctx.sol_t, want_x1=True, want_x2=True)
+            out = hyper_grads(xp, xp, lengthscale, outputscale, left.contiguous(), ctx.sol_t, want_x1=True, want_x2=True, kparam=kp)
+            d_ls, d_os, gx1, gx2 = out[:4]
             d_x = gx1 + gx2
-        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, left.contiguous(), ctx.sol_t)
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or kp is not None:
+            out = hyper_grads(xp, xp, lengthscale, outputscale, left.contiguous(), ctx.sol_t, kparam=kp)
+            d_ls, d_os = out[:2]
+        if kp is not None:
+            d_par = out[-1]
         if ctx.needs_input_grad[3]:
             d_noise = B.coldot(left.contiguous(), ctx.sol_t, xp.n).sum().reshape(noise.shape).to(noise.dtype)
         if ctx.needs_input_grad[4]:
             d_rhs = B.from_probe_major(y_t, xp.n).to(ctx.rhs_dtype)
-        return d_x, d_ls, d_os, d_noise, d_rhs, None, None, None
+        return d_x, d_ls, d_os, d_noise, d_rhs, None, None, None, d_par

@@ -121,12 +121,16 @@ class _StationaryFused(Kernel):
         # generation kernel needs (the reference's sq_dist centres for the same reason, kernel.py:29-30)
         return x1.detach().mean(dim=-2)
 
+    def _make_spec(self, x1, b=None, batch=None):
+        """Non-tensor description of the operator for batch member ``b`` (families with a shape parameter add it here)."""
+        return KernelSpec(self.kind, self._shift(x1))
+
     def forward(self, x1, x2, diag=False, **params):
         # float32 with d <= 16: fused MFMA / VALU kernels; float64 or d > 16: generic path (backend.kv_chunked)
         ls = self.lengthscale
         batch = torch.broadcast_shapes(x1.shape[:-2], x2.shape[:-2], ls.shape[:-2])
         if not batch:
-            op = FusedKernelLinearOperator(x1, x2, KernelSpec(self.kind, self._shift(x1)), ls)
+            op = FusedKernelLinearOperator(x1, x2, self._make_spec(x1), ls)
             return op.diagonal() if diag else op
         # batch mode: one fused operator per batch member (inputs and lengthscales broadcast against each other)
         same = x2 is x1
@@ -137,7 +141,7 @@ class _StationaryFused(Kernel):
         for b in range(x1b.shape[0]):
             xa = x1b[b]
             xb = xa if same else x2b[b]
-            ops.append(FusedKernelLinearOperator(xa, xb, KernelSpec(self.kind, self._shift(xa)), lsb[b]))
+            ops.append(FusedKernelLinearOperator(xa, xb, self._make_spec(xa, b, batch), lsb[b]))
         op = BatchLinearOperator(ops, batch)
         return op.diagonal() if diag else op
 
@@ -228,6 +232,33 @@ class MaternKernel(_StationaryFused):
 
     def _shift(self, x1):
         return x1.detach().mean(dim=-2)
+
+
+class RQKernel(_StationaryFused):
+    r"""k(x, x') = (1 + (x - x')^T Theta^-2 (x - x') / (2 alpha))^-alpha   (``gpytorch/kernels/rq_kernel.py:14-86``).  A native
+    covariance family of the fused float32 kernels (``KIND_RQ``: one ``v_log_f32`` + one ``v_exp_f32`` per pair); alpha is a learnable
+    shape parameter whose gradient comes out of the same fused derivative pass as the lengthscales'."""
+
+    kind = "rq"
+
+    def __init__(self, alpha_constraint=None, **kwargs):
+        super().__init__(**kwargs)
+        self.register_parameter("raw_alpha", torch.nn.Parameter(torch.zeros(*self._batch_shape, 1)))
+        self.register_constraint("raw_alpha", Positive() if alpha_constraint is None else alpha_constraint)
+
+    @property
+    def alpha(self):
+        return self._get_transformed("raw_alpha")
+
+    @alpha.setter
+    def alpha(self, value):
+        self._set_transformed("raw_alpha", value)
+
+    def _make_spec(self, x1, b=None, batch=None):
+        a = self.alpha
+        if b is not None:
+            a = a.expand(*batch, 1).reshape(-1, 1)[b]
+        return KernelSpec("rq", self._shift(x1), param=a)
 
 
 class ScaleKernel(Kernel):
@@ -361,5 +392,5 @@ class ProductKernel(Kernel):
         return res if diag else DenseLinearOperator(res)
 
 
-__all__ = ["Kernel", "RBFKernel", "MaternKernel", "PeriodicKernel", "ScaleKernel", "AdditiveKernel", "ProductKernel"]
+__all__ = ["Kernel", "RBFKernel", "MaternKernel", "RQKernel", "PeriodicKernel", "ScaleKernel", "AdditiveKernel", "ProductKernel"]
 _ = (math, Interval)

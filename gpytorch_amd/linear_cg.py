@@ -243,7 +243,7 @@ def linear_cg(
             flags = B.kv_flags(x, x, t)
             S, jc, wsn = B.kv_plan(x.kind, n, n, x.d, t, flags, ld)
             P = B.workspace(dev, wsn)
-            kind_id = B.KIND_IDS[x.kind]
+            kind_id = B.kind_id(x)
         ldp = ld
         min_iter = min(10, max_iter - 1)
         tri_floor = min(n_tri_iter, max_iter - 1) if n_tridiag else 0

@@ -430,7 +430,7 @@ class FusedKernelLinearOperator(LinearOperator):
     @property
     def requires_grad(self):
         return bool(self.lengthscale.requires_grad or (self.outputscale is not None and self.outputscale.requires_grad)
-                    or self.x1.requires_grad or self.x2.requires_grad)
+                    or self.x1.requires_grad or self.x2.requires_grad or (self.spec.param is not None and self.spec.param.requires_grad))
 
     @property
     def square_same_inputs(self):
@@ -449,15 +449,16 @@ class FusedKernelLinearOperator(LinearOperator):
 
     def prepared(self):
         if self._prep is None:
-            p1 = B.prep_points(self.spec.kind, self.x1, self.lengthscale, self.spec.shift)
-            p2 = p1 if self.square_same_inputs else B.prep_points(self.spec.kind, self.x2.to(self.x1.dtype), self.lengthscale, self.spec.shift)
+            pv = self.spec.param_value()
+            p1 = B.prep_points(self.spec.kind, self.x1, self.lengthscale, self.spec.shift, pv)
+            p2 = p1 if self.square_same_inputs else B.prep_points(self.spec.kind, self.x2.to(self.x1.dtype), self.lengthscale, self.spec.shift, pv)
             self._prep = (p1, p2)
         return self._prep
 
     def _matmul(self, rhs):
         # (distinct x2 tensors keep their own identity so that autograd can hand each its gradient)
         x2 = self.x1 if (self.x2 is self.x1 or (self.square_same_inputs and not self.x2.requires_grad)) else self.x2
-        return KernelMatmulFn.apply(self.x1, x2, self.lengthscale, self.outputscale, None, rhs, self.spec)
+        return KernelMatmulFn.apply(self.x1, x2, self.lengthscale, self.outputscale, None, rhs, self.spec, self.spec.param)
 
     def _transpose_nonbatch(self):
         return FusedKernelLinearOperator(self.x2, self.x1, self.spec, self.lengthscale, self.outputscale)
@@ -479,7 +480,7 @@ class FusedKernelLinearOperator(LinearOperator):
     def to_dense(self):
         if torch.is_grad_enabled() and self.requires_grad:
             x2 = self.x1 if (self.x2 is self.x1 or (self.square_same_inputs and not self.x2.requires_grad)) else self.x2
-            return KernelDenseFn.apply(self.x1, x2, self.lengthscale, self.outputscale, self.spec)
+            return KernelDenseFn.apply(self.x1, x2, self.lengthscale, self.outputscale, self.spec, self.spec.param)
         p1, p2 = self.prepared()
         return B.kernel_dense(p1, p2, self._os()).to(self.dtype)
 
@@ -594,7 +595,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
 
     def _matmul(self, rhs):
         k = self.kernel_op
-        return KernelMatmulFn.apply(k.x1, k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec())
+        return KernelMatmulFn.apply(k.x1, k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec(), k.spec.param)
 
     def _transpose_nonbatch(self):
         return self
@@ -640,14 +641,14 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             inv_quad_rhs = torch.zeros(n, 0, device=self.device, dtype=self.dtype)
         rhs = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
         if self._use_cholesky(settings.fast_computations.log_prob):
-            iq, ld = CholeskyInvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec())
+            iq, ld = CholeskyInvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec(), k.spec.param)
         else:
             if rhs.shape[-1] == 0:
                 rhs = torch.zeros(n, 1, device=self.device, dtype=self.dtype)
                 drop = True
             else:
                 drop = False
-            iq, ld = InvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec(), self._iql_opts())
+            iq, ld = InvQuadLogdetFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, rhs, self._spec(), self._iql_opts(), k.spec.param)
             if drop:
                 iq = iq[:0]
         if reduce_inv_quad:
@@ -707,7 +708,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             k = self.kernel_op
             self._preconditioner()
             sol = SolveFn.apply(k.x1, k.lengthscale, k.outputscale, self.noise, r, self._spec(), self._cache["precond"],
-                                settings.cg_tolerance.value())
+                                settings.cg_tolerance.value(), k.spec.param)
         else:
             p1, _ = self.kernel_op.prepared()
             if "precond" not in self._cache:
@@ -832,13 +833,13 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             if state["result"] is not None:   # Lanczos finished first: plain one-column products from here on
                 S1, jc1, ws1 = B.kv_plan(p1.kind, n, n, p1.d, 1, B.kv_flags(p1, p1, 1), ld)
                 P1 = B.workspace(dev, wsn + ws1)[wsn:]
-                check(L.gpamd_kv_partials_f32(B.KIND_IDS[p1.kind], B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(dt), ld, 1, B._ptr(P1), ld,
+                check(L.gpamd_kv_partials_f32(B.kind_id(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(dt), ld, 1, B._ptr(P1), ld,
                                               S1, jc1, B.kv_flags(p1, p1, 1), None, st), "kv_partials")
                 return P1, S1, ld
             q = state["q"]
             W[0].copy_(dt[0])
             W[1].copy_(q[0])
-            check(L.gpamd_kv_partials_f32(B.KIND_IDS[p1.kind], B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(W), ld, 2, B._ptr(P), ld, S, jc,
+            check(L.gpamd_kv_partials_f32(B.kind_id(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(W), ld, 2, B._ptr(P), ld, S, jc,
                                           flags, None, st), "kv_partials")
             # Lanczos column: slab row 1 of every split, rows 2 ld apart -> "t = 1 with ldp = 2 ld" for the reduction
             p_col1 = C.c_void_p(P.data_ptr() + 4 * ld)

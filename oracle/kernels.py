@@ -104,6 +104,15 @@ def matern_dl(x1, x2, lengthscale, nu, x1_eq_x2=None):
     raise RuntimeError("nu expected to be 0.5, 1.5, or 2.5")
 
 
+def rq(x1, x2, lengthscale, alpha, x1_eq_x2=None, direct=False):
+    """kernels/rq_kernel.py:60-74: (1 + sq_dist(x1 / l, x2 / l) / (2 alpha))^-alpha."""
+    if x1_eq_x2 is None:
+        x1_eq_x2 = x1.shape == x2.shape and torch.equal(x1, x2)
+    x1_, x2_ = x1.div(lengthscale), x2.div(lengthscale)
+    d2 = sq_dist_direct(x1_, x2_) if direct else sq_dist(x1_, x2_, x1_eq_x2)
+    return (1 + d2.div(2 * alpha)).pow(-alpha)
+
+
 KINDS = {"rbf": None, "matern12": 0.5, "matern32": 1.5, "matern52": 2.5}
 
 

@@ -171,3 +171,82 @@ def test_additive_kernel_posterior_with_cg(dev):
     var_ref = 1.5 - w.pow(2).sum(0)
     assert rel_err(mu, mu_ref) < 1e-3
     assert float((var.double().cpu() - var_ref).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("ard", [False, True])
+def test_rq_kernel_values_products_and_all_gradients(ard, dev):
+    """RQKernel (gpytorch/kernels/rq_kernel.py:60-74) as a native covariance family: dense values, K @ V on every column-count
+    kernel, and gradients w.r.t. lengthscale(s), alpha and the inputs against float64 autograd."""
+    import gpytorch_amd as g
+
+    gen = torch.Generator().manual_seed(0)
+    n, m, d = 700, 450, 3
+    x1 = torch.rand(n, d, generator=gen)
+    x2 = torch.rand(m, d, generator=gen)
+    kern = g.kernels.RQKernel(ard_num_dims=d if ard else None).to(dev)
+    ls = torch.tensor([[0.5, 0.8, 0.35]]) if ard else torch.tensor([[0.45]])
+    kern.lengthscale = ls
+    kern.alpha = 1.7
+    Kref = OK.rq(x1.double(), x2.double(), ls.double(), 1.7, x1_eq_x2=False, direct=True)
+    assert rel_err(kern(x1.to(dev), x2.to(dev)).to_dense(), Kref) < 1e-5
+    for t in (1, 4, 11, 16, 40, 65):
+        V = torch.randn(m, t, generator=gen)
+        assert rel_err(kern(x1.to(dev), x2.to(dev)) @ V.to(dev), Kref @ V.double()) < 3e-5, t
+    xa = x1.to(dev).requires_grad_(True)
+    V = torch.randn(n, 9, generator=gen)
+    out = kern(xa, xa) @ V.to(dev)
+    out.pow(2).sum().backward()
+    ls64 = ls.double().requires_grad_(True)
+    a64 = torch.tensor(1.7, dtype=torch.float64, requires_grad=True)
+    x64 = x1.double().requires_grad_(True)
+    ref = OK.rq(x64, x64, ls64, a64, x1_eq_x2=False, direct=True) @ V.double()
+    ref.pow(2).sum().backward()
+    sig = lambda raw: torch.sigmoid(raw.detach().double().cpu())  # noqa: E731
+    assert torch.allclose(kern.raw_lengthscale.grad.double().cpu(), ls64.grad * sig(kern.raw_lengthscale), rtol=2e-3)
+    assert abs(float(kern.raw_alpha.grad) - float(a64.grad) * float(sig(kern.raw_alpha))) < 2e-3 * abs(float(a64.grad))
+    assert rel_err(xa.grad, x64.grad) < 2e-3
+
+
+def test_rq_gp_mll_bbmm_and_cholesky(dev):
+    """ScaleKernel(RQKernel) ExactGP: MLL value on the Cholesky and BBMM branches and the alpha gradient (Cholesky branch)
+    against dense float64 autograd."""
+    import gpytorch_amd as g
+
+    n, d = 1200, 2
+    X, y = make_data(n, d)
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ZeroMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RQKernel())
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    p = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (0.3, 2.2, 1.3, 0.1)]   # ls, alpha, outputscale, noise
+    Kh = p[2] * OK.rq(X, X, p[0], p[1], x1_eq_x2=True, direct=True) + p[3] * torch.eye(n, dtype=torch.float64)
+    ref = OG.dense_log_prob(Kh, y) / n
+    gref = torch.autograd.grad(ref, p)
+    for branch in ("cholesky", "bbmm"):
+        lik = g.likelihoods.GaussianLikelihood().to(dev)
+        m = M(X.float().to(dev), y.float().to(dev), lik).to(dev)
+        m.covar_module.base_kernel.lengthscale = 0.3
+        m.covar_module.base_kernel.alpha = 2.2
+        m.covar_module.outputscale = 1.3
+        lik.noise = 0.1
+        mll = g.ExactMarginalLogLikelihood(lik, m)
+        m.train()
+        lik.train()
+        S = g.settings
+        with S.max_cholesky_size(10_000 if branch == "cholesky" else 0), S.cg_tolerance(1e-5), S.num_trace_samples(300), S.max_preconditioner_size(0):
+            torch.manual_seed(0)
+            val = mll(m(m.train_inputs[0]), m.train_targets)
+            val.backward()
+        tol_v, tol_g = (2e-4, 3e-3) if branch == "cholesky" else (5e-3, 0.15)
+        assert abs(float(val) - float(ref)) < tol_v * max(1.0, abs(float(ref))), branch
+        sp = lambda v: 1.0 - math.exp(-v)  # noqa: E731
+        got = torch.tensor([float(m.covar_module.base_kernel.raw_lengthscale.grad.sum()), float(m.covar_module.base_kernel.raw_alpha.grad.sum()),
+                            float(m.covar_module.raw_outputscale.grad), float(lik.noise_covar.raw_noise.grad.sum())], dtype=torch.float64)
+        want = torch.tensor([float(gref[0]) * sp(0.3), float(gref[1]) * sp(2.2), float(gref[2]) * sp(1.3), float(gref[3]) * sp(0.1 - 1e-4)], dtype=torch.float64)
+        assert float((got - want).norm() / want.norm()) < tol_g, (branch, got, want)
