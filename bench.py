@@ -349,6 +349,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n, d, cols, ls)
         print(json.dumps(out))
     if group is not None:
+        torch.distributed.barrier()   # rank 0 may still be in the (untimed) parity check
         torch.distributed.destroy_process_group()
 
 

@@ -86,7 +86,7 @@ def kind_id(xp: PreparedPoints) -> int:
     handed to the library first (``gpamd_set_kernel_param_f32``: thread-local host state read at launch time)."""
     if xp.param is not None:
         check(lib().gpamd_set_kernel_param_f32(float(xp.param)), "set_kernel_param")
-    return kind_id(xp)
+    return KIND_IDS[xp.kind]
 
 
 def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:

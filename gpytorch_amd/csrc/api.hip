@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "cg_kernels.hpp"
@@ -59,6 +60,17 @@ float prep_coef(int kind) {
     case GPAMD_RQ: return 1.0f / sqrtf(2.0f * g_kparam);   // (1 + |x - x'|^2 / (2 alpha l^2))^-alpha = (1 + |z - z'|^2)^-alpha
   }
   return 0.f;
+}
+
+int kv_skew() {  // GPAMD_KV_SKEW: phase skew of the 32-column-tile kernel, units of 512 cycles (tuning; common.hpp: phase_skew)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GPAMD_KV_SKEW");
+    v = e ? atoi(e) : 0;
+    if (v < 0) v = 0;
+    if (v > 64) v = 64;
+  }
+  return v;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -295,6 +307,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
     a.kparam = g_kparam;
+    a.skew = kv_skew();
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
     const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");

@@ -45,7 +45,16 @@ def _worker(rank, world, port, q):
     ysol = sol[:, -1].clone() if rank == 0 else torch.zeros(n, dtype=sol.dtype)
     D.broadcast_(ysol, 0, group)
     sol = torch.cat([sol[:, :t], ysol.unsqueeze(-1)], dim=-1)
-    q.put((rank, info["iters"], sol.numpy(), float(ld), (a, b)))  # plain data: a tensor would travel as a shm handle that dies with the worker
+    # the per-rank probe generator of settings.sharding: created once per (group, device), ADVANCES between evaluations (fresh probes
+    # every MLL call, as on one GPU), and differs between ranks
+    from gpytorch_amd import settings as S
+
+    g1 = S.sharding.rank_generator(group, torch.device("cpu"))
+    d1 = torch.randn(4, generator=g1)
+    g2 = S.sharding.rank_generator(group, torch.device("cpu"))
+    d2 = torch.randn(4, generator=g2)
+    assert g1 is g2 and not torch.equal(d1, d2)
+    q.put((rank, info["iters"], sol.numpy(), float(ld), (a, b), d1.tolist()))  # plain data: a tensor would travel as a shm handle that dies with the worker
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,7 +86,8 @@ def test_probe_sharding_matches_single_process():
     rhs = torch.cat([Z, y.unsqueeze(-1)], dim=-1)
     sol, T, info = OCG.linear_cg(mm, rhs, n_tridiag=t_total, tolerance=0.5, return_info=True)
     ld = OS.slq_logdet(T, n)
-    for rank, iters, s, ldr, (a, b) in results:
+    assert results[0][5] != results[1][5]                      # ranks draw different probes
+    for rank, iters, s, ldr, (a, b), _ in results:
         s = torch.from_numpy(s)
         assert iters == info["iters"]
         assert torch.allclose(s[:, : b - a], sol[:, a:b], rtol=0, atol=1e-12)

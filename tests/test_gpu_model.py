@@ -254,3 +254,29 @@ def test_fused_prediction_caches_equal_separate_caches(dev):
     for mode in ("fused", "separate"):
         assert rel_err(out[mode][0], mu_ref) < 1e-3
         assert float(((out[mode][1] - var_ref).abs() / var_ref).max()) < 0.05, mode
+
+
+def test_deterministic_probes_are_drawn_once_and_reused(dev):
+    """settings.deterministic_probes (linear_operator _probe_vectors_and_norms): with the flag on and nothing
+    injected, ONE Gaussian probe matrix is drawn on first use and re-used -- two MLL evaluations give bit-identical values (a
+    deterministic objective for L-BFGS / line searches); with the flag off they differ."""
+    kind, n, d, ls = "rbf", 1500, 3, 0.25
+    X, y = make_data(n, d)
+    g, m, lik = _model(kind, X, y, ls, 1.0, 0.1, dev)
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    m.train()
+    lik.train()
+    S = g.settings
+    S.deterministic_probes.probe_vectors = None
+    try:
+        with torch.no_grad(), S.max_cholesky_size(0), S.max_preconditioner_size(0):
+            with S.deterministic_probes(True):
+                a = float(mll(m(m.train_inputs[0]), m.train_targets))
+                assert S.deterministic_probes.probe_vectors is not None and S.deterministic_probes.probe_vectors.shape[0] == n
+                b = float(mll(m(m.train_inputs[0]), m.train_targets))
+            c = float(mll(m(m.train_inputs[0]), m.train_targets))
+            e = float(mll(m(m.train_inputs[0]), m.train_targets))
+    finally:
+        S.deterministic_probes.probe_vectors = None
+    assert a == b
+    assert c != e
