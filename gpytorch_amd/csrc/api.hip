@@ -62,17 +62,6 @@ float prep_coef(int kind) {
   return 0.f;
 }
 
-int kv_skew() {  // GPAMD_KV_SKEW: phase skew of the 32-column-tile kernel, units of 512 cycles (tuning; common.hpp: phase_skew)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("GPAMD_KV_SKEW");
-    v = e ? atoi(e) : 0;
-    if (v < 0) v = 0;
-    if (v > 64) v = 64;
-  }
-  return v;
-}
-
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // column-tile variant for t columns: valu (t <= 8) or mfma CT/EX
@@ -307,7 +296,6 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
     a.kparam = g_kparam;
-    a.skew = kv_skew();
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
     const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");

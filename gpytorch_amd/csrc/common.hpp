@@ -96,19 +96,6 @@ template <int KIND> __device__ __forceinline__ double cov_any(double s) { return
 template <int KIND> __device__ __forceinline__ float dcov_any(float s) { return dcov_dsq<KIND>(s); }
 template <int KIND> __device__ __forceinline__ double dcov_any(double s) { return dcov_dsq_f64<KIND>(s); }
 
-// Phase skew between the workgroups that share a CU.  Co-resident workgroups of these kernels run IDENTICAL phase sequences
-// (stage -> matrix-pipe phase -> VALU phase) and start together, so they stay phase-aligned: both want the matrix pipe at the same
-// time and both want the VALU at the same time.  Delaying the workgroups that sit in an odd wave slot once, at the start, by about
-// half a step makes one's MFMA phase cover the other's VALU / staging phase; successors inherit the slot and with it the offset.
-// HW_REG_HW_ID (id 4) bits [3:0] = wave slot within the SIMD.
-__device__ __forceinline__ void phase_skew(int units_of_512_cycles, int* lds_flag) {
-  if (units_of_512_cycles <= 0) return;
-  if (threadIdx.x == 0) *lds_flag = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u);
-  __syncthreads();
-  if (*lds_flag)
-    for (int i = 0; i < units_of_512_cycles; ++i) __builtin_amdgcn_s_sleep(8);
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

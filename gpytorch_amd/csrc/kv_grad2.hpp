@@ -36,7 +36,6 @@ struct Grad2Args {
   int rs;              // LDS row stride (floats) of the L / R tiles: >= 2*th4, == 4 mod 32
   double* part;        // [nrb*S][2 + DP]   (hyper-parameter partial sums; last entry: shape-parameter sum, RQ)
   float kparam;        // covariance shape parameter (RQ: alpha)
-  int skew;            // initial delay of odd-slot workgroups, units of 512 cycles (common.hpp: phase_skew)
   float* Px;           // optional [S][DP][ldx] partial slabs of Gz1 (probe-major: one coordinate per row) or nullptr
   int64_t ldx, pxstride;
 };
@@ -85,7 +84,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   _Float16* Xh = reinterpret_cast<_Float16*>(Rs + (size_t)BN * RS);  // [KH][BN][16]
   float* Zs = reinterpret_cast<float*>(Xh + KH * BN * 16);        // [4*GZ][LDZ]  (MODE 1)
   __shared__ double red[4][2 + DP];
-  __shared__ int skew_flag;
 
   const int unit = blockIdx.x;
   const int s = unit / a.nrb, rb = unit - s * a.nrb;
@@ -94,7 +92,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   const int i0 = rb * 128 + wave * 32;
   const int i = i0 + l31;
 
-  phase_skew(a.skew, &skew_flag);
   // zero the padded tiles once (columns >= t and the k-step padding stay zero for the whole kernel)
   for (int e = tid; e < (4 * 32 + BN) * RS; e += 256) dyn[e] = 0.f;
   if constexpr (MODE == 1)

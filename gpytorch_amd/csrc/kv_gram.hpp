@@ -41,10 +41,8 @@ void kv_gram_kernel(KvArgs a) {
   float* Vs = smem;
   float* Es = smem + TC * LDT;          // 16-B aligned (TC*LDT*4 is a multiple of 16)
   _Float16* Xh = reinterpret_cast<_Float16*>(Es + BN);   // [KH][BN][16] split augmented x_j rows
-  __shared__ int skew_flag;
 
   if (a.done && *a.done) return;
-  phase_skew(a.skew, &skew_flag);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int unit = blockIdx.x;

@@ -36,7 +36,6 @@ struct KvArgs {
   int S, jchunk, nrb;  // split count, j-chunk length (multiple of BN), row-block count
   const int* done;     // optional device flag: non-zero -> the launch is a no-op (converged CG)
   float kparam;        // shape parameter of the covariance family (RQ: alpha); 0 otherwise
-  int skew;            // initial delay of odd-slot workgroups, units of 512 cycles (common.hpp: phase_skew); 0 = off
 };
 
 constexpr int KV_BN = 128;           // j-tile staged in LDS per iteration

@@ -21,17 +21,6 @@ namespace {
 // Smaller groups raise the occupancy (34 columns: 36 KB, four workgroups per CU) but regenerate the pairs once per group, and that
 // loses: measured at n = 500 000, t = 65 (profiles/r02_s5_grad_timing_maxcols{66,34,18}.json) 349 / 396 / 494 ms for 66 / 34 / 18.
 // GPAMD_GRAD2_MAXCOLS overrides (tuning only).
-int g2_skew() {  // GPAMD_GRAD2_SKEW: units of 512 cycles (tuning); default chosen from profiles/r02_s11_grad_skew.json
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("GPAMD_GRAD2_SKEW");
-    v = e ? atoi(e) : 0;
-    if (v < 0) v = 0;
-    if (v > 64) v = 64;
-  }
-  return v;
-}
-
 int g2_maxcols() {
   static int v = 0;
   if (v == 0) {
@@ -180,7 +169,6 @@ int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int 
     a.rs = 2 * a.th4 + 4;   // = 4 * odd: eight lanes' 16-byte reads at this row stride cover all 32 banks exactly once
     a.part = workspace + (int64_t)g * units * (2 + dp);
     a.kparam = gpamd::g_kparam;
-    a.skew = g2_skew();
     a.Px = Gz1t ? xworkspace + (int64_t)g * S * dp * ldx : nullptr;
     a.ldx = ldx;
     a.pxstride = (int64_t)dp * ldx;

@@ -44,7 +44,7 @@ for kind, d, ls in (("rbf", 3, 0.25), ("matern52", 10, 0.8)):
     rec["grad2_ard_xgrad_ms"] = timed(lambda: B.kv_grad2(xp, xp, lt, rt, iso=False, want_gz1=True))
     a = B.kv_grad(xp, xp, lt, rt, iso=False)
     b, _ = B.kv_grad2(xp, xp, lt, rt, iso=False)
-    rec["max_rel_dev_vs_direct"] = float(((a - b).abs() / a.abs().clamp_min(1e-30))[: 1 + d].max())
+    rec["max_rel_dev_vs_direct"] = float(((a - b[: a.numel()]).abs() / a.abs().clamp_min(1e-30))[: 1 + d].max())
     for k in list(rec):
         if k.endswith("_ms"):
             rec[k.replace("_ms", "_tflops")] = flop / rec[k] / 1e9

@@ -1,0 +1,49 @@
+"""CPU: the batch launch plan (gpytorch_amd.operators.BatchLinearOperator) with dense members -- shapes, broadcasting,
+indexing and the mapped BBMM entry points agree with batched torch linear algebra (kernels/kernel.py:163-208 batch semantics)."""
+import torch
+
+from gpytorch_amd.operators import BatchLinearOperator, ConstantDiagLinearOperator, DenseLinearOperator, DiagLinearOperator
+
+
+def _batch(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mats = [torch.randn(5, 5, generator=g, dtype=torch.float64) for _ in range(6)]
+    return BatchLinearOperator([DenseLinearOperator(a @ a.t() + 5 * torch.eye(5, dtype=torch.float64)) for a in mats], (3, 2))
+
+
+def test_shapes_matmul_and_broadcast():
+    op = _batch()
+    K = op.to_dense()
+    assert op.shape == torch.Size([3, 2, 5, 5]) and op.batch_shape == torch.Size([3, 2]) and op.diagonal().shape == (3, 2, 5)
+    rhs = torch.randn(3, 2, 5, 4, dtype=torch.float64)
+    assert torch.allclose(op @ rhs, K @ rhs)
+    shared = torch.randn(5, 4, dtype=torch.float64)           # one right-hand side for every member
+    assert torch.allclose(op @ shared, K @ shared)
+    small = BatchLinearOperator.replicate(op.ops[0], (2,))
+    assert (small @ torch.randn(2, 5, 1, dtype=torch.float64)).shape == (2, 5, 1)
+    assert torch.allclose(op.mT.to_dense(), K.mT)
+
+
+def test_solves_logdets_and_indexing():
+    op = _batch(1)
+    K = op.to_dense()
+    rhs = torch.randn(3, 2, 5, 2, dtype=torch.float64)
+    iq, ld = op.inv_quad_logdet(rhs, logdet=True)
+    assert iq.shape == (3, 2) and torch.allclose(ld, torch.logdet(K)) and torch.allclose(iq, (rhs * torch.linalg.solve(K, rhs)).sum((-2, -1)))
+    assert torch.allclose(op.solve(rhs), torch.linalg.solve(K, rhs))
+    assert op[..., 1:4, :2].shape == (3, 2, 3, 2) and op[1].shape == (2, 5, 5) and op[1, 0].shape == (5, 5) and op[:, 0].shape == (3, 5, 5)
+    assert torch.allclose(op[2, 1].to_dense(), K[2, 1])
+    root = op.root_decomposition().root
+    assert torch.allclose(root @ root.mT, K)
+
+
+def test_batch_noise_and_scale():
+    op = _batch(2)
+    K = op.to_dense()
+    noisy = op + ConstantDiagLinearOperator(torch.tensor([[0.5], [1.0]], dtype=torch.float64), 5)   # batch (2,) of noises against batch (3, 2)
+    expect = K + torch.diag_embed(torch.tensor([0.5, 1.0], dtype=torch.float64).view(1, 2, 1).expand(3, 2, 5))
+    assert torch.allclose(noisy.to_dense(), expect)
+    het = op + DiagLinearOperator(torch.rand(3, 2, 5, dtype=torch.float64))
+    assert het.shape == (3, 2, 5, 5)
+    scaled = op.mul(torch.tensor([2.0, 3.0], dtype=torch.float64).view(2, 1, 1))
+    assert torch.allclose(scaled.to_dense(), K * torch.tensor([2.0, 3.0], dtype=torch.float64).view(1, 2, 1, 1))

@@ -280,3 +280,52 @@ def test_deterministic_probes_are_drawn_once_and_reused(dev):
         S.deterministic_probes.probe_vectors = None
     assert a == b
     assert c != e
+
+
+def test_observation_nan_policy_mask(dev):
+    """settings.observation_nan_policy("mask") (mlls/exact_marginal_log_likelihood.py:68-79): NaN targets are dropped from the
+    likelihood -- the MLL equals the dense float64 MLL of the observed subset times n_obs / n (the reference divides by the full
+    event size); "fill" is refused as in the reference."""
+    kind, n, d, ls = "rbf", 900, 2, 0.3
+    X, y = make_data(n, d)
+    g, m, lik = _model(kind, X, y, ls, 1.2, 0.1, dev)
+    yn = y.clone().float()
+    miss = torch.arange(0, n, 7)
+    yn[miss] = float("nan")
+    m.set_train_data(targets=yn.to(dev), strict=False)
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    m.train()
+    lik.train()
+    S = g.settings
+    with S.observation_nan_policy("mask"), S.max_cholesky_size(10_000):
+        val = mll(m(m.train_inputs[0]), m.train_targets)
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[miss] = False
+    ref, _ = OG.dense_mll_and_grads(kind, X[keep], y[keep], ls, 1.2, 0.1)
+    assert abs(float(val) - float(ref) * int(keep.sum()) / n) < 2e-4 * abs(float(ref))
+    with S.observation_nan_policy("fill"), pytest.raises(ValueError):
+        mll(m(m.train_inputs[0]), m.train_targets)
+
+
+def test_duplicate_points_at_the_gram_policy_limit(dev):
+    """Gram-form generation at its accuracy-policy limit (max |z|^2 close to 32) with DUPLICATED points: the reference forces
+    d_ii = 0 and clamps d >= 0 (kernels/kernel.py:45-49); the split-f16 expansion does neither, so K between duplicates is 1 only
+    to ~1e-5 -- the product still meets the stated 2e-5 / 5e-5 bound against the float64 oracle."""
+    from gpytorch_amd import backend as B
+
+    gen = torch.Generator().manual_seed(0)
+    n, t = 1500, 65
+    base = torch.rand(n // 2, 1, generator=gen, dtype=torch.float64)
+    X = torch.cat([base, base], 0)                                  # every point twice
+    ls = 1.04 * 0.5 / math.sqrt(32.0 / 0.7213)                      # puts max |z|^2 just under the policy limit (32) after centring
+    V = torch.randn(n, t, generator=gen, dtype=torch.float64)
+    xp = B.prep_points("rbf", X.float().to(dev), torch.tensor(ls), X.mean(0).float().to(dev))
+    assert 24.0 < xp.zmax2 <= B.GRAM_MAX_SQNORM and B.kv_flags(xp, xp, t) == B.KV_GRAM
+    out = B.from_probe_major(B.kv(xp, xp, B.to_probe_major(V.to(dev))), n)
+    ref = OK.rbf(X, X, ls, x1_eq_x2=True) @ V
+    assert rel_err(out, ref) < 5e-5
+    E = torch.zeros(4, B.round_up(n, 4), device=dev)
+    E[torch.arange(4), torch.arange(4)] = 1.0
+    cols = B.kv(xp, xp, E)[:, :n]                                   # columns 0..3 of K: entries (i, i) and (i, i + n/2) are duplicates
+    dup = torch.stack([cols[c, c] for c in range(4)] + [cols[c, c + n // 2] for c in range(4)])
+    assert float((dup - 1.0).abs().max()) < 2e-5
