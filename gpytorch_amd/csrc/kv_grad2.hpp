@@ -236,13 +236,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * q4 + e;
           float sv = half ? s1[r] : s0[r];
-          sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
           const float w = half ? w1[r] : w0[r];
-          float kv, dk, dpar;
-          cov_and_dcov<KIND>(sv, a.kparam, kv, dk, dpar);
-          f0 = __builtin_fmaf(w, kv, f0);
-          if constexpr (KIND == KIND_RQ) f2 = __builtin_fmaf(w, dpar, f2);
-          const float av = w * dk;
+          float av;
+          if constexpr (KIND == KIND_RBF) {
+            // dk/ds = -ln2 k: accumulate with A' = W k and apply -ln2 once per step (RBF_DK); a slightly negative S (cancellation)
+            // needs no clamp for 2^-S.  3 VALU ops + v_exp_f32 per pair instead of 6.
+            av = w * __builtin_amdgcn_exp2f(-sv);
+            f0 += av;
+          } else {
+            sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
+            float kv, dk, dpar;
+            cov_and_dcov<KIND>(sv, a.kparam, kv, dk, dpar);
+            f0 = __builtin_fmaf(w, kv, f0);
+            if constexpr (KIND == KIND_RQ) f2 = __builtin_fmaf(w, dpar, f2);
+            av = w * dk;
+          }
           if constexpr (MODE == 0) {
             f1 = __builtin_fmaf(av, sv, f1);
           } else {
@@ -252,17 +260,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
       }
     }
+    constexpr float RBF_DK = KIND == KIND_RBF ? -0.6931471805599453f : 1.0f;   // see the consume loop
     g[0] += (double)f0;
     g[1 + DP] += (double)f2;
     if constexpr (MODE == 0) {
-      g[1] += (double)f1;
+      g[1] += (double)(RBF_DK * f1);
     } else {
       // columns: 0 -> rs, 1 + q -> u_q, 1 + D + q -> v_q   (this lane's j half; the combination is linear in them)
-      const float rs = zacc[0][0];
+      const float rs = RBF_DK * zacc[0][0];
 #pragma unroll
       for (int q = 0; q < D; ++q) {
-        const float u = zacc[(1 + q) / 4][(1 + q) % 4];
-        const float v = zacc[(1 + D + q) / 4][(1 + D + q) % 4];
+        const float u = RBF_DK * zacc[(1 + q) / 4][(1 + q) % 4];
+        const float v = RBF_DK * zacc[(1 + D + q) / 4][(1 + D + q) % 4];
         const double zq = (double)zi[q];
         g[1 + q] += zq * zq * (double)rs - 2.0 * zq * (double)u + (double)v;
         gx[q] += 2.f * (zi[q] * rs - u);
