@@ -40,6 +40,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 MFMA peak (same guide; the sparsity figures are not used)
 
 
 def synth(n, d, seed=0):
@@ -188,6 +189,11 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="override the number of training points n (not --n: torch.distributed.run's parser treats that as an ambiguous prefix)")
     ap.add_argument("--dims", type=int, default=3)
     ap.add_argument("--probes", type=int, default=None, help="override: probes per GPU (metric / c2) or in total (c4)")
+    ap.add_argument("--contraction", choices=["f32", "split"], default="f32",
+                    help="K*V contraction of the TIMED steps: f32 = v_mfma_f32_32x32x2_f32 (the metric's fp32-MFMA roofline; default), "
+                         "split = hi/lo-split operands on the f16 matrix pipe (the library default, settings.split_contraction). "
+                         "The other one is measured once, untimed, and reported beside it (block 'split_contraction').")
+    ap.add_argument("--skip-split", action="store_true", help="skip the untimed step on the other contraction path")
     ap.add_argument("--skip-parity", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="skip the untimed API-level MLL fwd+bwd / posterior timings")
@@ -216,7 +222,10 @@ def main():
 
     from gpytorch_amd import backend as B
     from gpytorch_amd import linear_cg as LCG
+    from gpytorch_amd import settings as gsettings
     from gpytorch_amd.bbmm import LOG_2PI, inv_quad_logdet_forward
+
+    gsettings.split_contraction._set_state(args.contraction == "split")
 
     strong = args.config == "c4"
     n = args.size if args.size is not None else {"metric": 500_000, "c2": 100_000, "c4": 1_000_000}[args.config]
@@ -298,10 +307,79 @@ def main():
     if rank == 0 and not args.skip_parity:
         parity = parity_block(B.prep_points("rbf", Xd, lengthscale, shift), X, n, d, cols, ls, dev)
 
+    # the other contraction path: one untimed step on the same inputs (same probe stream), its kernel timed the same way
+    other = None
+    if world == 1 and not args.skip_split:
+        split_now = args.contraction != "split"
+        with gsettings.split_contraction(split_now):
+            gen.manual_seed(1234 + rank)
+            step()
+            LCG.KV_EVENT_LOG = []
+            gen.manual_seed(1234 + rank)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            mll_o, it_o = step()
+            torch.cuda.synchronize(dev)
+            el_o = time.perf_counter() - t1
+            d_o = sorted(e0.elapsed_time(e1) for (e0, e1, _, _, _) in LCG.KV_EVENT_LOG)
+            LCG.KV_EVENT_LOG = None
+            live_o = [x for x in d_o if x > 0.2 * d_o[len(d_o) // 2]]
+            ms_o = sum(live_o) / len(live_o)
+            other = {
+                "contraction": "split (hi/lo f16 operands on v_mfma_f32_32x32x16_f16, f32 accumulate; settings.split_contraction, "
+                               "the library default)" if split_now else "f32 (v_mfma_f32_32x32x2_f32)",
+                "kernel_ms": ms_o,
+                "kv_tflops_f32_equivalent": flop_per_launch / (ms_o * 1e-3) / 1e12,
+                "speedup_vs_timed_path": kv_ms / ms_o,
+                "ms_per_step": el_o * 1e3,
+                "cg_iterations": it_o,
+                "mll": float(mll_o),
+                "launches_timed": len(live_o),
+            }
+            if split_now:
+                # three f16 MFMAs per f32-equivalent multiply-add: executed flops against the dense f16 peak
+                ex = 3.0 * flop_per_launch / (ms_o * 1e-3) / 1e12
+                other["roofline"] = {"bound": "mfma", "achieved": ex, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s (f16, executed = 3 x algorithmic)",
+                                     "frac": ex / PEAK_F16_MFMA_TFLOPS, "kernel": "kv_gramh_kernel (csrc/kv_gramh.hpp)"}
+            if not args.skip_parity:
+                other["parity"] = parity_block(B.prep_points("rbf", Xd, lengthscale, shift), X, n, d, cols, ls, dev)
+
     extras = None
     if world == 1 and not args.skip_extras:
+        gsettings.split_contraction._set_state(None)   # API-level timings on the library defaults (split contraction on)
         extras = api_level_extras(Xd, yd, ls, t, dev)
+        extras["kv_contraction"] = "library default: split" if gsettings.split_contraction.on() else "f32"
 
+    if args.contraction == "f32":
+        roofline = {
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": traffic,
+            "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+            "kernel": f"kv_gram_kernel<RBF,D=3,CT={(cols - 1) // 32 if cols % 32 == 1 else (cols + 31) // 32},EX={1 if cols % 32 == 1 else 0}> on rank 0 (Gram-form generation "
+                      "on split-f16 MFMA + fp32 MFMA contraction; kv_mfma_kernel when max|z|^2 > 32)",
+            "kernel_ms": kv_ms,
+            "launches_timed": len(live),
+            "flop_per_launch": flop_per_launch,
+        }
+    else:
+        # three f16 MFMAs per f32-equivalent multiply-add: EXECUTED flops (3 x algorithmic) against the dense f16 peak
+        roofline = {
+            "bound": "mfma",
+            "achieved": 3.0 * achieved,
+            "peak": PEAK_F16_MFMA_TFLOPS,
+            "unit": "TFLOP/s (f16 MFMA, executed = 3 x algorithmic)",
+            "frac": 3.0 * achieved / PEAK_F16_MFMA_TFLOPS,
+            "traffic": None,
+            "kernel": "kv_gramh_kernel<RBF,D=3> on rank 0 (Gram-form generation and hi/lo-split contraction on v_mfma_f32_32x32x16_f16)",
+            "kernel_ms": kv_ms,
+            "launches_timed": len(live),
+            "flop_per_launch": flop_per_launch,
+            "algorithmic_tflops": achieved,
+        }
     if rank == 0:
         out = {
             "metric": "exactgp_mll_kv_tflops",
@@ -314,11 +392,11 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.contraction == "f32" else "f32 emulated on f16 MFMA (hi/lo-split operands, 21-22 bits, f32 accumulate)",
             "data": "synthetic",
             "config": {
                 "workload": f"ExactGP MLL evaluation (mBCG + SLQ), RBF, n={n}, d={d}, {t_total} probes in total ({t} on rank 0) + y column, "
-                            f"fused K*V HIP kernel, no preconditioner, cg_tolerance=1.0 (--config {args.config}: "
+                            f"fused K*V HIP kernel ({args.contraction} contraction), no preconditioner, cg_tolerance=1.0 (--config {args.config}: "
                             + {"metric": "the configuration BASELINE.json's metric is quoted on", "c2": "BASELINE configs[1]",
                                "c4": "BASELINE configs[3], 256 probes split over the ranks"}[args.config] + ")",
                 "name": args.config, "n": n, "d": d, "probes_total": t_total, "probes_rank0": t, "rhs_columns_rank0": cols,
@@ -326,23 +404,12 @@ def main():
                 "parallelism": f"probe-sharded x{world}, y column on rank 0",
             },
             "mll": float(mll),
-            "roofline": {
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": traffic,
-                "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
-                "kernel": f"kv_gram_kernel<RBF,D=3,CT={(cols - 1) // 32 if cols % 32 == 1 else (cols + 31) // 32},EX={1 if cols % 32 == 1 else 0}> on rank 0 (Gram-form generation "
-                          "on split-f16 MFMA + fp32 MFMA contraction; kv_mfma_kernel when max|z|^2 > 32)",
-                "kernel_ms": kv_ms,
-                "launches_timed": len(live),
-                "flop_per_launch": flop_per_launch,
-            },
+            "roofline": roofline,
         }
         if parity is not None:
             out["parity"] = parity
+        if other is not None:
+            out["split_contraction" if args.contraction != "split" else "f32_contraction"] = other
         if extras is not None:
             out["extras"] = extras
         if not args.skip_cpu_baseline and world == 1:  # timed on rank 0 at N = 1 only

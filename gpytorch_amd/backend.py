@@ -48,6 +48,8 @@ def work_dtype(t: torch.Tensor) -> torch.dtype:
 KV_GRAM = 1              # flag of gpamd_kv_partials_f32 (include/gpamd.h)
 KV_WIDE = 2              # with KV_GRAM, tuning / A-B only: keep 3..32 columns off the 4-column-group kernel (kv_gram4.hpp)
 KV_G4 = 4                # with KV_GRAM, tuning / A-B only: 9..12 columns on kv_gram4 (three groups) instead of kv_gram16
+KV_SPLIT = 8             # with KV_GRAM, >= 5 columns: contraction of hi/lo-split operands on the f16 matrix pipe (kv_gramh.hpp)
+SPLIT_CONTRACTION = None  # tests / tuning: force True / False; None -> settings.split_contraction
 GRAM_MAX_SQNORM = 32.0   # max |z|^2 for which the split-f16 quadratic expansion keeps K within 2e-5 (gram_f16.hpp)
 FORCE_GENERIC = False    # tests: send float32 / d <= 16 problems down the generic (row-block + GEMM) path too
 FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or KV_GRAM regardless of |z|
@@ -97,7 +99,15 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
         return FORCE_KV_FLAGS
     if x1.kind == "matern12":
         return 0
-    return KV_GRAM if max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) <= GRAM_MAX_SQNORM else 0
+    if max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) > GRAM_MAX_SQNORM:
+        return 0
+    if SPLIT_CONTRACTION is None:
+        from . import settings
+
+        split = settings.split_contraction.on()
+    else:
+        split = SPLIT_CONTRACTION
+    return KV_GRAM | (KV_SPLIT if split else 0)
 
 
 def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: torch.Tensor | None = None, param=None) -> PreparedPoints:

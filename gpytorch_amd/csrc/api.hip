@@ -14,6 +14,7 @@
 #include "kv_gramv.hpp"
 #include "kv_gram4.hpp"
 #include "kv_gram16.hpp"
+#include "kv_vsplit.hpp"
 #include "misc_kernels.hpp"
 
 using namespace gpamd;
@@ -70,6 +71,8 @@ struct KvVariant {
   int tpad;    // valu: 1,2,4,8
   int ct, ex;  // mfma
   int g4;      // > 0: kv_gram4 with this many column groups of four (2, 3, 6); 16 / 17: kv_gram16 without / with EX
+  bool split;  // kv_gramh: contraction of hi/lo-split operands on the f16 matrix pipe (ct, ex as for mfma)
+  int ni;      // kv_gramh: 32-row tiles per wave
   int bm;      // rows per workgroup
   int bn;      // j tile
 };
@@ -84,7 +87,14 @@ bool gram_ok(int kind, int flags);
 KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false) {  // t <= 129 handled per launch group; light: RBF, d <= 3
   KvVariant v{};
   const bool wide = flags & GPAMD_KV_WIDE;
-  if (gram && !wide && t >= 5 && t <= 24) {
+  if (gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KGH_GROUP + 1) {
+    v.split = true;
+    v.ex = (t % 32 == 1) ? 1 : 0;
+    v.ct = (t - v.ex + 31) / 32;
+    v.ni = kgh_ni(v.ct);
+    v.bm = kgh_bm(v.ni);
+    v.bn = KGH_BN;
+  } else if (gram && !wide && t >= 5 && t <= 24) {
     if (t <= 8) v.g4 = 2;
     else if (t <= 12 && (flags & GPAMD_KV_G4)) v.g4 = 3;
     else if (t <= 16) v.g4 = 16;   // kv_gram16
@@ -118,18 +128,60 @@ KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false) {  /
 
 constexpr int KV_GROUP = 128;  // columns per launch group (CT = 4); a trailing 129th column rides as EX
 
-// split [0, t) into launch groups of <= 128 (+1) columns
-int group_cols(int t, int g0) {
+bool split_on(int kind, int flags) { return gram_ok(kind, flags) && (flags & GPAMD_KV_SPLIT); }
+
+// split [0, t) into launch groups of <= cap (+1) columns: cap = 128, or 64 for the split-operand kernels
+int group_cols(int t, int g0, int cap = KV_GROUP) {
   int rem = t - g0;
-  if (rem <= KV_GROUP + 1) return rem;  // includes the 129 = 128 + EX case
-  return KV_GROUP;
+  if (rem <= cap + 1) return rem;  // includes the cap + EX case
+  return cap;
+}
+int group_cap(int kind, int flags) { return split_on(kind, flags) ? KGH_GROUP : KV_GROUP; }
+
+// Split-operand launches keep, behind the S partial slabs of the workspace: column maxima | column multipliers | the two f16
+// planes of every launch group (32 ct rows of ldh positions each).  Offsets in floats, all multiples of 4.
+struct SplitLayout {
+  int64_t base, colmax, colmul, planes, total;   // total: floats behind `base`
+  int64_t ldh;
+  int rows;                                      // plane rows over all split groups
+};
+SplitLayout split_layout(int kind, int flags, int m, int t, int S, int64_t ldo) {
+  SplitLayout L{};
+  L.base = ((int64_t)S * t * ldo + 3) / 4 * 4;
+  L.ldh = ((int64_t)m + KGH_BN - 1) / KGH_BN * KGH_BN;
+  if (!split_on(kind, flags)) return L;
+  const int cap = group_cap(kind, flags);
+  int rows = 0;
+  for (int g0 = 0; g0 < t;) {
+    const int tg = group_cols(t, g0, cap);
+    KvVariant v = pick_variant(tg, true, flags, false);
+    if (v.split) rows += 32 * v.ct;
+    g0 += tg;
+  }
+  L.rows = rows;
+  if (!rows) return L;
+  const int64_t ncol = (2 * (int64_t)t + 64 + 3) / 4 * 4;   // 32 ct + 1 multiplier slots per group (<= t + 32 groups + 1)
+  L.colmax = 0;
+  L.colmul = ncol;
+  L.planes = 2 * ncol;
+  L.total = 2 * ncol + (int64_t)rows * L.ldh;    // two f16 planes = rows * ldh floats
+  return L;
 }
 
 int kernel_dims(int d) {  // kernels exist for these valid-dimension counts; other d use the next one
   return d <= 6 ? d : (d <= 8 ? 8 : (d <= 10 ? 10 : (d <= 12 ? 12 : 16)));
 }
 
-const void* family_ptr(int kind, int mode, int d, int v, int ex) {
+const void* family_ptr(int kind, int mode, int d, int v, int ex, int ni = 0) {
+  if (mode == KV_MODE_GRAMH) {
+    switch (kind) {
+      case GPAMD_RBF: return kvh_kernel_ptr_rbf(d, v, ex, ni);
+      case GPAMD_MATERN32: return kvh_kernel_ptr_matern32(d, v, ex, ni);
+      case GPAMD_MATERN52: return kvh_kernel_ptr_matern52(d, v, ex, ni);
+      case GPAMD_RQ: return kvh_kernel_ptr_rq(d, v, ex, ni);
+    }
+    return nullptr;
+  }
   if (mode == KV_MODE_GRAM4) {
     switch (kind) {
       case GPAMD_RBF: return kvm_kernel_ptr_rbf(d, v);
@@ -162,6 +214,7 @@ bool gram_ok(int kind, int flags) { return (flags & GPAMD_KV_GRAM) && kind != GP
 
 int kv_mode(int kind, int flags, int d, const KvVariant& v) {
   const bool gram = gram_ok(kind, flags);
+  if (v.split) return KV_MODE_GRAMH;
   if (v.g4) return KV_MODE_GRAM4;
   if (v.valu) return gram ? KV_MODE_GRAMV : KV_MODE_VALU;
   return gram ? KV_MODE_GRAM : KV_MODE_MFMA;
@@ -179,10 +232,11 @@ int variant_key(const KvVariant& v) { return v.g4 ? v.g4 : (v.valu ? v.tpad : v.
 
 // resident workgroups per CU of the selected kernel (runtime occupancy query; static table without a device)
 int wg_per_cu(int kind, int mode, int dk, const KvVariant& v) {
-  const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex);
+  const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex, v.ni);
   int nb = 0;
   if (fn && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) return nb;
   (void)hipGetLastError();
+  if (v.split) return 3;
   if (v.g4) return 2;
   if (v.valu) return 4;
   if (mode == KV_MODE_GRAM) return 3;
@@ -194,7 +248,8 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // runs in ceil(units / slots) rounds of resident workgroups: pick the S whose last round is nearly
   // full (efficiency = units / (rounds * slots)), keeping every chunk >= 16 LDS tiles (per-unit prologue
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
-  KvVariant v = pick_variant(t > KV_GROUP + 1 ? KV_GROUP : t, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3);
+  const int cap = group_cap(kind, flags);
+  KvVariant v = pick_variant(t > cap + 1 ? cap : t, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3);
   const int mode = kv_mode(kind, flags, d, v);
   variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
@@ -264,7 +319,10 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
   plan_split(kind, n, m, d, t, flags, &S, &jc);
   if (S_host) *S_host = S;
   if (jchunk_host) *jchunk_host = jc;
-  if (workspace_floats_host) *workspace_floats_host = (int64_t)S * t * ldo;
+  if (workspace_floats_host) {
+    const SplitLayout L = split_layout(kind, flags, m, t, S, ldo);
+    *workspace_floats_host = L.total ? L.base + L.total : (int64_t)S * t * ldo;
+  }
   return 0;
 }
 
@@ -281,12 +339,23 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
   if (!aligned16(Vt) || !aligned16(X1p) || !aligned16(X2p)) return fail(GPAMD_EINVAL, "kv: buffers must be 16-byte aligned");
   if (jchunk % 4 || (int64_t)jchunk * S < m) return fail(GPAMD_EINVAL, "kv: jchunk*S must cover m and jchunk % 4 == 0");
   hipStream_t st = (hipStream_t)stream;
+  const int cap = group_cap(kind, flags);
+  const SplitLayout L = split_layout(kind, flags, m, t, S, ldo);
+  float* xbase = P + L.base;
+  if (L.total) {
+    if (!aligned16(P) || ldo % 4) return fail(GPAMD_EINVAL, "kv: the split-operand path needs a 16-byte aligned workspace and ldo % 4 == 0");
+    if (jchunk % KGH_BN) return fail(GPAMD_EINVAL, "kv: the split-operand path needs jchunk % 128 == 0 (use gpamd_kv_plan)");
+    (void)hipMemsetAsync(xbase + L.colmax, 0, sizeof(float) * (size_t)L.colmul, st);
+  }
+  int64_t prow = 0;   // plane rows used so far
+  int mulslot = 0;    // multiplier slots used so far
   for (int g0 = 0; g0 < t;) {
-    const int tg = group_cols(t, g0);
+    const int tg = group_cols(t, g0, cap);
     KvVariant v = pick_variant(tg, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3);
     const int mode = kv_mode(kind, flags, d, v);
     variant_geometry(mode, &v);
-    KvArgs a;
+    KvhArgs ka;
+    KvArgs& a = ka.a;
     a.X1 = X1p; a.X2 = X2p;
     a.Vt = Vt + (int64_t)g0 * ldv;
     a.P = P + (int64_t)g0 * ldo;
@@ -297,10 +366,29 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.done = done;
     a.kparam = g_kparam;
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
-    const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex);
+    const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex, v.ni);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
-    void* kargs[] = {(void*)&a};
-    (void)hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, 0, st);
+    if (v.split) {
+      // pre-pass: per-column scale + the two f16 planes of this group's matrix-pipe columns (the extra column stays f32)
+      const int tc = 32 * v.ct, tm = tg - v.ex;
+      unsigned* colmax = reinterpret_cast<unsigned*>(xbase + L.colmax) + mulslot;
+      float* colmul = xbase + L.colmul + mulslot;
+      _Float16* vh = reinterpret_cast<_Float16*>(xbase + L.planes) + 2 * prow * L.ldh;
+      _Float16* vl = vh + (int64_t)tc * L.ldh;
+      unsigned nbm = (unsigned)((m + 4095) / 4096);
+      if (nbm > 64) nbm = 64;
+      hipLaunchKernelGGL(vsplit_colmax_kernel, dim3(nbm, tm), dim3(256), 0, st, a.Vt, ldv, m, colmax, done);
+      hipLaunchKernelGGL(vsplit_kernel, dim3((unsigned)((L.ldh / 8 + 255) / 256), tc), dim3(256), 0, st, a.Vt, ldv, m, tm, vh, vl,
+                         L.ldh, (const unsigned*)colmax, colmul, done);
+      ka.Vh = vh; ka.Vl = vl; ka.ldh = L.ldh; ka.colmul = colmul;
+      prow += tc;
+      mulslot += tc + 1;
+      void* kargs[] = {(void*)&ka};
+      (void)hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, 0, st);
+    } else {
+      void* kargs[] = {(void*)&a};
+      (void)hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, 0, st);
+    }
     int rc = check_launch("kv_partials");
     if (rc) return rc;
     g0 += tg;

@@ -61,7 +61,7 @@ __device__ __forceinline__ _Float16 gram_slot_b(int s, const _Float16* bh, const
 
 // B operands of one output row for this lane's k-group h (elements 8h .. 8h+7 of every 16-slot group)
 template <int D>
-__device__ __forceinline__ void gram_pack_b(const float* z, int h, f16x8* out /* [KH] */) {
+__device__ __forceinline__ void gram_pack_b(const float* z, int h, f16x8* out /* [KH] */, float nshift = 0.f) {
   constexpr int KH = GramF16<D>::KH;
   _Float16 bh[D], bl[D], nh, nl;
   float nn = 0.f;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void gram_pack_b(const float* z, int h, f16x8* out /*
     nn = __builtin_fmaf(z[k], z[k], nn);
     f16_split(-2.f * z[k], bh[k], bl[k]);
   }
-  f16_split(nn, nh, nl);
+  f16_split(nn - nshift, nh, nl);   // nshift: S comes out as S - nshift (kv_gramh.hpp folds its 2^KSHIFT scale of K here)
 #pragma unroll
   for (int kh = 0; kh < KH; ++kh)
 #pragma unroll

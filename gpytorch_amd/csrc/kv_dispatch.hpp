@@ -4,7 +4,7 @@
 
 namespace gpamd {
 
-enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3, KV_MODE_GRAM4 = 4 };
+enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3, KV_MODE_GRAM4 = 4, KV_MODE_GRAMH = 5 };
 
 // MFMA / Gram variants: CT 32-column tiles (1..4) + EX extra VALU column; NI row tiles per wave by CT.
 // NI*CT*16 accumulator registers: 64 (CT <= 2) .. 128 (CT = 4)
@@ -28,5 +28,11 @@ const void* kvm_kernel_ptr_rbf(int d, int groups);
 const void* kvm_kernel_ptr_matern32(int d, int groups);
 const void* kvm_kernel_ptr_matern52(int d, int groups);
 const void* kvm_kernel_ptr_rq(int d, int groups);
+
+// split-operand kernels: generation and contraction on the f16 matrix pipe (kvh_<family>.hip); ct = 1, 2
+const void* kvh_kernel_ptr_rbf(int d, int ct, int ex, int ni);
+const void* kvh_kernel_ptr_matern32(int d, int ct, int ex, int ni);
+const void* kvh_kernel_ptr_matern52(int d, int ct, int ex, int ni);
+const void* kvh_kernel_ptr_rq(int d, int ct, int ex, int ni);
 
 }  // namespace gpamd

@@ -244,6 +244,18 @@ class deterministic_probes(_feature_flag):
     probe_vectors = None
 
 
+class split_contraction(_feature_flag):
+    """(no counterpart in the reference.)  With five or more right-hand sides the fused ``K @ V`` contraction runs on the f16
+    matrix pipe at float32 accuracy: both operands are split exactly into f16 hi + lo parts (21-22 significant bits, per-column
+    power-of-two scaling, float32 accumulation) -- three ``v_mfma_f32_32x32x16_f16`` in place of eight
+    ``v_mfma_f32_32x32x2_f32`` (``csrc/kv_gramh.hpp``; 2.5x at n = 500 000, 65 columns, same 2e-5 bound against the float64
+    oracle).  ``split_contraction(False)`` keeps the contraction on the float32 MFMA instructions; the environment variable
+    ``GPAMD_KV_SPLIT=0`` sets that as the process default."""
+    import os as _os
+
+    _default = _os.environ.get("GPAMD_KV_SPLIT", "1") not in ("0", "")
+
+
 class fast_computations:
     """``linear_operator.settings.fast_computations``: three independent flags."""
 

@@ -43,7 +43,12 @@ enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 enum {
   GPAMD_KV_GRAM = 1,
   GPAMD_KV_WIDE = 2, /* tuning / A-B only: with GRAM, the pre-round-2 selection (no kv_gram4 / kv_gram16) */
-  GPAMD_KV_G4 = 4    /* tuning / A-B only: with GRAM, 9..12 columns on kv_gram4 instead of kv_gram16 */
+  GPAMD_KV_G4 = 4,   /* tuning / A-B only: with GRAM, 9..12 columns on kv_gram4 instead of kv_gram16 */
+  /* with GRAM, >= 5 columns: the contraction K * V runs on the f16 matrix pipe at f32 accuracy -- both operands split exactly
+   * into f16 hi + lo parts (21-22 significant bits, power-of-two column scaling, f32 accumulation), three
+   * v_mfma_f32_32x32x16_f16 in place of eight v_mfma_f32_32x32x2_f32 (kv_gramh.hpp).  The f16 planes of V live behind the
+   * partial slabs of the workspace: size it with gpamd_kv_plan called with the same flags. */
+  GPAMD_KV_SPLIT = 8
 };
 
 int gpamd_abi_version(void);
@@ -56,7 +61,8 @@ int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, c
                           const float* shift, float* Xp, int dp, void* stream);
 
 /* Launch plan for one fused K*V: split count S and j-chunk so the grid is a whole number of chip fills of the
- * kernel variant that (kind, d, t, flags) selects.  Outputs on the host. workspace_floats = S * t * ldo. */
+ * kernel variant that (kind, d, t, flags) selects.  Outputs on the host. workspace_floats = S * t * ldo (the partial slabs),
+ * plus the split operand planes when flags carries GPAMD_KV_SPLIT. */
 int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, int* S_host, int* jchunk_host,
                   int64_t* workspace_floats_host);
 

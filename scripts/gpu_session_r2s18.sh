@@ -1,0 +1,7 @@
+#!/bin/bash
+set +e
+OUT=gpurun_out/r2s18; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_gpu_kv_split.py -m gpu -q -x -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
+grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/pytest.log | head -20
+timeout 300 python scripts/kgh_ablate.py r2s18 > $OUT/ablate.log 2>&1; echo "ablate rc=$?"; grep -E "^\{|Error|error" $OUT/ablate.log | cut -c1-300
+timeout 300 python scripts/kv_split_time.py r2s18 500000 64,65,32 > $OUT/time.log 2>&1; echo "rc=$?"; grep -E "^\{|Error|error" $OUT/time.log | cut -c1-420

@@ -153,9 +153,9 @@ def test_kv_gram_policy(dev):
     sh = X.mean(0).float().to(dev)
     wide = _prep("rbf", X, 0.5, dev, sh)
     narrow = _prep("rbf", X, 0.02, dev, sh)
-    assert B.kv_flags(wide, wide, 65) == B.KV_GRAM
+    assert B.kv_flags(wide, wide, 65) & B.KV_GRAM
     assert B.kv_flags(narrow, narrow, 65) == 0
-    assert B.kv_flags(wide, wide, 4) == B.KV_GRAM
+    assert B.kv_flags(wide, wide, 4) & B.KV_GRAM
     assert B.kv_flags(_prep("matern12", X, 0.5, dev, sh), _prep("matern12", X, 0.5, dev, sh), 65) == 0
     # and the short-lengthscale problem is still accurate (direct path)
     V = torch.randn(500, 33, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
