@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgpamd.so")
+# GPAMD_LIBRARY: A/B builds of the same ABI (tuning sessions only); the product is csrc/libgpamd.so
+LIB_PATH = os.environ.get("GPAMD_LIBRARY") or os.path.join(_HERE, "csrc", "libgpamd.so")
 
 _lib = None
 

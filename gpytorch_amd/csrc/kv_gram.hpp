@@ -177,7 +177,9 @@ void kv_gram_kernel(KvArgs a) {
         for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(&Vs[(ct * 32 + l31) * LDT + jl]);
         f32x4 ev;
         if constexpr (EX) ev = *reinterpret_cast<const f32x4*>(&Es[jl]);
+#ifndef GPAMD_NO_SETPRIO   // A/B: 240.7 ms with, 245.0-246.0 ms without (n = 500 000, 65 columns; profiles/r02_s23_setprio_ab_fp32_kernel.txt)
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
 #pragma unroll
@@ -188,7 +190,9 @@ void kv_gram_kernel(KvArgs a) {
             if constexpr (EX) eacc[ni] = __builtin_fmaf(kk[ni][4 * g + st], ev[st], eacc[ni]);
           }
         }
+#ifndef GPAMD_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
       }
     }
   }

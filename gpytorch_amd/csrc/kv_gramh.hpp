@@ -99,7 +99,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // written in that order and __builtin_amdgcn_sched_group_barrier pins the interleave "1 MFMA : VPM VALU".  To keep the pipeline
 // full across LDS tiles the split x_j rows (and the extra column) are staged ONE TILE AHEAD (double-buffered): the last step
 // of a tile generates the first block of the next one.
-// ABL (ablation builds of libgpamd_tune.so only; 0 in the product): 1 no generation VALU, 2 no contraction MFMAs, 3 V planes staged
+// ABL (ablation builds of libgpamd_tune.so only; 0 in the product; 6 = register prefetch of the next tile): 1 no generation VALU, 2 no contraction MFMAs, 3 V planes staged
 // once (no global loads / LDS writes per tile; barriers stay), 4 as 3 and no barriers, 5 A operands read once per tile
 template <int KIND, int D, int CT, int NI, int EX, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -109,7 +109,10 @@ void kv_gramh_kernel(KvhArgs ka) {
   constexpr int KH = GramF16<D>::KH;
   constexpr int BN = KGH_BN, LDH = KGH_LDH, TC = 32 * CT;
   constexpr int XHS = KH * BN * 16;     // f16 elements of one Xh buffer
-  constexpr bool PF = NI * CT <= 4 && KH <= 2;   // A operands of block jb + 32 fetched during block jb (16 CT more registers)
+  // V planes / x rows of the next tile prefetched into registers during compute: measured, no gain (86.2 vs 86.3 ms at n = 500 000,
+  // 64 columns, profiles/r02_s22_kgh_ablate.json) -- what staging costs is LDS-write and L2 throughput, not latency; tune builds only
+  constexpr bool VPF = (ABL == 6);
+  constexpr bool PF = NI * CT <= 4 && KH <= 2 && !VPF;   // A operands of block jb + 32 fetched during block jb (16 CT more registers)
   __shared__ __attribute__((aligned(16))) _Float16 Vhs[TC * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 Vls[TC * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 Xh[2 * XHS];        // [buf][kh][j][16] split augmented x_j rows
@@ -150,23 +153,25 @@ void kv_gramh_kernel(KvhArgs ka) {
 
   constexpr int VQ = TC * (BN / 8) / 256;   // 16-byte chunks per thread and plane (= 2 CT)
 
-  // split x_j rows + extra column of the tile starting at j0 -> buffer `buf` (rows beyond jend: zero -> k = 2^KSHIFT, V = 0)
-  auto stage_x = [&](int j0, int buf) {
+  // split x_j rows + extra column of the tile starting at j0 -> buffer `buf` (rows beyond jend: zero -> k = 2^KSHIFT, V = 0).
+  // Two halves so that the global loads can be issued a whole tile of compute ahead of the LDS writes (VPF).
+  float xz[DP];
+  f32x4 xe = {0.f, 0.f, 0.f, 0.f};
+  bool xvalid = false;
+  auto load_x = [&](int j0) {
     if (tid < BN) {
       const int j = j0 + tid;
-      float z[DP];
+      xvalid = j < jend;
 #pragma unroll
       for (int q = 0; q < DQ; ++q) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP + 4 * q);
-        z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
+        xz[4 * q + 0] = v[0]; xz[4 * q + 1] = v[1]; xz[4 * q + 2] = v[2]; xz[4 * q + 3] = v[3];
       }
-      gram_pack_a<D>(z, j < jend, Xh + buf * XHS, tid, BN);
     }
     if constexpr (EX) {
       if (tid >= BN && tid < BN + BN / 4) {
-        const int q = tid - BN;
-        const int j = j0 + 4 * q;
+        const int j = j0 + 4 * (tid - BN);
         const float* src = a.Vt + (int64_t)TC * a.ldv + j;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (j + 4 <= jend) {
@@ -176,12 +181,21 @@ void kv_gramh_kernel(KvhArgs ka) {
           for (int e = 0; e < 4; ++e)
             if (j + e < jend) v[e] = src[e];
         }
-        *reinterpret_cast<f32x4*>(&Es[buf * BN + 4 * q]) = v;
+        xe = v;
       }
     }
   };
+  auto store_x = [&](int buf) {
+    if (tid < BN) gram_pack_a<D>(xz, xvalid, Xh + buf * XHS, tid, BN);
+    if constexpr (EX) {
+      if (tid >= BN && tid < BN + BN / 4) *reinterpret_cast<f32x4*>(&Es[buf * BN + 4 * (tid - BN)]) = xe;
+    }
+  };
+  auto stage_x = [&](int j0, int buf) {
+    load_x(j0);
+    store_x(buf);
+  };
 
-  // generation of one step: squared distances (matrix pipe) -> K (VALU) -> extra column -> packed hi / lo B operands
   auto load_aq = [&](int buf, int jb, f16x8* aq) {
 #pragma unroll
     for (int kh = 0; kh < KH; ++kh) aq[kh] = *reinterpret_cast<const f16x8*>(&Xh[buf * XHS + (kh * BN + jb + l31) * 16 + 8 * h]);
@@ -254,30 +268,48 @@ void kv_gramh_kernel(KvhArgs ka) {
     finish_half(kk, 1, 0, 0, 0, bh[1], bl[1]);
   }
 
+  // V planes of one tile: global -> registers (-> LDS between the barriers).  VPF: the loads of tile k + 1 are issued right
+  // after the barrier that opens tile k, so their latency hides under a whole tile of compute.
+  u32x4 pvh[VQ], pvl[VQ];
+  auto load_v = [&](int j0) {
+    const int64_t jc = min((int64_t)j0, ka.ldh - BN);   // past the chunk end: any in-bounds tile (never consumed)
+#pragma unroll
+    for (int rr = 0; rr < VQ; ++rr) {
+      const int idx = tid + 256 * rr;
+      const int c = idx / (BN / 8), q = idx % (BN / 8);
+      const int64_t off = (int64_t)c * ka.ldh + jc + 8 * q;
+      pvh[rr] = *reinterpret_cast<const u32x4*>(ka.Vh + off);
+      pvl[rr] = *reinterpret_cast<const u32x4*>(ka.Vl + off);
+    }
+  };
+  if constexpr (VPF) {
+    load_v(jbeg);
+    load_x(jbeg + BN);
+  }
+
   int buf = 0;
   for (int j0 = jbeg; j0 < jend; j0 += BN, buf ^= 1) {
     if (ABL != 4) __syncthreads();   // every wave is done with the V planes of the previous tile and with Xh[buf ^ 1]
     if ((ABL != 3 && ABL != 4) || j0 == jbeg) {
-      u32x4 vh[VQ], vl[VQ];
-#pragma unroll
-      for (int rr = 0; rr < VQ; ++rr) {
-        const int idx = tid + 256 * rr;
-        const int c = idx / (BN / 8), q = idx % (BN / 8);
-        const int64_t off = (int64_t)c * ka.ldh + j0 + 8 * q;
-        vh[rr] = *reinterpret_cast<const u32x4*>(ka.Vh + off);
-        vl[rr] = *reinterpret_cast<const u32x4*>(ka.Vl + off);
+      if constexpr (!VPF) {
+        load_v(j0);
+        load_x(j0 + BN);   // past the end of the chunk: zero rows and a zero extra column (the last step's look-ahead generation
+                           // must stay finite and add nothing to the extra column)
       }
-      stage_x(j0 + BN, buf ^ 1);   // past the end of the chunk: zero rows and a zero extra column (the last step's look-ahead
-                                   // generation must stay finite and add nothing to the extra column)
+      store_x(buf ^ 1);
 #pragma unroll
       for (int rr = 0; rr < VQ; ++rr) {
         const int idx = tid + 256 * rr;
         const int c = idx / (BN / 8), q = idx % (BN / 8);
-        *reinterpret_cast<u32x4*>(&Vhs[c * LDH + 8 * q]) = vh[rr];
-        *reinterpret_cast<u32x4*>(&Vls[c * LDH + 8 * q]) = vl[rr];
+        *reinterpret_cast<u32x4*>(&Vhs[c * LDH + 8 * q]) = pvh[rr];
+        *reinterpret_cast<u32x4*>(&Vls[c * LDH + 8 * q]) = pvl[rr];
       }
     }
     if (ABL != 4 || j0 == jbeg) __syncthreads();
+    if constexpr (VPF) {   // next tile's global loads fly during this tile's compute
+      load_v(j0 + BN);
+      load_x(j0 + 2 * BN);
+    }
 
     // A operands of a block (V planes): 16 contiguous bytes per (16-row half, column tile, plane).  Block jb + 32's are
     // fetched during block jb (LDS latency off the critical path); only the first block of a tile waits for them.
