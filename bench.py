@@ -269,7 +269,9 @@ def main():
     t0 = time.perf_counter()
     iters_total = 0
     mll = None
+    gen_state = None
     for _ in range(args.steps):
+        gen_state = gen.get_state()   # (the untimed step on the other contraction path re-uses the last step's probe draw)
         mll, it = step()
         iters_total += it
     barrier()
@@ -312,10 +314,10 @@ def main():
     if world == 1 and not args.skip_split:
         split_now = args.contraction != "split"
         with gsettings.split_contraction(split_now):
-            gen.manual_seed(1234 + rank)
+            gen.set_state(gen_state)
             step()
             LCG.KV_EVENT_LOG = []
-            gen.manual_seed(1234 + rank)
+            gen.set_state(gen_state)      # same probe vectors as the last timed step
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             mll_o, it_o = step()
@@ -333,7 +335,9 @@ def main():
                 "speedup_vs_timed_path": kv_ms / ms_o,
                 "ms_per_step": el_o * 1e3,
                 "cg_iterations": it_o,
+                "cg_iterations_timed_path_same_probes": it,
                 "mll": float(mll_o),
+                "mll_timed_path_same_probes": float(mll),
                 "launches_timed": len(live_o),
             }
             if split_now:

@@ -414,7 +414,9 @@ int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int
   if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return fail(GPAMD_EINVAL, "kv: bad shape");
   plan_split(kind, n, m, d, t, flags, &S, &jc);
   const int64_t ldp = (n + 3) / 4 * 4;
-  if (workspace_floats < (int64_t)S * t * ldp) return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4))");
+  const SplitLayout L = split_layout(kind, flags, m, t, S, ldp);
+  if (workspace_floats < (L.total ? L.base + L.total : (int64_t)S * t * ldp))
+    return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4) and the same flags)");
   int rc = gpamd_kv_partials_f32(kind, X1p, n, X2p, m, d, Vt, ldv, t, workspace, ldp, S, jc, flags, nullptr, stream);
   if (rc) return rc;
   return gpamd_kv_reduce_f32(workspace, S, ldp, t, n, scale, dscale, nullptr, Vd, ldd, Out, ldo, nullptr, stream);

@@ -99,10 +99,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // written in that order and __builtin_amdgcn_sched_group_barrier pins the interleave "1 MFMA : VPM VALU".  To keep the pipeline
 // full across LDS tiles the split x_j rows (and the extra column) are staged ONE TILE AHEAD (double-buffered): the last step
 // of a tile generates the first block of the next one.
-// ABL (ablation builds of libgpamd_tune.so only; 0 in the product; 6 = register prefetch of the next tile): 1 no generation VALU, 2 no contraction MFMAs, 3 V planes staged
+// ABL (ablation builds of libgpamd_tune.so only; 0 in the product; 6 = register prefetch of the next tile, 7 = one wave per SIMD, 8 = no sched_barrier pinning): 1 no generation VALU, 2 no contraction MFMAs, 3 V planes staged
 // once (no global loads / LDS writes per tile; barriers stay), 4 as 3 and no barriers, 5 A operands read once per tile
 template <int KIND, int D, int CT, int NI, int EX, int ABL = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ABL == 7 ? 1 : 2, ABL == 7 ? 1 : 2)))
 void kv_gramh_kernel(KvhArgs ka) {
   const KvArgs& a = ka.a;
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
@@ -346,7 +346,7 @@ void kv_gramh_kernel(KvhArgs ka) {
         load_ev(bufn, jbn, 1, ev[1]);
         const f32x16 kkn = gram(wrap ? aqn : aqc, nin);
         u32x4 bhn[2], bln[2];
-        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 8) __builtin_amdgcn_sched_barrier(0);
         // contraction of this step, each MFMA followed by its share of the next step's generation; sched_barrier(0) pins the
         // source order (left alone the scheduler groups the MFMAs, and the wave stalls 32 cycles on each with the VALU idle).
         // Eight half-chunks (gen_a / gen_b of four pairs) over the 3 CT MFMAs of a half:
@@ -369,7 +369,7 @@ void kv_gramh_kernel(KvhArgs ka) {
               if ((u & 1) == 0) gen_a(kkn, mf, u >> 1, ev[mf], nin, kv[u >> 1], bhn[mf]);
               else gen_b(kv[u >> 1], u >> 1, bhn[mf][u >> 1], bln[mf]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (ABL != 8) __builtin_amdgcn_sched_barrier(0);
           }
         }
         if (ABL != 1) { bh[0] = bhn[0]; bh[1] = bhn[1]; bl[0] = bln[0]; bl[1] = bln[1]; }

@@ -32,7 +32,7 @@ colmul = torch.ones(80, device=dev)
 S, jc, _ = B.kv_plan("rbf", n, n, 3, 64, B.KV_GRAM | B.KV_SPLIT, ld)
 P = torch.empty(S * 64 * ld, device=dev)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-names = {0: "full", 1: "no generation VALU", 2: "no contraction MFMAs", 3: "V planes staged once", 4: "staged once, no barriers", 5: "A operands from one block", 6: "next tile prefetched into registers"}
+names = {0: "full", 1: "no generation VALU", 2: "no contraction MFMAs", 3: "V planes staged once", 4: "staged once, no barriers", 5: "A operands from one block", 6: "next tile prefetched into registers", 7: "one wave per SIMD", 8: "no sched_barrier pinning"}
 out = []
 for abl, ni in cases:
     def run():

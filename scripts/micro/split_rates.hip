@@ -106,6 +106,46 @@ void run(const char* name, float* out, double ops_per_it) {
   }
 }
 
+// one wave per SIMD, ONE instruction stream: MFMA followed by NV independent VALU instructions (v_fma_f32), repeated
+template <int NV>
+__global__ __launch_bounds__(256) void kmix(float* out, float seed) {
+  f32x16 c[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
+  f16x8 h8;
+  for (int e = 0; e < 8; ++e) h8[e] = (_Float16)(seed + e);
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = seed + i + threadIdx.x * 1e-3f;
+  for (int it = 0; it < REP; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      c[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8, h8, c[u & 3], 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[v & 7]) : "v"(seed));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float s = 0;
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += c[i][r];
+  for (int i = 0; i < 8; ++i) s += x[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int NV>
+void runmix(float* out) {
+  for (int threads = 256; threads <= 512; threads += 256) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kmix<NV>, dim3(256), dim3(256), 0, 0, out, 1.0001f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kmix<NV>, dim3(256 * (threads / 256)), dim3(256), 0, 0, out, 1.0001f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("one stream: MFMA + %d v_fma_f32, %d wave(s)/SIMD: %8.3f ms  %6.2f cycles per MFMA slot (@2.4 GHz)\n", NV, threads / 256, ms,
+           ms * 1e-3 * 2.4e9 / (REP * 8.0 * (threads / 256)));
+  }
+}
+
 int main() {
   float* out; hipMalloc(&out, 512 * 512 * 4);
   run<0>("v_exp_f32", out, 8);
@@ -114,5 +154,6 @@ int main() {
   run<3>("v_pk_fma_f32", out, 8);
   run<4>("v_fma_f32", out, 8);
   run<5>("mix exp+fma_mix+cvt_pkrtz", out, 24);
+  runmix<0>(out); runmix<2>(out); runmix<4>(out); runmix<6>(out); runmix<8>(out); runmix<12>(out);
   return 0;
 }
