@@ -72,3 +72,25 @@ def test_no_cpu_fallback():
     op = k(torch.rand(5, 2))  # lazily evaluated: constructing the operator is fine ...
     with pytest.raises(Exception):
         op.to_dense()            # ... evaluating it is not
+
+
+def test_split_contraction_setting_scopes_and_env(monkeypatch):
+    """settings.split_contraction: on by default, nests like the reference's feature flags, GPAMD_KV_SPLIT=0 turns the process
+    default off (read at import), and it only ever adds KV_SPLIT on top of the Gram-form flag."""
+    import subprocess
+    import sys
+
+    from gpytorch_amd import backend as B
+    from gpytorch_amd import settings
+
+    assert settings.split_contraction.on()
+    with settings.split_contraction(False):
+        assert settings.split_contraction.off()
+        with settings.split_contraction(True):
+            assert settings.split_contraction.on()
+        assert settings.split_contraction.off()
+    assert settings.split_contraction.on()
+    code = "import gpytorch_amd.settings as s; print(int(s.split_contraction.on()))"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**__import__("os").environ, "GPAMD_KV_SPLIT": "0"})
+    assert out.stdout.strip() == "0", out.stderr
+    assert B.KV_SPLIT == 8 and B.KV_GRAM == 1

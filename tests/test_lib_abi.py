@@ -53,6 +53,20 @@ def test_kv_plan_covers_and_fills():
             S, jc, ws = B.kv_plan(kind, n, m, 3, t, flags, B.round_up(n, 4))
             assert S >= 1 and jc % 128 == 0 and S * jc >= m and (S - 1) * jc < m
             assert ws == S * t * B.round_up(n, 4)
+        # split-operand contraction: the two f16 planes of V (one row per 32-column tile row, round_up(m, 128) positions) and the
+        # per-column scales live behind the slabs; nothing extra below five columns (the VALU-contraction kernel runs there)
+        S, jc, ws = B.kv_plan("rbf", n, m, 3, t, B.KV_GRAM | B.KV_SPLIT, B.round_up(n, 4))
+        slabs = S * t * B.round_up(n, 4)
+        assert S >= 1 and jc % 128 == 0 and S * jc >= m
+        if t < 5:
+            assert ws == slabs
+        else:
+            ldh = (m + 127) // 128 * 128
+            full, rem = divmod(t, 64)
+            rows = 64 * full + (0 if rem < 5 else 32 * ((rem - (1 if rem % 32 == 1 else 0) + 31) // 32))
+            if rem == 1 and full:          # 64 k + 1 columns: the last group carries the extra column, no further plane rows
+                rows = 64 * full
+            assert ws >= slabs + rows * ldh and ws <= slabs + rows * ldh + 2 * (2 * t + 64) + 8 and ws % 4 == 0, (n, m, t, ws, slabs, rows)
 
 
 def test_argument_validation_without_gpu():

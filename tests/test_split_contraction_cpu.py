@@ -1,0 +1,107 @@
+"""CPU emulation of the split-operand contraction (gpytorch_amd/csrc/kv_gramh.hpp, kv_vsplit.hpp): the same operand scheme --
+K generated as 2^12 K and split hi = f16 toward zero, lo = f16(K - hi); every column of V scaled by a power of two so that
+max |V_c| lands in [2^13, 2^14) and split with round-to-nearest; three exact f16 x f16 products accumulated in float32; the
+result multiplied by 2^-12 / scale_c -- against float64.  Pins the accuracy claim of DESIGN.md 3.1b without a GPU: the split
+contraction is as accurate as a plain float32 matrix product of the same operands (the 2e-5 bound of the GPU tests is dominated
+by the squared distances and the float32 accumulation, which both contraction paths share), for well- and badly-scaled columns,
+and documents what the 2^12 scale of K buys (it removes the one-sided truncation of small K entries at no cost)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+KSHIFT, VEXP = 12, 14
+
+
+def _rtz_f16(x: torch.Tensor) -> torch.Tensor:
+    """float32 -> float16 toward zero (v_cvt_pkrtz_f16_f32) for x >= 0."""
+    h = x.to(torch.float16)
+    over = h.to(torch.float32) > x
+    bits = h.view(torch.int16) - over.to(torch.int16)        # previous representable value
+    return bits.view(torch.float16)
+
+
+def _split_k(k: torch.Tensor, shift: int):
+    ks = k * (2.0 ** shift)
+    hi = _rtz_f16(ks)
+    lo = _rtz_f16(ks - hi.to(torch.float32))
+    return hi, lo
+
+
+def _split_v(v: torch.Tensor):
+    """v: [t, m] float32 -> (hi, lo, colmul); column = one row here (probe-major)."""
+    mx = v.abs().amax(dim=1)
+    scale = torch.ones_like(mx)
+    nz = mx > 0
+    ex = torch.frexp(mx[nz])[1]                               # mx = f 2^ex, f in [0.5, 1)
+    scale[nz] = torch.ldexp(torch.ones_like(mx[nz]), (VEXP - ex).clamp(-100, 100))
+    vs = v * scale[:, None]
+    hi = vs.to(torch.float16)
+    lo = (vs - hi.to(torch.float32)).to(torch.float16)
+    return hi, lo, (2.0 ** -KSHIFT) / scale
+
+
+def _split_product(k: torch.Tensor, v: torch.Tensor, shift: int = KSHIFT) -> torch.Tensor:
+    kh, kl = _split_k(k, shift)
+    vh, vl, colmul = _split_v(v)
+    colmul = colmul * (2.0 ** (KSHIFT - shift))
+    f = torch.float32
+    acc = vl.to(f) @ kh.to(f) + vh.to(f) @ kl.to(f) + vh.to(f) @ kh.to(f)   # [t, n]; products exact, float32 accumulation
+    return acc * colmul[:, None]
+
+
+def _rbf(n, m, d, ls, seed):
+    g = torch.Generator().manual_seed(seed)
+    x1, x2 = torch.rand(n, d, generator=g, dtype=torch.float64), torch.rand(m, d, generator=g, dtype=torch.float64)
+    sq = ((x2[:, None, :] - x1[None, :, :]) ** 2).sum(-1)
+    return torch.exp(-0.5 * sq / ls ** 2)                     # K[j][i], float64
+
+
+@pytest.mark.parametrize("ls", [0.1, 0.25, 1.0])
+def test_split_product_matches_float64(ls):
+    g = torch.Generator().manual_seed(7)
+    n, m, t = 64, 3000, 9
+    k64 = _rbf(n, m, 3, ls, 1)
+    k = k64.float()                                           # the kernel's K is a float32 value; its own error is not under test
+    v = torch.randn(t, m, generator=g)
+    v[0] *= 1e-25
+    v[1] *= 1e25
+    v[2] = 0.0
+    v[3] = 1.0 + 0.1 * torch.rand(m, generator=g)             # smooth, positive: no cancellation, a biased split would show here
+    v[4] = torch.sign(v[4])
+    v[5] = torch.exp(6.0 * v[5])                              # entries over ~20 orders of magnitude in one column
+    got = _split_product(k, v).double()
+    ref = v.double() @ k.double()
+    f32 = (v @ k).double()                                    # plain float32 product of the same operands
+    for c in range(t):
+        scale = ref[c].abs().max().clamp_min(1e-300)
+        err = float((got[c] - ref[c]).abs().max() / scale)
+        err32 = float((f32[c] - ref[c]).abs().max() / scale)
+        assert err < max(3.0 * err32, 1e-6), (ls, c, err, err32)
+    assert float(got[2].abs().max()) == 0.0
+
+
+def test_the_shift_of_k_is_what_keeps_small_entries_unbiased():
+    """Short lengthscale, positive V: almost all K entries are far below 1.  Without the 2^12 scale the f16 subnormal spacing
+    (6e-8) truncates the small ones toward zero -- a one-sided error (1.4e-6 of the result here); with the scale, which costs
+    nothing, the product is accurate to 1e-7."""
+    n, m = 16, 20000
+    k = _rbf(n, m, 3, 0.02, 3).float()
+    v = (1.0 + 0.1 * torch.rand(1, m, generator=torch.Generator().manual_seed(4)))
+    ref = (v.double() @ k.double())[0]
+    with_shift = _split_product(k, v, KSHIFT).double()[0]
+    without = _split_product(k, v, 0).double()[0]
+    err_with = float(((with_shift - ref).abs() / ref.abs().max()).max())
+    err_without = float(((without - ref).abs() / ref.abs().max()).max())
+    assert err_with < 2e-7
+    assert err_without > 5 * err_with
+
+
+def test_rtz_helper_is_toward_zero():
+    x = torch.tensor([1.0, 1.0009765625, 1.0004, 0.3333333, 4095.9, 6.0e-5, 1e-7, 0.0])
+    h = _rtz_f16(x).to(torch.float32)
+    assert bool((h <= x).all())
+    up = torch.nextafter(_rtz_f16(x), torch.tensor(float("inf"), dtype=torch.float16)).to(torch.float32)
+    assert bool((up > x)[x > 0].all())
+    assert h[0] == 1.0 and h[1] == 1.0009765625 and h[2] == 1.0
