@@ -217,6 +217,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void cg_update_xr_kernel(CgState<T> st, int k, int same_z) {
   __shared__ T sm[4];
   if (*st.done) return;
+  if (k < 0) k = st.done[1];   // replayed from a captured graph: the iteration index lives on the device (cg_stop advances it)
   const int c = blockIdx.y;
   T den = sum_partials(st.part_a + (int64_t)c * CG_MAXNB, st.nb, sm);
   const bool bad = den < st.eps;
@@ -252,6 +253,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void cg_update_d_kernel(CgState<T> st, int k) {
   __shared__ T sm[4];
   if (*st.done) return;
+  if (k < 0) k = st.done[1];
   const int c = blockIdx.y;
   T rho_new = sum_partials(st.part_rz + (int64_t)c * CG_MAXNB, st.nb, sm);
   T rho_old = st.rho[(k & 1) * st.t + c];
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(256) void cg_stats_kernel(CgState<T> st) {
 template <typename T>
 __global__ void cg_stop_kernel(CgState<T> st, int k, int min_iter, int tridiag_floor, T tol) {
   if (threadIdx.x != 0 || *st.done) return;
+  if (k < 0) k = st.done[1];
   T mean = st.stats[0] / st.stats[1];
   if (!(mean == mean)) {
     st.done[0] = 2;

@@ -259,7 +259,10 @@ def linear_cg(
         poll_every = 1 if float(n_poll) * n_poll * t_poll > 2e11 else 8
         flag = 0
         iters = 0
-        for k in range(max_iter):
+
+        def iteration(k, st):
+            """One mBCG iteration on stream ``st``; k = -1: the kernels take the iteration index from the device (graph replay)."""
+            nonlocal P, S, ldp
             ev = None
             if KV_EVENT_LOG is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -297,6 +300,28 @@ def linear_cg(
             if group is not None:
                 allreduce_sum_(stats, group)
             check(F["stop"](h, k, min_iter, tri_floor, float(tolerance), st), "cg_stop")
+
+        # settings.cg_graph (off by default: measured, no gain -- the loop is bound by the execution of its small dependent kernels,
+        # not by their launches): iteration 0 runs eagerly, then ONE iteration is recorded into a hipGraph (torch's stream capture
+        # sees the ctypes launches like any other work on the capturing stream) and replayed; the kernels read the iteration index
+        # from the device, converged solves keep turning into no-ops through the done flag as before.
+        graph = None
+        use_graph = (settings.cg_graph.on() and kv_partials is None and x.fused and group is None and row_shard is None
+                     and KV_EVENT_LOG is None and max_iter > 2 and float(n) * n * t <= settings.cg_graph.max_work)
+        for k in range(max_iter):
+            if graph is not None:
+                graph.replay()
+            else:
+                iteration(k, st)
+                if use_graph and k == 0:
+                    try:
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            iteration(-1, B._stream(dev))
+                    except Exception as exc:   # capture refused (an op in a user-supplied preconditioner, an old runtime): stay eager
+                        warnings.warn(f"mBCG: graph capture failed ({exc}); continuing with eager launches", RuntimeWarning)
+                        graph, use_graph = None, False
+                        torch.cuda.synchronize(dev)
             iters = k + 1
             if k >= first_poll and ((k - first_poll) % poll_every == 0 or k == max_iter - 1):
                 flag, iters_dev = (int(v) for v in done_t.tolist())

@@ -244,6 +244,17 @@ class deterministic_probes(_feature_flag):
     probe_vectors = None
 
 
+class cg_graph(_feature_flag):
+    """(no counterpart in the reference.)  Small mBCG solves -- ``n^2 t <= cg_graph.max_work`` -- can record ONE iteration (fused
+    K V, reduction, the vector updates, the preconditioner apply, the stopping rule) into a hipGraph after the first iteration
+    and replay it.  Same kernels in the same order: the results are bitwise those of the eager loop
+    (``test_cg_graph_replay_is_bitwise_the_eager_loop``).  OFF by default: measured on MI355X the eager loop is not launch-bound
+    -- the host enqueues faster than the 7-15 dependent small kernels of an iteration execute (60 us per iteration at n = 2000,
+    eleven columns) and the replayed graph runs them no faster (0.94-0.98x, ``profiles/r02_s28_cg_graph.json``)."""
+    _default = False
+    max_work = 1.0e10
+
+
 class split_contraction(_feature_flag):
     """(no counterpart in the reference.)  With five or more right-hand sides the fused ``K @ V`` contraction runs on the f16
     matrix pipe at float32 accuracy: both operands are split exactly into f16 hi + lo parts (21-22 significant bits, per-column

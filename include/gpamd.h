@@ -141,7 +141,8 @@ int gpamd_cg_update_d_apply_f32(gpamd_cg_t* h, int k, void* stream);
 /* Q = scale * sum_s P[s] + (dscale + dvec) .* D, and d.q partials */
 int gpamd_cg_reduce_q_f32(gpamd_cg_t* h, const float* P, int S, int64_t ldp, const float* scale, const float* dscale,
                           const float* dvec, void* stream);
-/* alpha; X += alpha D; R -= alpha Q */
+/* alpha; X += alpha D; R -= alpha Q.   k (here, in update_d and in stop): the iteration index, or -1 = take it from the device
+ * (the count cg_stop maintains) -- the form to record into a hipGraph that is then replayed once per iteration. */
 int gpamd_cg_update_xr_f32(gpamd_cg_t* h, int k, void* stream);
 /* (caller applies Z = P^-1 R here when preconditioned)  beta; D = Z + beta D; residual statistics -> stats */
 int gpamd_cg_update_d_f32(gpamd_cg_t* h, int k, void* stream);

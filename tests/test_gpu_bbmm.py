@@ -264,3 +264,33 @@ def test_full_size_solve_residual_symmetry_and_rows(dev):
     cols = B.kv(p5, p5, E)[:, :n5]
     rows = B.kernel_rows(p5, idx, p5)
     assert float((cols - rows).abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize("precond_rank", [0, 10])
+def test_cg_graph_replay_is_bitwise_the_eager_loop(precond_rank, dev):
+    """Launch-bound solves record one mBCG iteration into a hipGraph and replay it (settings.cg_graph): same kernels, same order,
+    the iteration index read from the device -- solution, iteration count and the recorded alpha / beta tridiagonals are
+    bitwise those of the eager loop, with and without the pivoted-Cholesky preconditioner."""
+    from gpytorch_amd import backend as B
+    from gpytorch_amd import settings
+    from gpytorch_amd.bbmm import build_preconditioner
+    from gpytorch_amd.linear_cg import linear_cg
+
+    g = torch.Generator().manual_seed(21)
+    n, t = 3000, 11
+    X = torch.rand(n, 2, generator=g)
+    rhs = torch.randn(t, n, generator=g)
+    xp = B.prep_points("rbf", X.to(dev), torch.tensor(0.2), X.mean(0).to(dev))
+    rt = torch.zeros(t, B.round_up(n, 4), device=dev)
+    rt[:, :n] = rhs.to(dev)
+    scale, noise = torch.tensor([1.0], device=dev), torch.tensor([0.01], device=dev)
+    pc = build_preconditioner(xp, scale, noise, rank=precond_rank, min_size=0) if precond_rank else None
+    out = {}
+    for graph in (False, True):
+        with settings.cg_graph(graph):
+            xt, info = linear_cg(xp, scale, noise, rt, n_tridiag=t - 1, tolerance=1e-3, max_iter=400, preconditioner=pc)
+        out[graph] = (xt.clone(), info)
+    (xa, ia), (xb, ib) = out[False], out[True]
+    assert ia.iterations == ib.iterations and ia.tolerance_reached and ib.tolerance_reached and ia.iterations > 12
+    assert torch.equal(xa, xb)
+    assert torch.equal(ia.t_mats, ib.t_mats)
