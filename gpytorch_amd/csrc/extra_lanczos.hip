@@ -70,7 +70,7 @@ int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* o
 // ---- preconditioner coefficients W = R Q1^T in mixed precision (lanczos_kernels.hpp: pc_coef_kernel) ----
 int64_t gpamd_precond_coef_workspace_doubles(int n, int t, int k) {
   if (n <= 0 || t <= 0 || k <= 0) return 0;
-  long nb = ((long)n + 2047) / 2048;
+  long nb = ((long)n + 255) / 256;   // >= 256 elements per workgroup: small n still spreads over several CUs
   if (nb > 256) nb = 256;
   return (int64_t)nb * t * k;
 }
@@ -79,7 +79,7 @@ int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* 
                               double* workspace, int64_t workspace_doubles, void* stream) {
   if (!R || !Q || !W || !workspace || n <= 0 || t <= 0 || k <= 0 || ldr < n || ldq < n) return lz_fail("precond_coef: bad arguments");
   if (k > 16 * PC_MT) return lz_fail("precond_coef: rank > 128");
-  long nb = ((long)n + 2047) / 2048;
+  long nb = ((long)n + 255) / 256;   // >= 256 elements per workgroup: small n still spreads over several CUs
   if (nb > 256) nb = 256;
   if (workspace_doubles < (int64_t)nb * t * k) return GPAMD_EWORKSPACE;
   const int slice = (int)(((long)n + nb - 1) / nb + PC_CHUNK - 1) / PC_CHUNK * PC_CHUNK;
@@ -95,6 +95,16 @@ int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* 
     hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((tg * k + 255) / 256), dim3(256), 0, st, (const double*)part, (int)nb, tg * k, W + (int64_t)c0 * k);
   }
   return lz_check("precond_coef");
+}
+
+int gpamd_precond_apply_f32f64(const float* R, int64_t ldr, int t, const double* Q, int64_t ldq, int k, int n, const double* W,
+                               const float* sigma2, float* Out, int64_t ldo, void* stream) {
+  if (!R || !Q || !W || !sigma2 || !Out || n <= 0 || t <= 0 || k <= 0 || ldr < n || ldq < n || ldo < n)
+    return lz_fail("precond_apply: bad arguments");
+  if (k > 16 * PC_MT) return lz_fail("precond_apply: rank > 128");
+  hipLaunchKernelGGL(pc_apply_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)((t + PA_CT - 1) / PA_CT)), dim3(256), 0, (hipStream_t)stream,
+                     R, ldr, t, Q, ldq, k, n, W, sigma2, Out, ldo);
+  return lz_check("precond_apply");
 }
 
 }  // extern "C"

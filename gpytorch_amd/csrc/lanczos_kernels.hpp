@@ -176,4 +176,34 @@ __global__ void pc_coef_sum_kernel(const double* __restrict__ part, int nb, int 
   W[e] = s;
 }
 
+// Second half of the preconditioner apply, fused:  Out[c][i] = (R[c][i] - sum_m W[c][m] Q1[m][i]) / sigma2  with the subtraction and
+// the division in float64 (the cancellation that float32 cannot carry), R / Out float32, Q1 / W float64.  One workgroup = 256
+// consecutive i for PA_CT columns: W of the column group sits in LDS (broadcast reads), every Q1 element is read once per column
+// group and stays in a register across its PA_CT multiply-adds.  Replaces float64 copy of R + addmm + div + copy-back (four torch
+// kernels and three [t][n] float64 temporaries).
+constexpr int PA_CT = 16;
+__global__ __launch_bounds__(256) void pc_apply_kernel(const float* __restrict__ R, int64_t ldr, int t, const double* __restrict__ Q,
+                                                       int64_t ldq, int k, int n, const double* __restrict__ W,
+                                                       const float* __restrict__ sigma2, float* __restrict__ Out, int64_t ldo) {
+  __shared__ double Ws[PA_CT * 16 * PC_MT];   // [c][m], k <= 128
+  const int c0 = blockIdx.y * PA_CT;
+  const int nc = min(PA_CT, t - c0);
+  for (int e = threadIdx.x; e < nc * k; e += 256) Ws[(e / k) * (16 * PC_MT) + (e % k)] = W[(int64_t)(c0 + e / k) * k + (e % k)];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double acc[PA_CT];
+#pragma unroll
+  for (int c = 0; c < PA_CT; ++c) acc[c] = 0.0;
+  for (int m = 0; m < k; ++m) {
+    const double q = Q[(int64_t)m * ldq + i];
+#pragma unroll
+    for (int c = 0; c < PA_CT; ++c) acc[c] = fma(Ws[c * (16 * PC_MT) + m], q, acc[c]);
+  }
+  const double inv = 1.0 / (double)sigma2[0];
+#pragma unroll
+  for (int c = 0; c < PA_CT; ++c)
+    if (c < nc) Out[(int64_t)(c0 + c) * ldo + i] = (float)(((double)R[(int64_t)(c0 + c) * ldr + i] - acc[c]) * inv);
+}
+
 }  // namespace gpamd

@@ -97,23 +97,39 @@ class Preconditioner:
         solve.  I - Q1 Q1^T has eigenvalues s2 / (s2 + lambda): for a smooth kernel (RBF, d = 3, n = 5e5: lambda / s2 ~ 1e6) the
         leading components of R must cancel to 6 digits, which float32 cannot deliver -- the float32 apply made preconditioned CG
         stall at a relative residual of 4 after 2000 iterations (profiles/r02_s5_posterior_profile_precond_fp32_stalls.json).
-        Cost: two [t, n] x [n, k] float64 GEMMs per CG iteration, < 1 ms against a >= 19 ms K*V at that size."""
+        Cost: two kernels per CG iteration (the k x t coefficients, then the fused subtraction / division), < 1 ms against a
+        >= 19 ms K*V at n = 5e5 and ~25 us at n = 2000 (the four torch float64 operations they replaced took 280 us there)."""
         q1t = self.q1t if self.q1t.dtype == torch.float64 else self.q1t.to(torch.float64)
-        r64 = rt.to(torch.float64)
         k = q1t.shape[0]
-        if rt.dtype == torch.float32 and rt.is_cuda and k <= 128 and rt.stride(1) == 1 and q1t.stride(1) == 1:
+        fast = rt.dtype == torch.float32 and rt.is_cuda and k <= 128 and rt.stride(1) == 1 and q1t.stride(1) == 1
+        if fast:
             # W = R Q1^T: own mixed-precision reduction kernel (rocBLAS' float64 GEMM takes 80 ms for some tall-skinny shapes)
             t, n = rt.shape[0], min(rt.shape[1], q1t.shape[1])
             L = lib()
-            nws = int(L.gpamd_precond_coef_workspace_doubles(n, t, k))
-            ws = torch.empty(nws, device=rt.device, dtype=torch.float64)
-            w = torch.empty(t, k, device=rt.device, dtype=torch.float64)
-            check(L.gpamd_precond_coef_f32f64(B._ptr(rt), rt.stride(0), t, B._ptr(q1t), q1t.stride(0), k, n, B._ptr(w), B._ptr(ws), nws,
+            key = (t, n, k, rt.device)
+            if getattr(self, "_apply_ws_key", None) != key:
+                nws = int(L.gpamd_precond_coef_workspace_doubles(n, t, k))
+                self._apply_ws = (torch.empty(nws, device=rt.device, dtype=torch.float64), torch.empty(t, k, device=rt.device, dtype=torch.float64))
+                self._apply_ws_key = key
+            ws, w = self._apply_ws
+            check(L.gpamd_precond_coef_f32f64(B._ptr(rt), rt.stride(0), t, B._ptr(q1t), q1t.stride(0), k, n, B._ptr(w), B._ptr(ws), ws.numel(),
                                               B._stream(rt.device)), "precond_coef")
+            if self.reduce is not None:
+                self.reduce(w)
+            s2 = self.sigma2 if self.sigma2.dtype == torch.float32 else self.sigma2.to(torch.float32)
+            if out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[1] >= n and out.data_ptr() != rt.data_ptr() and s2.numel() == 1:
+                # second half fused: (R - W Q1) / s2 in float64 arithmetic, one kernel, no float64 temporaries
+                check(L.gpamd_precond_apply_f32f64(B._ptr(rt), rt.stride(0), t, B._ptr(q1t), q1t.stride(0), k, n, B._ptr(w), B._ptr(s2),
+                                                   B._ptr(out), out.stride(0), B._stream(rt.device)), "precond_apply")
+                if out.shape[1] > n:
+                    out[:, n:].zero_()
+                return out
+            r64 = rt.to(torch.float64)
         else:
+            r64 = rt.to(torch.float64)
             w = r64 @ q1t.t()
-        if self.reduce is not None:
-            self.reduce(w)
+            if self.reduce is not None:
+                self.reduce(w)
         z = torch.addmm(r64, w, q1t, alpha=-1.0)
         z.div_(self.sigma2.to(torch.float64))
         out.copy_(z)

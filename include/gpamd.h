@@ -185,6 +185,10 @@ int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* o
 int64_t gpamd_precond_coef_workspace_doubles(int n, int t, int k);
 int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* Q, int64_t ldq, int k, int n, double* W,
                               double* workspace, int64_t workspace_doubles, void* stream);
+/* second half, fused:  Out[c][i] = (R[c][i] - sum_m W[c][m] Q1[m][i]) / sigma2[0]  (float64 arithmetic, float32 in / out; Out may
+ * alias nothing but itself -- R and Out are different buffers in the mBCG state).  sigma2: one float on the device. */
+int gpamd_precond_apply_f32f64(const float* R, int64_t ldr, int t, const double* Q, int64_t ldq, int k, int n, const double* W,
+                               const float* sigma2, float* Out, int64_t ldo, void* stream);
 
 /* ---- fused bilinear derivative: out[0] = sum_ij W_ij k_ij, out[1+q] = sum_ij W_ij dk/ds_ij (z_iq - z_jq)^2,
  * W = Lt^T Rt (never formed).  Replaces LinearOperator._bilinear_derivative on the kernel operator and the

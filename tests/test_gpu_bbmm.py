@@ -164,6 +164,13 @@ def test_preconditioner_matches_dense_inverse(dev):
     assert abs(float(pre.logdet) - float(torch.linalg.slogdet(P)[1])) < 1e-3 * abs(float(torch.linalg.slogdet(P)[1]))
     assert build_preconditioner(xp, sc, s2, rank=0) is None
     assert build_preconditioner(xp, sc, s2, rank=15, min_size=5000) is None
+    # the fused second half (gpamd_precond_apply_f32f64) against the same formula in torch float64, several column groups
+    R = torch.randn(37, vt.shape[1], generator=torch.Generator().manual_seed(3)).to(dev)
+    R[:, n:] = 0
+    got = pre.apply_(R, torch.empty_like(R)).double()
+    q = pre.q1t.double()
+    want = (R.double() - (R.double() @ q.t()) @ q) / 0.1
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-6
 
 
 def _probes(n, t, L, s2, seed=1234):
