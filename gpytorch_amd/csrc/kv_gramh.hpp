@@ -69,34 +69,13 @@ __device__ __forceinline__ float cov_scaled(float s, float p) {
   }
 }
 
-// (k0, k1) >= 0 -> packed f16 hi (toward zero) and lo = k - hi
-__device__ __forceinline__ void split_pair_rtz(float k0, float k1, float negone, uint32_t& hi, uint32_t& lo) {
-  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-  const auto hp = __builtin_amdgcn_cvt_pkrtz(k0, k1);
-  hi = __builtin_bit_cast(uint32_t, hp);
-  const f16x2 hv = __builtin_bit_cast(f16x2, hp);
-#ifdef GPAMD_KGH_ASM_MIX
-  float l0, l1;
-  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(k0));
-  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(k1));
-#else
-  // fmaf((float)h, -1, k) with an OPAQUE -1 (an SGPR the optimiser cannot see through, else it rewrites the fma as k - h and
-  // the conversion becomes its own instruction): with f32 denormals flushed (kvh_*.hip are built with
-  // -fgpu-flush-denormals-to-zero) the f16 -> f32 extension folds into ONE v_fma_mix_f32 per element.  Plain C++ rather than
-  // inline asm: asm statements are invisible to the sched_group_barrier masks below.
-  const float l0 = __builtin_fmaf((float)hv[0], negone, k0);
-  const float l1 = __builtin_fmaf((float)hv[1], negone, k1);
-#endif
-  lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(l0, l1));
-}
-
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Software pipeline.  One "step" = one 32x32 block of pairs of one row tile: generation (KH Gram MFMAs, then per element
 // v_exp_f32 + the hi/lo split: ~4 VALU instructions) and contraction (6 CT MFMAs of 8 passes).  A wave issues in order, and a
 // second MFMA cannot issue while the first occupies the pipe, so MFMAs written back to back stall the wave for 32 cycles each
 // with the VALU idle.  The loop therefore generates the B operands of step s+1 WHILE the MFMAs of step s run: the source is
-// written in that order and __builtin_amdgcn_sched_group_barrier pins the interleave "1 MFMA : VPM VALU".  To keep the pipeline
+// written in that order -- one MFMA, then its share of the next step's VALU work -- and sched_barrier(0) pins it.  To keep the pipeline
 // full across LDS tiles the split x_j rows (and the extra column) are staged ONE TILE AHEAD (double-buffered): the last step
 // of a tile generates the first block of the next one.
 // ABL (ablation builds of libgpamd_tune.so only; 0 in the product; 6 = register prefetch of the next tile, 7 = one wave per SIMD, 8 = no sched_barrier pinning): 1 no generation VALU, 2 no contraction MFMAs, 3 V planes staged
@@ -119,7 +98,7 @@ void kv_gramh_kernel(KvhArgs ka) {
   __shared__ __attribute__((aligned(16))) float Es[EX ? 2 * BN : 4];   // [buf][j] extra column
 
   if (a.done && *a.done) return;
-  float negone;   // -1.0f the optimiser cannot see through (split_pair_rtz)
+  float negone;   // -1.0f the optimiser cannot see through (gen_b)
   asm("s_mov_b32 %0, 0xbf800000" : "=s"(negone));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -234,7 +213,9 @@ void kv_gramh_kernel(KvhArgs ka) {
     const f16x2 hv = __builtin_bit_cast(f16x2, hiw);
     // fmaf((float)h, -1, k) with an OPAQUE -1 (an SGPR the optimiser cannot see through, else it rewrites the fma as k - h and
     // the conversion becomes its own instruction): with f32 denormals flushed (kvh_*.hip are built with
-    // -fgpu-flush-denormals-to-zero) the f16 -> f32 extension folds into ONE v_fma_mix_f32 per element.
+    // -fgpu-flush-denormals-to-zero) the f16 -> f32 extension folds into ONE v_fma_mix_f32 per element.  (hiw comes BY VALUE:
+    // __builtin_bit_cast on element p of a `const u32x4&` parameter was compiled as element 0 for every p.  Writing the packed lo
+    // word with v_fma_mixlo_f16 / v_fma_mixhi_f16 instead -- one instruction fewer per pair -- measured slower, 90 vs 83 ms.)
     const float l0 = __builtin_fmaf((float)hv[0], negone, kv[0]);
     const float l1 = __builtin_fmaf((float)hv[1], negone, kv[1]);
     bl[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(l0, l1));
