@@ -108,6 +108,7 @@ def test_c3_end_to_end_preconditioned_mll(dev):
     ones, the preconditioner does not change the solution of the y column and reduces the iteration counts."""
     import json
     import os
+    import time
 
     from gpytorch_amd import backend as B
     from gpytorch_amd.bbmm import LOG_2PI, build_preconditioner, inv_quad_logdet_forward
@@ -118,13 +119,21 @@ def test_c3_end_to_end_preconditioned_mll(dev):
     xp = B.prep_points(kind, Xd, torch.tensor([ls]), Xd.mean(0))
     sc, s2 = torch.tensor([1.0], device=dev), torch.tensor([0.1], device=dev)
     rhs_t = B.to_probe_major(yd.unsqueeze(-1))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
     pre = build_preconditioner(xp, sc, s2, rank=100, min_size=0)
+    torch.cuda.synchronize(dev)
+    pre_seconds = time.perf_counter() - t0
     assert pre is not None and pre.q1t.shape[0] == 100
-    log = {}
+    log = {"preconditioner_build_seconds": pre_seconds}
     sols = {}
     for tag, p in (("precond100", pre), ("noprecond", None)):
         gen = torch.Generator(device=dev).manual_seed(11)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
         res = inv_quad_logdet_forward(xp, sc, s2, rhs_t, num_probes=16, precond=p, generator=gen, tolerance=1.0, max_iter=600)
+        torch.cuda.synchronize(dev)
+        seconds = time.perf_counter() - t0
         assert res.info.tolerance_reached, (tag, res.info.iterations, float(res.info.residual_norms.mean()))
         full = torch.cat([res.zt, rhs_t], 0)
         rel = _true_residual(xp, sc, s2, res.solves_t, full)
@@ -136,7 +145,7 @@ def test_c3_end_to_end_preconditioned_mll(dev):
         assert math.isfinite(mll)
         sols[tag] = res
         log[tag] = dict(iterations=res.info.iterations, mean_true_rel_residual=float(rel.mean()), mll=mll,
-                        inv_quad=float(res.inv_quad.sum()), logdet=float(res.logdet))
+                        inv_quad=float(res.inv_quad.sum()), logdet=float(res.logdet), mll_evaluation_seconds=seconds)
     # tighter solve of the y column alone (eval tolerance): with and without the preconditioner -> same solution
     from gpytorch_amd.linear_cg import linear_cg
 
