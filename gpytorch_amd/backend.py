@@ -104,6 +104,9 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
     if SPLIT_CONTRACTION is None:
         from . import settings
 
+        # no size rule: the three extra launches of the pre-pass do not make small products slower -- measured, mBCG per iteration
+        # with the fp32-MFMA contraction instead: 107 vs 57 us at n = 2000, 231 vs 105 us at n = 5000, 229 vs 144 us at n = 20 000
+        # (eleven columns; profiles/r02_s33_cg_small_n_fp32_contraction.json vs r02_s30_*)
         split = settings.split_contraction.on()
     else:
         split = SPLIT_CONTRACTION
