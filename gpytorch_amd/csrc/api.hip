@@ -84,14 +84,16 @@ bool gram_ok(int kind, int flags);
 //   9..16  kv_gram16 (16-column 16x16x1_4B tile)  17..24 kv_gram4, six groups     25..  kv_gram (32-column tiles)
 // flags (tuning / A-B only): GPAMD_KV_WIDE restores the older selection (VALU contraction up to 16 columns, the 32-column
 // tile above), GPAMD_KV_G4 sends 9..12 columns to kv_gram4 with three groups
-KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false) {  // t <= 129 handled per launch group; light: RBF, d <= 3
+// small: few output rows (n < KGH_SMALL_N) -- the split kernels then take ONE 32-row tile per wave (128 rows per workgroup) so that
+// the launch still spreads over the chip
+KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool small = false) {  // t <= 129 handled per launch group; light: RBF, d <= 3
   KvVariant v{};
   const bool wide = flags & GPAMD_KV_WIDE;
   if (gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KGH_GROUP + 1) {
     v.split = true;
     v.ex = (t % 32 == 1) ? 1 : 0;
     v.ct = (t - v.ex + 31) / 32;
-    v.ni = kgh_ni(v.ct);
+    v.ni = small ? 1 : kgh_ni(v.ct);
     v.bm = kgh_bm(v.ni);
     v.bn = KGH_BN;
   } else if (gram && !wide && t >= 5 && t <= 24) {
@@ -154,7 +156,7 @@ SplitLayout split_layout(int kind, int flags, int m, int t, int S, int64_t ldo) 
   int rows = 0;
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0, cap);
-    KvVariant v = pick_variant(tg, true, flags, false);
+    KvVariant v = pick_variant(tg, true, flags, false, false);   // (row tiling does not change the plane rows)
     if (v.split) rows += 32 * v.ct;
     g0 += tg;
   }
@@ -249,7 +251,7 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // full (efficiency = units / (rounds * slots)), keeping every chunk >= 16 LDS tiles (per-unit prologue
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
   const int cap = group_cap(kind, flags);
-  KvVariant v = pick_variant(t > cap + 1 ? cap : t, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3);
+  KvVariant v = pick_variant(t > cap + 1 ? cap : t, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3, n < KGH_SMALL_N);
   const int mode = kv_mode(kind, flags, d, v);
   variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
@@ -351,7 +353,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
   int mulslot = 0;    // multiplier slots used so far
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0, cap);
-    KvVariant v = pick_variant(tg, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3);
+    KvVariant v = pick_variant(tg, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3, n < KGH_SMALL_N);
     const int mode = kv_mode(kind, flags, d, v);
     variant_geometry(mode, &v);
     KvhArgs ka;

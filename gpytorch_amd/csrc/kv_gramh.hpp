@@ -40,6 +40,7 @@ constexpr int KGH_LDH = KGH_BN + 8;     // f16 row stride of the V planes in LDS
 constexpr int KGH_KSHIFT = 12;          // K generated as 2^12 K
 constexpr int KGH_VEXP = 14;            // max |V_c| * scale_c in [2^13, 2^14)
 constexpr int KGH_GROUP = 64;           // columns per launch group (+ 1 extra VALU column)
+constexpr int KGH_SMALL_N = 16384;      // fewer output rows: one row tile per wave (NI = 1), four times as many workgroups
 constexpr int KGH_MIN_COLS = 5;         // fewer columns: the VALU-contraction kernel (kv_gramv.hpp) wins
 constexpr int kgh_ni(int ct) { return ct == 1 ? 4 : 2; }   // 32-row tiles per wave: 16 NI CT accumulators
 inline int kgh_bm(int ni) { return 4 * ni * 32; }
