@@ -140,3 +140,24 @@ def test_split_cg_solve_and_done_flag(split, dev):
     ref = torch.linalg.solve(Kh, rhs.float().double().T).T
     sol = xt[:, :n].double().cpu()
     assert float((sol - ref).norm() / ref.norm()) < 2e-3
+
+
+@pytest.mark.parametrize("kind,d,t", [("matern32", 6, 33), ("rq", 2, 64), ("matern52", 12, 65), ("rbf", 5, 32)])
+def test_split_product_large_row_tiles(split, kind, d, t, dev):
+    """n >= 16 384 output rows: the two- / four-row-tile kernels (the small shapes above run one row tile per wave), checked on a
+    row sample for the families and dimensions the at-size configurations do not cover."""
+    B = split
+    g = torch.Generator().manual_seed(d * 100 + t)
+    n = 20_000
+    X = torch.rand(n, d, generator=g, dtype=torch.float64)
+    V = torch.randn(t, n, generator=g, dtype=torch.float64)
+    ls = 0.25 + 0.12 * d
+    p = _prep(B, kind, X, ls, dev, X.mean(0))
+    vt = torch.zeros(t, B.round_up(n, 4), device=dev)
+    vt[:, :n] = V.float().to(dev)
+    assert B.kv_flags(p, p, t) == (B.KV_GRAM | B.KV_SPLIT)
+    rows = torch.cat([torch.arange(0, 200), torch.randint(200, n - 200, (400,), generator=g), torch.arange(n - 200, n)])
+    out = B.kv(p, p, vt)[:, rows.to(dev)].double().cpu()
+    ref = (_oracle_K(kind, X.float().double()[rows], X.float().double(), ls, 1.7) @ V.float().double().T).T
+    err = ((out - ref).abs().amax(1) / ref.abs().amax(1)).max()
+    assert float(err) < 2e-5, (kind, float(err))
