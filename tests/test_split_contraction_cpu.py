@@ -105,3 +105,46 @@ def test_rtz_helper_is_toward_zero():
     up = torch.nextafter(_rtz_f16(x), torch.tensor(float("inf"), dtype=torch.float16)).to(torch.float32)
     assert bool((up > x)[x > 0].all())
     assert h[0] == 1.0 and h[1] == 1.0009765625 and h[2] == 1.0
+
+
+def test_operand_layout_of_the_split_kernel():
+    """The index algebra of kv_gramh.hpp / kv_vsplit.hpp, emulated lane by lane: the 32x32x16 MFMA computes
+    D[m][n] = sum_k A[m][k] B[k][n] with lane l = (h = l >> 5, x = l & 31) supplying A[m = x][k = 8h .. 8h+7] and
+    B[k = 8h .. 8h+7][n = x], and leaves lane (h, x) with D[(r & 3) + 8 (r >> 2) + 4h][x] in register r.
+      * Gram MFMA (A = x_j rows, B = x_i rows): lane (h, i) register r holds K[j(r, h)][i], j(r, h) = (r & 3) + 8 (r >> 2) + 4h;
+      * contraction MFMA mf = 0, 1: B slot (h, e) := the lane's own register r = 8 mf + e;  A slot (h, e) := plane position
+        16 (2 b + mf) + 8h + e of the V planes, which vsplit_kernel fills with j = 16 g + (e & 3) + 8 (e >> 2) + 4h (g = 2 b + mf).
+    The two MFMAs of a 32-row block b must then add up to sum_j V[c][j] K[j][i] over the block's 32 rows."""
+    rng = np.random.default_rng(0)
+    nblk, C, I = 3, 32, 32
+    m = 32 * nblk
+    K = rng.standard_normal((m, I))            # K[j][i]
+    V = rng.standard_normal((C, m))            # V[c][j]
+    # vsplit_kernel: plane[c][16 g + 8 h + e] = V[c][16 g + (e & 3) + 8 (e >> 2) + 4 h]
+    plane = np.zeros_like(V)
+    for g in range(m // 16):
+        for h in range(2):
+            for e in range(8):
+                plane[:, 16 * g + 8 * h + e] = V[:, 16 * g + (e & 3) + 8 * (e >> 2) + 4 * h]
+    assert sorted(set((e & 3) + 8 * (e >> 2) + 4 * h for h in range(2) for e in range(8))) == list(range(16))
+    out = np.zeros((C, I))
+    for b in range(nblk):
+        # registers of the Gram result: reg[h][i][r] = K[32 b + j(r, h)][i]
+        reg = np.zeros((2, I, 16))
+        for h in range(2):
+            for r in range(16):
+                reg[h, :, r] = K[32 * b + (r & 3) + 8 * (r >> 2) + 4 * h, :]
+        for mf in range(2):
+            A = np.zeros((C, 16))              # A[m = c][k]
+            Bm = np.zeros((16, I))             # B[k][n = i]
+            for h in range(2):
+                for e in range(8):
+                    A[:, 8 * h + e] = plane[:, 16 * (2 * b + mf) + 8 * h + e]
+                    Bm[8 * h + e, :] = reg[h, :, 8 * mf + e]
+            out += A @ Bm
+    np.testing.assert_allclose(out, V @ K, rtol=0, atol=1e-12)
+    # the extra (f32) column of half mf reads rows 16 mf + 4 h .. + 3 and 16 mf + 8 + 4 h .. + 3: exactly j(8 mf + 0..3, h), j(8 mf + 4..7, h)
+    for mf in range(2):
+        for h in range(2):
+            rows = [16 * mf + 4 * h + q for q in range(4)] + [16 * mf + 8 + 4 * h + q for q in range(4)]
+            assert rows == [((8 * mf + e) & 3) + 8 * ((8 * mf + e) >> 2) + 4 * h for e in range(8)]
