@@ -5,7 +5,6 @@ result multiplied by 2^-12 / scale_c -- against float64.  Pins the accuracy clai
 contraction is as accurate as a plain float32 matrix product of the same operands (the 2e-5 bound of the GPU tests is dominated
 by the squared distances and the float32 accumulation, which both contraction paths share), for well- and badly-scaled columns,
 and documents what the 2^12 scale of K buys (it removes the one-sided truncation of small K entries at no cost)."""
-import math
 
 import numpy as np
 import pytest
