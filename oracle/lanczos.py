@@ -6,7 +6,8 @@ Restates the published algorithm of ``linear_operator.utils.lanczos.lanczos_trid
 Reference call sites: ``gpytorch/models/exact_prediction_strategies.py:202,234-238,271``
 (``root_inv_decomposition`` for the LOVE ``covar_cache``).
 Iteration-level parity with the reference is UNPINNED; pinned via Q^T Q = I,
-Q T Q^T ~= A on the Krylov space and predictive variances vs dense Cholesky.
+Q T Q^T ~= A on the Krylov space and predictive variances vs dense Cholesky, and against an independent Lanczos
+(same T, same Krylov basis up to signs; exact quadrature b^T log(A) b for k = n: tests/test_oracle_independent_cpu.py).
 """
 from __future__ import annotations
 

@@ -6,8 +6,10 @@ Reference call sites: ``gpytorch/distributions/multivariate_normal.py:249`` (thr
 ``inv_quad_logdet``) and ``gpytorch/models/exact_prediction_strategies.py:286,444`` (through
 ``solve``); asserted-called at ``test/lazy/test_lazy_evaluated_kernel_tensor.py:82-111``.
 
-Iteration-level parity with the reference is UNPINNED (no golden vectors exist); results are
-pinned against dense Cholesky in tests/test_oracle_bbmm.py.
+Iteration-level parity with the reference is UNPINNED (no golden vectors exist, the package is absent); results are
+pinned against dense Cholesky in tests/test_oracle_bbmm.py, and the recurrences themselves against independent third-party
+code in tests/test_oracle_independent_cpu.py (k-step iterates == scipy.sparse.linalg.cg's, with and without a preconditioner;
+the alpha / beta tridiagonal == an independent Lanczos tridiagonalisation).
 
 Layout here is the reference's: rhs is (n, c) with one right-hand side per COLUMN.
 

@@ -7,7 +7,8 @@ Restates the published algorithms of linear_operator v0.6.x (third-party, not ve
   * ``operators/added_diag_linear_operator.py::_preconditioner/_init_cache`` (SURVEY.md A.4)
   * ``LinearOperator._probe_vectors_and_norms``
 Iteration-level parity with the reference is UNPINNED; results pinned by properties
-(L L^T -> K as rank grows; P^-1 exact vs dense inverse; logdet(P) vs dense slogdet).
+(L L^T -> K as rank grows; P^-1 exact vs dense inverse; logdet(P) vs dense slogdet) and, step for step, against LAPACK's
+diagonally pivoted Cholesky dpstrf (same pivots, same factor columns: tests/test_oracle_independent_cpu.py).
 """
 from __future__ import annotations
 
