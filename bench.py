@@ -302,6 +302,14 @@ def main():
     except Exception:
         traffic = None
 
+    split_traffic = None   # the split kernel's PMC passes (same rules as above): profiles/r02_s24_pmc_split_t65.json
+    try:
+        sp = json.load(open(os.path.join(ROOT, "profiles", "r02_s24_pmc_split_t65.json"))).get("_derived", {})
+        if [n, d, cols] == [500_000, 3, 65]:
+            split_traffic = sp.get("hbm_bytes_per_launch")
+    except Exception:
+        split_traffic = None
+
     # whole-job algorithmic flops of the timed region: every rank's columns (t_total probes + one y) x CG iterations
     flops_job = 2.0 * n * n * (t_total + 1) * iters_total
     value = flops_job / elapsed / 1e12
@@ -344,7 +352,7 @@ def main():
                 # three f16 MFMAs per f32-equivalent multiply-add: executed flops against the dense f16 peak
                 ex = 3.0 * flop_per_launch / (ms_o * 1e-3) / 1e12
                 other["roofline"] = {"bound": "mfma", "achieved": ex, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s (f16, executed = 3 x algorithmic)",
-                                     "frac": ex / PEAK_F16_MFMA_TFLOPS, "kernel": "kv_gramh_kernel (csrc/kv_gramh.hpp)"}
+                                     "frac": ex / PEAK_F16_MFMA_TFLOPS, "traffic": split_traffic, "kernel": "kv_gramh_kernel (csrc/kv_gramh.hpp)"}
             if not args.skip_parity:
                 other["parity"] = parity_block(B.prep_points("rbf", Xd, lengthscale, shift), X, n, d, cols, ls, dev)
 
@@ -377,7 +385,8 @@ def main():
             "peak": PEAK_F16_MFMA_TFLOPS,
             "unit": "TFLOP/s (f16 MFMA, executed = 3 x algorithmic)",
             "frac": 3.0 * achieved / PEAK_F16_MFMA_TFLOPS,
-            "traffic": None,
+            "traffic": split_traffic,
+            "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
             "kernel": "kv_gramh_kernel<RBF,D=3> on rank 0 (Gram-form generation and hi/lo-split contraction on v_mfma_f32_32x32x16_f16)",
             "kernel_ms": kv_ms,
             "launches_timed": len(live),
