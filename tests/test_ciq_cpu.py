@@ -48,3 +48,22 @@ def test_contour_integral_quad_with_estimated_bounds():
     res2, _ = contour_integral_quad(lambda v: v @ K, b, n, inverse=False, tol=1e-9)
     ref2 = b @ (U @ torch.diag(ev.sqrt()) @ U.t())
     assert float((res2 - ref2).norm() / ref2.norm()) < 1e-6
+
+
+def test_msminres_iterates_are_scipy_minres_iterates():
+    """Independent pin of the multi-shift MINRES recurrences: for every shift the k-step iterate equals SciPy's MINRES iterate
+    after k steps on (A + s I) x = b (scipy.sparse.linalg.minres solves (A - shift I) x = b: shift = -s)."""
+    import numpy as np
+    import scipy.sparse.linalg as spla
+
+    n = 90
+    K = _spd(n, 5, floor=0.3)
+    b = torch.randn(1, n, generator=torch.Generator().manual_seed(6), dtype=torch.float64)
+    shifts = torch.tensor([0.0, 0.2, 1.5, 10.0], dtype=torch.float64)
+    for k in (1, 2, 5, 12):
+        X, it = msminres(lambda v: v @ K, b, shifts, n, tol=0.0, max_iter=k)
+        assert it == k
+        for q, s in enumerate(shifts.tolist()):
+            ref, _ = spla.minres(K.numpy(), b[0].numpy(), shift=-s, rtol=0.0, maxiter=k, x0=np.zeros(n))
+            ref = torch.from_numpy(ref)
+            assert float((X[q, 0] - ref).norm() / ref.norm()) < 1e-8, (k, s)
