@@ -79,7 +79,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // written in that order -- one MFMA, then its share of the next step's VALU work -- and sched_barrier(0) pins it.  To keep the pipeline
 // full across LDS tiles the split x_j rows (and the extra column) are staged ONE TILE AHEAD (double-buffered): the last step
 // of a tile generates the first block of the next one.
-// ABL (ablation builds of libgpamd_tune.so only; 0 in the product; 6 = register prefetch of the next tile, 7 = one wave per SIMD, 8 = no sched_barrier pinning): 1 no generation VALU, 2 no contraction MFMAs, 3 V planes staged
+// ABL (ablation builds of libgpamd_tune.so only; 0 in the product; 6 = register prefetch of the next tile, 7 = one wave per SIMD, 8 = no sched_barrier pinning, 10 = Gram MFMA one step further ahead): 1 no generation VALU, 2 no contraction MFMAs, 3 V planes staged
 // once (no global loads / LDS writes per tile; barriers stay), 4 as 3 and no barriers, 5 A operands read once per tile
 template <int KIND, int D, int CT, int NI, int EX, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ABL == 7 ? 1 : 2, ABL == 7 ? 1 : 2)))
@@ -242,12 +242,17 @@ void kv_gramh_kernel(KvhArgs ka) {
   stage_x(jbeg, 0);
   __syncthreads();
   u32x4 bh[2], bl[2];
+  // DEEP (tune builds, ABL = 10, NI = 2): the Gram MFMA runs one full step ahead of the generation that consumes it -- the
+  // distances of step s + 2 are issued at the start of step s, the generation during step s reads those issued during s - 1
+  constexpr bool DEEP = (ABL == 10) && NI == 2;
+  f32x16 kk_pend;
   {
     f16x8 aq0[KH];
     load_aq(0, 0, aq0);
     const f32x16 kk = gram(aq0, 0);
     finish_half(kk, 0, 0, 0, 0, bh[0], bl[0]);
     finish_half(kk, 1, 0, 0, 0, bh[1], bl[1]);
+    if constexpr (DEEP) kk_pend = gram(aq0, 1);   // distances of step (0, 1), consumed during step (0, 0)
   }
 
   // V planes of one tile: global -> registers (-> LDS between the barriers).  VPF: the loads of tile k + 1 are issued right
@@ -326,7 +331,13 @@ void kv_gramh_kernel(KvhArgs ka) {
         f32x4 ev[2][2];
         load_ev(bufn, jbn, 0, ev[0]);
         load_ev(bufn, jbn, 1, ev[1]);
-        const f32x16 kkn = gram(wrap ? aqn : aqc, nin);
+        f32x16 kkn, kk_new;
+        if constexpr (DEEP) {
+          kk_new = gram(aqn, ni);   // step s + 2 = (jb + 32, ni): x rows of the next block
+          kkn = kk_pend;
+        } else {
+          kkn = gram(wrap ? aqn : aqc, nin);
+        }
         u32x4 bhn[2], bln[2];
         if (ABL != 8) __builtin_amdgcn_sched_barrier(0);
         // contraction of this step, each MFMA followed by its share of the next step's generation; sched_barrier(0) pins the
@@ -355,6 +366,7 @@ void kv_gramh_kernel(KvhArgs ka) {
           }
         }
         if (ABL != 1) { bh[0] = bhn[0]; bh[1] = bhn[1]; bl[0] = bln[0]; bl[1] = bln[1]; }
+        if constexpr (DEEP) kk_pend = kk_new;
       }
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) aqc[kh] = aqn[kh];

@@ -19,7 +19,7 @@ extern "C" int gpamd_tune_kv_gramh_rbf3(int abl, int ni, const float* X1p, int n
   ka.Vh = (const _Float16*)Vh; ka.Vl = (const _Float16*)Vl; ka.ldh = ldh; ka.colmul = colmul;
   const dim3 grid((unsigned)a.nrb * S), block(256);
 #define L(A, N) if (abl == A && ni == N) hipLaunchKernelGGL((kv_gramh_kernel<KIND_RBF, 3, 2, N, 0, A>), grid, block, 0, (hipStream_t)stream, ka);
-  L(0, 2) L(1, 2) L(3, 2) L(4, 2) L(6, 2) L(7, 2) L(8, 2)
+  L(0, 2) L(1, 2) L(3, 2) L(4, 2) L(6, 2) L(7, 2) L(8, 2) L(10, 2)
 #undef L
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

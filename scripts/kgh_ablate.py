@@ -32,7 +32,7 @@ colmul = torch.ones(80, device=dev)
 S, jc, _ = B.kv_plan("rbf", n, n, 3, 64, B.KV_GRAM | B.KV_SPLIT, ld)
 P = torch.empty(S * 64 * ld, device=dev)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-names = {0: "full", 1: "no generation VALU", 2: "no contraction MFMAs", 3: "V planes staged once", 4: "staged once, no barriers", 5: "A operands from one block", 6: "next tile prefetched into registers", 7: "one wave per SIMD", 8: "no sched_barrier pinning"}
+names = {0: "full", 1: "no generation VALU", 2: "no contraction MFMAs", 3: "V planes staged once", 4: "staged once, no barriers", 5: "A operands from one block", 6: "next tile prefetched into registers", 7: "one wave per SIMD", 8: "no sched_barrier pinning", 10: "Gram MFMA one step further ahead"}
 out = []
 for abl, ni in cases:
     def run():
@@ -46,6 +46,11 @@ for abl, ni in cases:
         run()
     e1.record(); torch.cuda.synchronize()
     rec = dict(abl=abl, what=names[abl], ni=ni, S=S, ms=e0.elapsed_time(e1) / 3)
+    res = P.view(S, 64, ld).sum(0)
+    if abl == 0:
+        ref0 = res.clone()
+    elif abl in (6, 7, 8, 10) and "ref0" in dir():
+        rec["max_rel_dev_vs_full"] = float((res - ref0).abs().max() / ref0.abs().max())
     print(json.dumps(rec), flush=True)
     out.append(rec)
 os.makedirs("gpurun_out", exist_ok=True)
