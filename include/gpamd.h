@@ -47,7 +47,8 @@ enum {
   /* with GRAM, >= 5 columns: the contraction K * V runs on the f16 matrix pipe at f32 accuracy -- both operands split exactly
    * into f16 hi + lo parts (21-22 significant bits, power-of-two column scaling, f32 accumulation), three
    * v_mfma_f32_32x32x16_f16 in place of eight v_mfma_f32_32x32x2_f32 (kv_gramh.hpp).  The f16 planes of V live behind the
-   * partial slabs of the workspace: size it with gpamd_kv_plan called with the same flags. */
+   * partial slabs of the workspace: size it with gpamd_kv_plan called with the same flags and pass the plan's jchunk (a multiple of
+   * 128); the workspace must be 16-byte aligned and ldo a multiple of 4. */
   GPAMD_KV_SPLIT = 8
 };
 
