@@ -245,6 +245,9 @@ void kv_gramh_kernel(KvhArgs ka) {
   // DEEP (tune builds, ABL = 10, NI = 2): the Gram MFMA runs one full step ahead of the generation that consumes it -- the
   // distances of step s + 2 are issued at the start of step s, the generation during step s reads those issued during s - 1
   constexpr bool DEEP = (ABL == 10) && NI == 2;
+  // LEAN (NI * CT > 4: tune builds with four row tiles per wave and two column tiles): operands of a half are fetched just before
+  // its MFMAs instead of per block -- 128 accumulator registers leave no room for the whole block's operands
+  constexpr bool LEAN = NI * CT > 4;
   f32x16 kk_pend;
   {
     f16x8 aq0[KH];
@@ -311,7 +314,7 @@ void kv_gramh_kernel(KvhArgs ka) {
         }
     };
     f16x8 ah[2][CT], al[2][CT], aqc[KH];
-    load_a(0, ah, al);
+    if constexpr (!LEAN) load_a(0, ah, al);
     load_aq(buf, 0, aqc);
 #pragma unroll 2
     for (int jb = 0; jb < BN; jb += 32) {
@@ -329,8 +332,10 @@ void kv_gramh_kernel(KvhArgs ka) {
         const int jbn = wrap ? ((jb + 32) & (BN - 1)) : jb;
         const int bufn = (wrap && jb == BN - 32) ? (buf ^ 1) : buf;
         f32x4 ev[2][2];
-        load_ev(bufn, jbn, 0, ev[0]);
-        load_ev(bufn, jbn, 1, ev[1]);
+        if constexpr (!LEAN) {
+          load_ev(bufn, jbn, 0, ev[0]);
+          load_ev(bufn, jbn, 1, ev[1]);
+        }
         f32x16 kkn, kk_new;
         if constexpr (DEEP) {
           kk_new = gram(aqn, ni);   // step s + 2 = (jb + 32, ni): x rows of the next block
@@ -349,6 +354,15 @@ void kv_gramh_kernel(KvhArgs ka) {
           const f16x8 bhv = __builtin_bit_cast(f16x8, bh[mf]);
           const f16x8 blv = __builtin_bit_cast(f16x8, bl[mf]);
           f32x2 kv[4];
+          if constexpr (LEAN) {
+            load_ev(bufn, jbn, mf, ev[mf]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              const int o = (ct * 32 + l31) * LDH + jb + 16 * mf + 8 * h;
+              ah[mf][ct] = *reinterpret_cast<const f16x8*>(&Vhs[o]);
+              al[mf][ct] = *reinterpret_cast<const f16x8*>(&Vls[o]);
+            }
+          }
 #pragma unroll
           for (int q = 0; q < 3 * CT; ++q) {
             // the two small terms first, then the leading one; consecutive instructions alternate accumulators
@@ -375,7 +389,7 @@ void kv_gramh_kernel(KvhArgs ka) {
         for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) { ah[mf][ct] = ahn[mf][ct]; al[mf][ct] = aln[mf][ct]; }
-      } else {
+      } else if constexpr (!LEAN) {
         load_a((jb + 32) & (BN - 1), ah, al);
       }
     }
