@@ -113,6 +113,14 @@ def rq(x1, x2, lengthscale, alpha, x1_eq_x2=None, direct=False):
     return (1 + d2.div(2 * alpha)).pow(-alpha)
 
 
+def periodic(x1, x2, lengthscale, period_length):
+    """kernels/periodic_kernel.py:125-142: exp(-2 sum_q sin^2(pi (x1_q - x2_q) / p_q) / l_q); lengthscale / period_length [1, d or 1].
+    (The reference takes the per-dimension |x1_q - x2_q| through covar_dist(last_dim_is_batch=True); sin^2 is even, so the signed
+    difference gives the same value.)"""
+    diff = math.pi * (x1.unsqueeze(-2) - x2.unsqueeze(-3)) / period_length
+    return torch.exp(-2.0 * (diff.sin().pow(2) / lengthscale).sum(-1))
+
+
 KINDS = {"rbf": None, "matern12": 0.5, "matern32": 1.5, "matern52": 2.5}
 
 

@@ -17,10 +17,51 @@ from tests.util import make_data, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def periodic_ref(x1, x2, ls, period):
-    """periodic_kernel.py:125-142: exp(-2 sum_q sin^2(pi (x1_q - x2_q) / p_q) / l_q)."""
-    diff = math.pi * (x1.unsqueeze(-2) - x2.unsqueeze(-3)) / period
-    return torch.exp(-2.0 * (diff.sin().pow(2) / ls).sum(-1))
+periodic_ref = OK.periodic   # pinned to the reference's own PeriodicKernel.forward by tests/test_oracle_golden.py::test_periodic_and_rq_golden
+
+
+@pytest.mark.parametrize("name", list("pqrs"))
+def test_periodic_and_rq_against_reference_generated_fixtures(name, dev):
+    """The product kernels against OUTPUTS OF THE REFERENCE'S OWN CODE (tests/golden/composite_values.npz: PeriodicKernel.forward,
+    periodic_kernel.py:125-142, and RQKernel.forward, rq_kernel.py:61-74, executed through the reference's Kernel.covar_dist by
+    tests/golden/make_golden.py): dense values, diagonal, and the gradients of sum(W * K) w.r.t. every hyper-parameter."""
+    import os
+
+    import numpy as np
+
+    import gpytorch_amd as g
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "composite_values.npz"))
+    x1 = torch.from_numpy(z[f"{name}_x1"]).float().to(dev)
+    x2 = torch.from_numpy(z[f"{name}_x2"]).float().to(dev)
+    W = torch.from_numpy(z[f"{name}_W"]).to(dev)
+    ls, per, al = (torch.from_numpy(z[f"{name}_{k}"]).float() for k in ("ls", "period", "alpha"))
+    d = x1.shape[1]
+    ard = d if ls.shape[-1] > 1 else None
+    eye = torch.eye(x2.shape[0], device=dev)
+
+    def sig(raw):   # softplus chain rule: d softplus(raw) / d raw
+        return torch.sigmoid(raw.detach().double().cpu())
+
+    def close(got, want, raw, tol=3e-3):
+        want = torch.from_numpy(np.asarray(want)).double().reshape(got.shape) * sig(raw).reshape(got.shape)
+        return torch.allclose(got.double().cpu(), want, rtol=tol, atol=tol * float(want.abs().max()))
+
+    kp = g.kernels.PeriodicKernel(ard_num_dims=ard).to(dev)
+    kp.lengthscale, kp.period_length = ls, per
+    assert rel_err(kp(x1, x2).to_dense(), torch.from_numpy(z[f"{name}_periodic"]).double()) < 1e-5
+    assert torch.equal(kp(x1, diag=True).cpu().double(), torch.from_numpy(z[f"{name}_periodic_diag"]).double())
+    ((kp(x1, x2) @ eye) * W.float()).sum().backward()
+    assert close(kp.raw_lengthscale.grad, z[f"{name}_periodic_dls"], kp.raw_lengthscale)
+    assert close(kp.raw_period_length.grad, z[f"{name}_periodic_dperiod"], kp.raw_period_length)
+
+    kr = g.kernels.RQKernel(ard_num_dims=ard).to(dev)
+    kr.lengthscale, kr.alpha = ls, al
+    assert rel_err(kr(x1, x2).to_dense(), torch.from_numpy(z[f"{name}_rq"]).double()) < 1e-5
+    assert torch.equal(kr(x1, diag=True).cpu().double(), torch.from_numpy(z[f"{name}_rq_diag"]).double())
+    ((kr(x1, x2) @ eye) * W.float()).sum().backward()
+    assert close(kr.raw_lengthscale.grad, z[f"{name}_rq_dls"], kr.raw_lengthscale)
+    assert close(kr.raw_alpha.grad, z[f"{name}_rq_dalpha"], kr.raw_alpha)
 
 
 @pytest.mark.parametrize("ard", [False, True])

@@ -113,3 +113,37 @@ def test_parameter_transforms_golden():
     gt = GreaterThan(1e-4)
     assert torch.allclose(gt.transform(gt.inverse_transform(x + 1e-4)), x + 1e-4, rtol=1e-9, atol=0)
     assert float(gt.transform(torch.tensor(-50.0, dtype=torch.float64))) >= 1e-4 * (1 - 1e-6)  # the bound is a float32 buffer
+
+
+def test_periodic_and_rq_golden():
+    """oracle.kernels.periodic / rq against the outputs of the reference's OWN PeriodicKernel.forward (periodic_kernel.py:125-142) and
+    RQKernel.forward (rq_kernel.py:61-74) run through its own Kernel.covar_dist (tests/golden/composite_values.npz, make_golden.py):
+    values, diagonals and the gradients of sum(W * K) w.r.t. lengthscale, period_length and alpha."""
+    from oracle import kernels as OK
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "composite_values.npz"))
+    for name in "pqrs":
+        x1, x2 = torch.from_numpy(z[f"{name}_x1"]), torch.from_numpy(z[f"{name}_x2"])
+        W = torch.from_numpy(z[f"{name}_W"])
+        f32 = x1.dtype == torch.float32
+        tol = 2e-5 if f32 else 1e-11
+        ls = torch.from_numpy(z[f"{name}_ls"]).requires_grad_(True)
+        per = torch.from_numpy(z[f"{name}_period"]).requires_grad_(True)
+        al = torch.from_numpy(z[f"{name}_alpha"]).requires_grad_(True)
+        same = bool(z[f"{name}_same"])
+        kp = OK.periodic(x1, x2, ls, per)
+        assert np.abs(kp.detach().numpy() - z[f"{name}_periodic"]).max() < tol, name
+        gl, gp = torch.autograd.grad((kp * W).sum(), [ls, per])
+        gtol = 2e-3 if f32 else 1e-9
+        assert np.allclose(gl.numpy(), z[f"{name}_periodic_dls"], rtol=gtol, atol=gtol * np.abs(z[f"{name}_periodic_dls"]).max()), name
+        assert np.allclose(gp.numpy(), z[f"{name}_periodic_dperiod"], rtol=gtol, atol=gtol * np.abs(z[f"{name}_periodic_dperiod"]).max()), name
+        assert np.array_equal(z[f"{name}_periodic_diag"], np.ones_like(z[f"{name}_periodic_diag"]))
+        # the reference's Gram-trick sq_dist (the oracle's default form) and the direct pairwise form both match its output
+        for direct in (False, True):
+            kr = OK.rq(x1, x2, ls, al, x1_eq_x2=same, direct=direct)
+            assert np.abs(kr.detach().numpy() - z[f"{name}_rq"]).max() < (tol if not direct else max(tol, 1e-10) * 10), (name, direct)
+        kr = OK.rq(x1, x2, ls, al, x1_eq_x2=same)
+        gl, ga = torch.autograd.grad((kr * W).sum(), [ls, al])
+        assert np.allclose(gl.numpy(), z[f"{name}_rq_dls"], rtol=gtol, atol=gtol * np.abs(z[f"{name}_rq_dls"]).max()), name
+        assert np.allclose(ga.numpy(), z[f"{name}_rq_dalpha"], rtol=gtol, atol=gtol * abs(float(z[f"{name}_rq_dalpha"][0]))), name
+        assert np.array_equal(z[f"{name}_rq_diag"], np.ones_like(z[f"{name}_rq_diag"]))
