@@ -23,15 +23,14 @@ _f = C.c_float
 SIGNATURES = {
     "gpamd_abi_version": (_i, []),
     "gpamd_last_error": (C.c_char_p, []),
-    "gpamd_set_kernel_param_f32": (_i, [_f]),
-    "gpamd_prep_points_f32": (_i, [_i, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
+    "gpamd_prep_points_f32": (_i, [_i, _f, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
     "gpamd_kv_plan": (_i, [_i, _i, _i, _i, _i, _i, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
-    "gpamd_kv_partials_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _p]),
+    "gpamd_kv_partials_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _p]),
     "gpamd_kv_reduce_f32": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
-    "gpamd_kv_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
-    "gpamd_kernel_rows_f32": (_i, [_i, _p, _p, _i, _p, _i, _i, _p, _p, _i64, _p]),
-    "gpamd_kernel_dense_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _p, _i64, _p]),
-    "gpamd_kernel_diag_f32": (_i, [_i, _p, _p, _i, _i, _p, _p, _p]),
+    "gpamd_kv_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
+    "gpamd_kernel_rows_f32": (_i, [_i, _f, _p, _p, _i, _p, _i, _i, _p, _p, _i64, _p]),
+    "gpamd_kernel_dense_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _p]),
+    "gpamd_kernel_diag_f32": (_i, [_i, _f, _p, _p, _i, _i, _p, _p, _p]),
     "gpamd_coldot_f32": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
     "gpamd_cg_fscratch_elems": (_i64, [_i, _i]),
     "gpamd_cg_iscratch_elems": (_i64, [_i]),
@@ -52,7 +51,7 @@ SIGNATURES = {
     "gpamd_cg_update_d_f32": (_i, [_p, _i, _p]),
     "gpamd_cg_stop_f32": (_i, [_p, _i, _i, _i, _f, _p]),
     "gpamd_cg_finish_f32": (_i, [_p, _p]),
-    "gpamd_pivoted_cholesky_f32": (_i, [_i, _p, _i, _i, _p, _i, _f, _p, _i64, _p, _p, _p, _p]),
+    "gpamd_pivoted_cholesky_f32": (_i, [_i, _f, _p, _i, _i, _p, _i, _f, _p, _i64, _p, _p, _p, _p]),
     "gpamd_lanczos_num_partials": (_i, [_i]),
     "gpamd_lanczos_partial_stride": (_i, []),
     "gpamd_lanczos_residual_f32": (_i, [_p, _p, _p, _p, _i, _p]),
@@ -87,7 +86,7 @@ SIGNATURES = {
     "gpamd_kv_grad_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p]),
     "gpamd_kv_grad2_workspace_doubles": (_i64, [_i, _i, _i, _i]),
     "gpamd_kv_grad2_xworkspace_floats": (_i64, [_i, _i, _i, _i]),
-    "gpamd_kv_grad2_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p, _i64, _p, _i64, _p]),
+    "gpamd_kv_grad2_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p, _i64, _p, _i64, _p]),
 }
 
 
@@ -109,7 +108,7 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if h.gpamd_abi_version() != 1:
+        if h.gpamd_abi_version() != 2:
             raise GpamdError("libgpamd.so ABI version mismatch")
         _lib = h
     return _lib

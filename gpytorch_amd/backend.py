@@ -84,11 +84,14 @@ class PreparedPoints:
 
 
 def kind_id(xp: PreparedPoints) -> int:
-    """Integer id of the covariance family of ``xp`` for the C ABI; for parametrised families (RQ) the shape parameter is
-    handed to the library first (``gpamd_set_kernel_param_f32``: thread-local host state read at launch time)."""
-    if xp.param is not None:
-        check(lib().gpamd_set_kernel_param_f32(float(xp.param)), "set_kernel_param")
+    """Integer id of the covariance family of ``xp`` for the C ABI."""
     return KIND_IDS[xp.kind]
+
+
+def kind_args(xp: PreparedPoints):
+    """(kind, kparam): the two leading arguments of every float32 entry point that evaluates the covariance (ABI version 2: the shape
+    parameter of a parametrised family -- RQ's alpha -- is an explicit argument, the library keeps no per-thread kernel state)."""
+    return KIND_IDS[xp.kind], float(xp.param) if xp.param is not None else 0.0
 
 
 def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
@@ -122,7 +125,8 @@ def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: to
         param = float(param)
         if work_dtype(x) != torch.float32 or x.shape[-1] > MAX_INPUT_DIM:
             raise NotImplementedError("RQKernel runs on the fused float32 kernels only (float32 inputs, d <= 16)")
-        check(lib().gpamd_set_kernel_param_f32(param), "set_kernel_param")
+        if not param > 0.0:
+            raise ValueError("the rational-quadratic shape parameter alpha must be positive")
     else:
         param = None
     n, d = x.shape[-2], x.shape[-1]
@@ -135,7 +139,8 @@ def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: to
     sh = None if shift is None else shift.detach().to(device=x.device, dtype=wd).reshape(-1).contiguous()
     xp = torch.empty(n, dp, device=x.device, dtype=wd)
     fn = lib().gpamd_prep_points_f64 if wd == torch.float64 else lib().gpamd_prep_points_f32
-    check(fn(KIND_IDS[kind], _ptr(x), n, d, x.stride(0), _ptr(ls), ls.numel(), _ptr(sh), _ptr(xp), dp, _stream(x.device)), "prep_points")
+    lead = (KIND_IDS[kind],) if wd == torch.float64 else (KIND_IDS[kind], param if param is not None else 0.0)
+    check(fn(*lead, _ptr(x), n, d, x.stride(0), _ptr(ls), ls.numel(), _ptr(sh), _ptr(xp), dp, _stream(x.device)), "prep_points")
     return PreparedPoints(xp, n, d, dp, kind, param)
 
 
@@ -198,7 +203,7 @@ def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dsc
     L = lib()
     check(
         L.gpamd_kv_partials_f32(
-            kind_id(x1), _ptr(x1.xp), n, _ptr(x2.xp), m, x1.d, _ptr(vt), ldv, t, _ptr(ws), ldo, S, jc,
+            *kind_args(x1), _ptr(x1.xp), n, _ptr(x2.xp), m, x1.d, _ptr(vt), ldv, t, _ptr(ws), ldo, S, jc,
             flags, None, st
         ),
         "kv_partials",
@@ -223,7 +228,7 @@ def kernel_row_block(x1: PreparedPoints, r0: int, nrows: int, x2: PreparedPoints
                                           _ptr(out), out.stride(0), st), "kernel_rows_f64")
     else:
         blk = x1.xp[r0 : r0 + nrows]
-        check(lib().gpamd_kernel_dense_f32(kind_id(x1), _ptr(blk), nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
+        check(lib().gpamd_kernel_dense_f32(*kind_args(x1), _ptr(blk), nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
                                            out.stride(0), st), "kernel_dense")
     return out
 
@@ -305,7 +310,7 @@ def kernel_dense(x1: PreparedPoints, x2: PreparedPoints, scale=None) -> torch.Te
     out = torch.empty(x1.n, x2.n, device=x1.xp.device, dtype=torch.float32)
     check(
         lib().gpamd_kernel_dense_f32(
-            kind_id(x1), _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out), out.stride(0),
+            *kind_args(x1), _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out), out.stride(0),
             _stream(out.device),
         ),
         "kernel_dense",
@@ -324,7 +329,7 @@ def kernel_rows(x1: PreparedPoints, rows: torch.Tensor, x2: PreparedPoints, scal
     out = torch.empty(rows.numel(), x2.n, device=x1.xp.device, dtype=torch.float32)
     check(
         lib().gpamd_kernel_rows_f32(
-            kind_id(x1), _ptr(x1.xp), _ptr(rows), rows.numel(), _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
+            *kind_args(x1), _ptr(x1.xp), _ptr(rows), rows.numel(), _ptr(x2.xp), x2.n, x1.dp, _ptr(scale), _ptr(out),
             out.stride(0), _stream(out.device),
         ),
         "kernel_rows",
@@ -343,7 +348,7 @@ def kernel_diag(x1: PreparedPoints, x2: PreparedPoints, scale=None) -> torch.Ten
     out = torch.empty(x1.n, device=x1.xp.device, dtype=torch.float32)
     check(
         lib().gpamd_kernel_diag_f32(
-            kind_id(x1), _ptr(x1.xp), _ptr(x2.xp), x1.n, x1.dp, _ptr(scale), _ptr(out), _stream(out.device)
+            *kind_args(x1), _ptr(x1.xp), _ptr(x2.xp), x1.n, x1.dp, _ptr(scale), _ptr(out), _stream(out.device)
         ),
         "kernel_diag",
     )
@@ -381,7 +386,7 @@ def pivoted_cholesky(xp: PreparedPoints, scale, rank: int, tol: float):
     iwork = torch.zeros(2 + 2 * n, device=dev, dtype=torch.int32)
     check(
         lib().gpamd_pivoted_cholesky_f32(
-            kind_id(xp), _ptr(xp.xp), n, xp.dp, _ptr(scale), rank, float(tol), _ptr(L), ldl, _ptr(piv), _ptr(fwork),
+            *kind_args(xp), _ptr(xp.xp), n, xp.dp, _ptr(scale), rank, float(tol), _ptr(L), ldl, _ptr(piv), _ptr(fwork),
             _ptr(iwork), _stream(dev),
         ),
         "pivoted_cholesky",
@@ -444,7 +449,7 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
         gzt = torch.empty(x1.d, ldg, device=dev, dtype=torch.float32)
     check(
         L.gpamd_kv_grad2_f32(
-            kind_id(x1), _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.d, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
+            *kind_args(x1), _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.d, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
             1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, _stream(dev),
         ),
         "kv_grad2",

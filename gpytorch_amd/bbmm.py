@@ -21,8 +21,9 @@ from . import settings
 from .linear_cg import CGInfo, Preconditioner, linear_cg
 
 
-def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=None, tol=None, min_size=None):
-    """Pivoted-Cholesky preconditioner P = L L^T + s2 I (constant-diagonal branch of A.4).
+def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=None, tol=None, min_size=None, dvec=None):
+    """Pivoted-Cholesky preconditioner P = L L^T + s2 I (constant-diagonal branch of A.4); with ``dvec`` (a fixed per-point noise
+    vector [>= n] added on top of s2: FixedNoiseGaussianLikelihood) the non-constant-diagonal branch, P = L L^T + diag(s2 + dvec).
 
     Returns ``None`` when disabled (rank 0 or n < min_preconditioning_size), else a
     :class:`Preconditioner` holding Q1 (as [k, ld] rows), log|P| and L^T.
@@ -45,13 +46,36 @@ def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=
 
         warnings.warn("NaNs encountered in preconditioner computation. Attempting to continue without preconditioning.", NumericalWarning)
         return None
+    if dvec is not None:
+        return preconditioner_from_factor(lt, n, sigma2.detach().reshape(()).to(dvec.dtype) + dvec.detach()[:n], x.dtype, noise_is_vector=True)
+    return preconditioner_from_factor(lt, n, sigma2, x.dtype)
+
+
+def preconditioner_from_factor(lt: torch.Tensor, n: int, noise: torch.Tensor, wd, noise_is_vector: bool = False) -> Preconditioner:
+    """P = L L^T + D from the (pivoted-Cholesky) factor ``lt`` [k, >= n] and the diagonal D: a scalar sigma^2 (A.4's constant branch)
+    or a vector [>= n] (the reference's ``_init_cache_for_non_constant_diag``: fixed heteroskedastic noise, per-task noise).
+
+    The reference takes a Householder QR of [L; sqrt(s2) I]; here the same thin factor comes from two rounds of Cholesky-QR in
+    float64 (n x k GEMMs + k x k Cholesky + triangular solve).  For a vector D the system is rescaled: Lt = D^-1/2 L, sigma^2 = 1,
+    log|P| = sum log d + log|Lt^T Lt + I| and the apply is D^-1/2 (I - Q1 Q1^T) D^-1/2 (``Preconditioner.dinv_sqrt``)."""
     dev = lt.device
-    wd = x.dtype
+    k = lt.shape[0]
     ld = B.round_up(n, 4)
-    s2 = sigma2.detach().reshape(()).to(torch.float64)
     eye = torch.eye(k, device=dev, dtype=torch.float64)
+    ltd = lt[:, :n].to(torch.float64)
+    extra_logdet = 0.0
+    dinv_sqrt = None
+    if noise_is_vector:
+        d = noise.detach().reshape(-1)[:n].to(torch.float64)
+        di = d.rsqrt()
+        ltd = ltd * di.unsqueeze(0)
+        extra_logdet = d.log().sum()
+        s2 = torch.ones((), device=dev, dtype=torch.float64)
+        dinv_sqrt = torch.zeros(ld, device=dev, dtype=torch.float64)
+        dinv_sqrt[:n] = di
+    else:
+        s2 = noise.detach().reshape(()).to(torch.float64)
     # Cholesky-QR twice, all in float64 (n x k GEMMs: 2 n k^2 flop each, < 10 ms at n = 5e5, k = 100)
-    ltd = lt.to(torch.float64)
     r1 = torch.linalg.cholesky(ltd @ ltd.t() + s2 * eye, upper=True)           # G = L^T L + s2 I = R1^T R1
     r1inv = torch.linalg.solve_triangular(r1, eye, upper=True)
     q1t = r1inv.t() @ ltd                                                       # [k, n] = (L R1^-1)^T
@@ -60,25 +84,89 @@ def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=
     r2inv = torch.linalg.solve_triangular(r2, eye, upper=True)
     q1t = r2inv.t() @ q1t
     rdiag = (r2 @ r1).diagonal()
-    logdet = 2.0 * rdiag.abs().log().sum() + (n - k) * torch.log(s2)
+    logdet = 2.0 * rdiag.abs().log().sum() + (n - k) * torch.log(s2) + extra_logdet
     q1t_pad = torch.zeros(k, ld, device=dev, dtype=torch.float64)              # kept in float64: see Preconditioner.apply_
     q1t_pad[:, :n] = q1t
     lt_pad = torch.zeros(k, ld, device=dev, dtype=wd)
-    lt_pad[:, :n] = lt
-    return Preconditioner(q1t_pad, sigma2.detach().reshape(()).to(wd), logdet.to(wd), lt_pad)
+    lt_pad[:, :n] = lt[:, :n]
+    return Preconditioner(q1t_pad, s2.to(wd), logdet.to(wd), lt_pad, dinv_sqrt=dinv_sqrt)
 
 
-def deterministic_probe_matrix(n: int, t: int, device, dtype=torch.float32):
+def pivoted_cholesky_rows(row_fn, kdiag: torch.Tensor, rank: int, tol: float) -> torch.Tensor:
+    """Pivoted Cholesky of a matrix that is only available ROW BY ROW -- the noise-free part of the structured
+    operators (sum of kernels, Kronecker K_XX (x) K_TT, Hadamard K_X o K_TT[ti, ti]), whose rows are combinations of rows of their
+    members' fused kernels (``gpamd_kernel_rows_f32``).  ``row_fn(p)``: row p ([n]) for a 1-element device index tensor;
+    ``kdiag``: the diagonal [n].  Same greedy rule as ``gpamd_pivoted_cholesky_f32`` (largest remaining diagonal, ties by position;
+    stop once the remaining trace falls below ``tol`` x the largest diagonal entry).  No host synchronisation: every one of the
+    ``rank`` steps is enqueued, steps after the tolerance is met write zero rows (a zero column of L leaves P unchanged).
+    Returns L^T as [rank, n] float32 / float64 (the dtype of ``kdiag``)."""
+    n = kdiag.numel()
+    rank = min(rank, n)
+    dev, wd = kdiag.device, kdiag.dtype
+    d = kdiag.clone()
+    orig = d.max()
+    lt = torch.zeros(rank, n, device=dev, dtype=wd)
+    used = torch.zeros(n, device=dev, dtype=torch.bool)
+    ninf = torch.full((), float("-inf"), device=dev, dtype=wd)
+    zero = torch.zeros((), device=dev, dtype=wd)
+    for m in range(rank):
+        rem = torch.where(used, zero, d)
+        go = (rem.sum() / orig > tol) & (rem.max() > 0)
+        p = torch.where(used, ninf, d).argmax().reshape(1)
+        lmm = d[p].clamp_min(1e-30).sqrt()                      # [1]
+        row = row_fn(p).reshape(-1).to(wd)
+        l = row - (lt[:m, p].t() @ lt[:m]).reshape(-1) if m else row
+        l = l / lmm
+        l = torch.where(used, zero, l)
+        l[p] = lmm
+        l = torch.where(go, l, torch.zeros_like(l))
+        lt[m] = l
+        d = d - l * l
+        used[p] = used[p] | go
+    return lt
+
+
+def build_preconditioner_rows(row_fn, kdiag: torch.Tensor, noise: torch.Tensor, noise_is_vector: bool, rank=None, tol=None, min_size=None):
+    """The pivoted-Cholesky preconditioner of a structured operator K + D (``pivoted_cholesky_rows`` + ``preconditioner_from_factor``).
+    The reference preconditions every ``AddedDiagLinearOperator`` this way, whatever its first summand (``settings.py:6-31``
+    ``max_preconditioner_size``, ``kernels/multitask_kernel.py:46-54``); ``None`` when disabled."""
+    rank = settings.max_preconditioner_size.value() if rank is None else rank
+    tol = settings.preconditioner_tolerance.value() if tol is None else tol
+    min_size = settings.min_preconditioning_size.value() if min_size is None else min_size
+    n = kdiag.numel()
+    if rank == 0 or n < min_size or not bool((noise.detach() > 0).all()):
+        return None
+    lt = pivoted_cholesky_rows(row_fn, kdiag.detach(), rank, tol)
+    if not bool(torch.isfinite(lt).all()):
+        import warnings
+
+        from .linear_cg import NumericalWarning
+
+        warnings.warn("NaNs encountered in preconditioner computation. Attempting to continue without preconditioning.", NumericalWarning)
+        return None
+    return preconditioner_from_factor(lt, n, noise, kdiag.dtype, noise_is_vector)
+
+
+def deterministic_probe_matrix(n: int, t: int, device, dtype=torch.float32, shard=None):
     """``settings.deterministic_probes`` (A.5): ONE (n, t) Gaussian matrix, drawn on first use, stored on the setting
     and re-used by every later evaluation (so line searches / L-BFGS see a deterministic objective).  A user-injected
-    matrix is used as it is; a stored matrix of the wrong length (another model) is redrawn.  ``None`` when the flag is off."""
+    matrix (``deterministic_probes.probe_vectors = Z``) of the right length is used as it is; matrices the library draws are kept
+    per (n, t), so alternating between models of different size does not redraw.  ``None`` when the flag is off.
+    ``shard = (t_total, a, b)`` (probe-column sharding): the stored matrix has ``t_total`` columns -- identical on identically seeded
+    ranks, as the single-process run would draw it -- and THIS rank's columns [a, b) are returned, so the estimator keeps
+    ``t_total`` distinct probes instead of ``world`` copies of the same ``t_local`` ones."""
     if not settings.deterministic_probes.on():
         return None
+    t_all = t if shard is None else shard[0]
     z = settings.deterministic_probes.probe_vectors
-    if z is None or z.shape[-2] != n:
-        z = torch.randn(n, t, device=device, dtype=dtype)
+    if z is None or z.shape[-2] != n or (shard is not None and z.shape[-1] != t_all):
+        key = (n, t_all, str(device), dtype)
+        z = settings.deterministic_probes._drawn.get(key)
+        if z is None:
+            z = torch.randn(n, t_all, device=device, dtype=dtype)
+            settings.deterministic_probes._drawn[key] = z
         settings.deterministic_probes.probe_vectors = z
-    return z
+    return z if shard is None else z[:, shard[1] : shard[2]]
 
 
 def probe_vectors(n: int, t: int, precond: Preconditioner | None, device, generator=None, probes=None, dtype=torch.float32):
@@ -101,7 +189,7 @@ def probe_vectors(n: int, t: int, precond: Preconditioner | None, device, genera
         k = precond.lt.shape[0]
         e1 = torch.randn(t, k, device=device, generator=generator, dtype=dtype)
         e2 = torch.randn(t, n, device=device, generator=generator, dtype=dtype)
-        zt[:, :n] = (e1 @ precond.lt.to(dtype))[:, :n] + precond.sigma2.to(dtype).sqrt() * e2
+        zt[:, :n] = (e1 @ precond.lt.to(dtype))[:, :n] + precond.noise_sqrt(n, dtype) * e2
     norms = B.coldot(zt, zt, n).sqrt()
     zt.div_(norms.unsqueeze(-1))
     return zt, norms
@@ -149,6 +237,8 @@ def inv_quad_logdet_forward(
     t_total=None,
     dvec=None,
     rhs_owner: int = 0,
+    kv_partials=None,
+    nvec=None,
 ) -> InvQuadLogdetResult:
     """A.6 forward for K_hat = scale*K(x,x) + sigma2*I.
 
@@ -156,18 +246,25 @@ def inv_quad_logdet_forward(
     With ``group`` set the probe columns are sharded over ranks: ``num_probes`` / ``probes`` are THIS rank's probes,
     ``t_total`` the global probe count (default: all-reduced sum).  The rhs columns are solved by ONE rank
     (``rhs_owner``, a rank of the group; default 0) -- the others carry probes only -- and their solves / inverse quadratic
-    forms are broadcast once at the end.  Communication: the 2-float stopping-rule all-reduce per CG iteration (stream-
+    forms are broadcast once at the end.
+    STRUCTURED operators (sum of kernels, Kronecker, Hadamard): ``x = None``, ``kv_partials(Dt) -> (P, S, ldp)`` is the noise-free
+    product (as for :func:`linear_cg`), ``nvec`` the vector length, ``dvec`` the WHOLE diagonal and ``precond`` an explicit
+    :class:`Preconditioner` (``build_preconditioner_rows``) or None; everything else -- probes from N(0, P), sharding, SLQ -- is shared.  Communication: the 2-float stopping-rule all-reduce per CG iteration (stream-
     ordered under RCCL), one scalar all-reduce of the SLQ sums, one broadcast of the c rhs solves."""
-    n = x.n
+    n = x.n if nvec is None else nvec
     dev = rhs_t.device
-    wd = x.dtype
+    wd = x.dtype if x is not None else rhs_t.dtype
     t = settings.num_trace_samples.value() if num_probes is None else num_probes
-    if dvec is not None:
-        precond = None  # the pivoted-Cholesky preconditioner is built for the constant-diagonal branch only (A.4)
     if precond == "auto":
-        precond = build_preconditioner(x, scale, sigma2)
-    if probes is None:
-        probes = deterministic_probe_matrix(n, t, dev, wd)
+        precond = build_preconditioner(x, scale, sigma2, dvec=dvec) if x is not None else None
+    if probes is None and settings.deterministic_probes.on():
+        shard = None
+        if group is not None and t_total is not None:
+            from .distributed import probe_shard
+
+            a, b = probe_shard(t_total, torch.distributed.get_world_size(group), torch.distributed.get_rank(group))
+            shard = (t_total, a, b)
+        probes = deterministic_probe_matrix(n, t, dev, wd, shard=shard)
     if probes is not None:
         t = probes.shape[-1]
     zt, znorm = probe_vectors(n, t, precond, dev, generator, probes, dtype=wd)
@@ -184,7 +281,7 @@ def inv_quad_logdet_forward(
     full = torch.cat([zt, rhs_t.to(wd)], dim=0).contiguous() if owns_rhs else zt
     solves_t, info = linear_cg(
         x, scale, sigma2, full, n_tridiag=t, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, group=group,
-        dvec=dvec,
+        dvec=dvec, kv_partials=kv_partials, nvec=nvec,
     )
     if settings.skip_logdet_forward.on():
         ld_slq = torch.zeros((), dtype=torch.float64)
@@ -202,6 +299,64 @@ def inv_quad_logdet_forward(
     logdet = ld_slq + (precond.logdet if precond is not None else 0.0)
     inv_quad = B.coldot(solves_t[t : t + c], rhs_t.to(wd), n)
     return InvQuadLogdetResult(inv_quad, logdet, solves_t, zt, znorm, precond, info, ld_slq, owns_rhs)
+
+
+def backward_vectors(res: InvQuadLogdetResult, g_iq: torch.Tensor, g_ld: torch.Tensor, t_total: int):
+    """The left / right vectors of the A.6 backward, d/dtheta [g_iq . inv_quad + g_ld logdet] = sum_c left[c]^T (dK_hat/dtheta) right[c]:
+    left = [K^-1 z_j |z_j| g_ld / t_total  |  -K^-1 y g_iq], right = [P^-1 z_j |z_j|  |  K^-1 y].  Probe-sharded: a rank that does not
+    own the rhs columns contributes its probe block only (the owner adds the rhs block once; gradients are all-reduced by the caller).
+    Returns (left, right, s_y) with s_y = K^-1 y ([c, ld], every rank has it)."""
+    t = res.zt.shape[0]
+    wd = res.solves_t.dtype
+    c = res.solves_t.shape[0] - t
+    g_iq = g_iq.to(wd).reshape(c, 1)
+    g_ld = g_ld.to(wd).reshape(())
+    s_z = res.solves_t[:t] * res.znorm.unsqueeze(-1)
+    s_y = res.solves_t[t:]
+    zr = res.zt * res.znorm.unsqueeze(-1)
+    if res.precond is not None:
+        zr = res.precond.apply_(zr, torch.zeros_like(zr))
+    if res.owns_rhs:
+        left = torch.cat([s_z * (g_ld / t_total), -s_y * g_iq], dim=0).contiguous()
+        right = torch.cat([zr, s_y], dim=0).contiguous()
+    else:
+        left = (s_z * (g_ld / t_total)).contiguous()
+        right = zr.contiguous()
+    return left, right, s_y
+
+
+def allreduce_grads_(grads: list, group):
+    """Sum a list of (possibly None) gradient tensors over the probe group in ONE packed all-reduce (in place)."""
+    live = [g for g in grads if g is not None]
+    if group is None or not live:
+        return grads
+    pack = torch.cat([g.reshape(-1).to(torch.float32) for g in live])
+    allreduce_sum_(pack, group)
+    o = 0
+    for g in live:
+        g.copy_(pack[o : o + g.numel()].reshape(g.shape).to(g.dtype))
+        o += g.numel()
+    return grads
+
+
+def structured_opts(opts: dict, device) -> dict:
+    """Solver options of a structured-operator MLL evaluation: ``bbmm_opts`` completed with the ``settings.sharding`` probe group
+    (each rank draws its share of ``num_trace_samples`` from a rank-specific generator) -- the same completion
+    ``FusedKernelAddedDiagLinearOperator._iql_opts`` performs for the single-kernel operator."""
+    group = opts.get("group", settings.sharding.probe_group())
+    if group is None or "group" in opts or torch.distributed.get_world_size(group) == 1:
+        return opts
+    from .distributed import probe_shard
+
+    world, rank = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
+    t_total = settings.num_trace_samples.value()
+    a, b = probe_shard(t_total, world, rank)
+    if b - a < 1:
+        raise ValueError(f"probe sharding needs num_trace_samples >= world size ({t_total} < {world})")
+    opts = dict(opts, group=group, num_probes=b - a, t_total=t_total)
+    if "generator" not in opts and opts.get("probes") is None:
+        opts["generator"] = settings.sharding.rank_generator(group, device)
+    return opts
 
 
 def solve(x: B.PreparedPoints, scale, sigma2, rhs_t, tolerance=None, max_iter=None, precond="auto"):

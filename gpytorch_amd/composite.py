@@ -3,7 +3,7 @@
 ``K = sum_i theta_i k_i(x, x)`` stays a list of :class:`~gpytorch_amd.operators.FusedKernelLinearOperator` members; products,
 mBCG solves, SLQ log-determinants and Lanczos decompositions use the members' fused K*V launches summed per product (the
 ``kv_partials`` hook of :func:`gpytorch_amd.linear_cg.linear_cg`), and the A.6 backward runs one fused bilinear derivative per
-member.  No preconditioner (the pivoted-Cholesky kernel works on one stationary kernel).
+member.  Preconditioner: pivoted Cholesky on rows of the SUMMED kernel (``sum_preconditioner``; ``bbmm.pivoted_cholesky_rows``).
 """
 from __future__ import annotations
 
@@ -11,8 +11,8 @@ import torch
 
 from . import backend as B
 from . import settings
-from .bbmm import deterministic_probe_matrix, slq_logdet
-from .functions import hyper_grads
+from .bbmm import allreduce_grads_, backward_vectors, build_preconditioner_rows, inv_quad_logdet_forward, structured_opts
+from .functions import _prep, hyper_grads
 from .linear_cg import linear_cg
 from .operators import (
     ConstantDiagLinearOperator,
@@ -21,6 +21,7 @@ from .operators import (
     LinearOperator,
     RootLinearOperator,
     ZeroLinearOperator,
+    split_diag,
 )
 
 
@@ -85,11 +86,9 @@ class SumFusedLinearOperator(LinearOperator):
             return self
         if isinstance(other, (FusedKernelLinearOperator, SumFusedLinearOperator)):
             return SumFusedLinearOperator.of([self, other])
-        if isinstance(other, ConstantDiagLinearOperator) and self.is_square and not other.batch_shape:
-            return SumFusedAddedDiagLinearOperator(self, other.diag_values)
         if isinstance(other, DiagLinearOperator) and self.is_square and not other.batch_shape:
-            zero = torch.zeros(1, device=self.device, dtype=self.dtype)
-            return SumFusedAddedDiagLinearOperator(self, zero, noise_vec=other._diag)
+            noise, vec = split_diag(other, self.device, self.dtype)
+            return SumFusedAddedDiagLinearOperator(self, noise, noise_vec=vec)
         return super().__add__(other)
 
     __radd__ = __add__
@@ -135,11 +134,10 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
         return SumFusedAddedDiagLinearOperator(self.kernel_sum.detach(), self.noise.detach(), self.noise_vec, self.bbmm_opts)
 
     def __add__(self, other):
-        if isinstance(other, ConstantDiagLinearOperator) and not other.batch_shape:
-            return SumFusedAddedDiagLinearOperator(self.kernel_sum, self.noise + other.diag_values.reshape(-1)[:1], self.noise_vec, self.bbmm_opts)
         if isinstance(other, DiagLinearOperator) and not other.batch_shape:
-            nv = other._diag if self.noise_vec is None else self.noise_vec + other._diag
-            return SumFusedAddedDiagLinearOperator(self.kernel_sum, self.noise, nv, self.bbmm_opts)
+            noise, vec = split_diag(other, self.device, self.dtype)
+            nv = self.noise_vec if vec is None else (vec if self.noise_vec is None else self.noise_vec + vec)
+            return SumFusedAddedDiagLinearOperator(self.kernel_sum, self.noise + noise, nv, self.bbmm_opts)
         return super().__add__(other)
 
     def restrict(self, idx):
@@ -178,8 +176,10 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
             if drop:
                 rhs = torch.zeros(n, 1, device=self.device, dtype=self.dtype)
             flat = []
+            empty = torch.empty(0, device=self.device)
             for o in self.kernel_sum.ops:
-                flat += [o.x1, o.lengthscale, o.outputscale if o.outputscale is not None else torch.empty(0, device=self.device)]
+                flat += [o.x1, o.lengthscale, o.outputscale if o.outputscale is not None else empty,
+                         o.spec.param if o.spec.param is not None else empty]
             specs = [o.spec for o in self.kernel_sum.ops]
             iq, ld = SumInvQuadLogdetFn.apply(self.noise, rhs, specs, self._dvec(B.work_dtype(self.kernel_sum.ops[0].x1)), self.bbmm_opts, *flat)
             if drop:
@@ -214,8 +214,11 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
         else:
             partials, wd = self._partials()
             nz = self.noise.detach().reshape(-1)[:1].to(wd).contiguous()
+            dv = self._dvec(wd)
+            if not hasattr(self, "_precond_cache"):
+                self._precond_cache = sum_preconditioner(self._prepared(), nz, dv, self.shape[-1])
             sol_t, _ = linear_cg(None, None, nz, B.to_probe_major(r.detach(), wd), n_tridiag=0, tolerance=settings.cg_tolerance.value(),
-                                 kv_partials=partials, dvec=self._dvec(wd), nvec=self.shape[-1])
+                                 kv_partials=partials, dvec=dv, nvec=self.shape[-1], preconditioner=self._precond_cache)
             sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
         if lhs is not None:
             sol = lhs @ sol
@@ -240,35 +243,52 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
         return RootLinearOperator(B.from_probe_major(rt, n).to(self.dtype))
 
 
+def sum_preconditioner(prepared, noise, dvec, n, rank=None, tol=None, min_size=None):
+    """Pivoted-Cholesky preconditioner of (sum_i theta_i k_i) + noise I (+ diag(dvec)): a row of the sum is the sum of the members'
+    ``gpamd_kernel_rows_f32`` rows (the reference preconditions a SumLinearOperator + diagonal the same way, through its generic
+    ``pivoted_cholesky``; ``gpytorch/kernels/kernel.py:592-632`` + ``settings.py:6-31``)."""
+    if not all(xp.fused for xp, _ in prepared):
+        return None
+    wd = prepared[0][0].dtype
+
+    def row_fn(p):
+        out = None
+        for xp, os_ in prepared:
+            r = B.kernel_rows(xp, p, xp, os_).reshape(-1)
+            out = r if out is None else out + r
+        return out
+
+    kdiag = None
+    for xp, os_ in prepared:
+        dg = B.kernel_diag(xp, xp, os_)
+        kdiag = dg if kdiag is None else kdiag + dg
+    nz = noise.detach().reshape(-1)[:1].to(wd)
+    if dvec is None:
+        return build_preconditioner_rows(row_fn, kdiag, nz, False, rank, tol, min_size)
+    return build_preconditioner_rows(row_fn, kdiag, nz + dvec[:n].to(wd), True, rank, tol, min_size)
+
+
 class SumInvQuadLogdetFn(torch.autograd.Function):
-    """(inv_quad[c], logdet) of sum_i theta_i k_i(x_i, x_i) + noise I by mBCG + SLQ; backward: one fused bilinear derivative
-    per member with the shared left / right vectors of A.6."""
+    """(inv_quad[c], logdet) of sum_i theta_i k_i(x_i, x_i) + noise I by preconditioned mBCG + SLQ (``bbmm.inv_quad_logdet_forward`` on the
+    summed product; probe columns shardable over ``opts["group"]``); backward: one fused bilinear derivative per member with the shared
+    left / right vectors of A.6.  ``flat``: (x, lengthscale, outputscale-or-empty, shape-parameter-or-empty) per member -- RQ members
+    carry their alpha as an explicit argument all the way into the kernels (C ABI version 2), so two RQ members with different alpha
+    interleave freely."""
 
     @staticmethod
     def forward(ctx, noise, rhs, specs, dvec, opts, *flat):
-        members = [(flat[3 * i], flat[3 * i + 1], flat[3 * i + 2] if flat[3 * i + 2].numel() else None) for i in range(len(specs))]
+        nm = len(specs)
+        members = [(flat[4 * i], flat[4 * i + 1], flat[4 * i + 2] if flat[4 * i + 2].numel() else None,
+                    flat[4 * i + 3] if flat[4 * i + 3].numel() else None) for i in range(nm)]
         n = members[0][0].shape[-2]
         dev = rhs.device
         prepared = []
-        for (x, ls, os_), spec in zip(members, specs):
-            xp = B.prep_points(spec.kind, x, ls, spec.shift)
+        for (x, ls, os_, _), spec in zip(members, specs):
+            xp = _prep(spec, x, ls)
             prepared.append((xp, None if os_ is None else os_.detach().reshape(-1)[:1].to(xp.dtype).contiguous()))
         wd = prepared[0][0].dtype
-        t = opts.get("num_probes") or settings.num_trace_samples.value()
-        ld = B.round_up(n, 4)
-        probes = opts.get("probes")
-        if probes is None:
-            probes = deterministic_probe_matrix(n, t, dev, wd)
-        if probes is not None:
-            t = probes.shape[-1]
-        zt = torch.zeros(t, ld, device=dev, dtype=wd)
-        if probes is not None:
-            zt[:, :n] = probes.to(device=dev, dtype=wd).t()
-        else:
-            zt[:, :n] = torch.randint(0, 2, (t, n), device=dev, generator=opts.get("generator"), dtype=torch.int8).to(wd) * 2 - 1
-        znorm = B.coldot(zt, zt, n).sqrt()
-        zt.div_(znorm.unsqueeze(-1))
-        rhs_t = B.to_probe_major(rhs, wd)
+        opts_in = opts
+        opts = structured_opts(opts, dev)
 
         def partials(dt):
             out = None
@@ -278,41 +298,39 @@ class SumInvQuadLogdetFn(torch.autograd.Function):
             return out, 1, out.stride(0)
 
         nz = noise.detach().reshape(-1)[:1].to(wd).contiguous()
-        solves_t, info = linear_cg(None, None, nz, torch.cat([zt, rhs_t], 0).contiguous(), n_tridiag=t, tolerance=opts.get("tolerance"),
-                                   max_iter=opts.get("max_iter"), kv_partials=partials, dvec=dvec, nvec=n)
-        logdet = slq_logdet(info.t_mats, n).to(device=dev, dtype=wd)
-        c = rhs_t.shape[0]
-        inv_quad = B.coldot(solves_t[t : t + c], rhs_t, n)
-        ctx.prepared, ctx.n, ctx.t = prepared, n, t
-        ctx.solves_t, ctx.zt, ctx.znorm = solves_t, zt, znorm
+        pre = opts.get("precond", "auto")
+        if pre == "auto":
+            pre = sum_preconditioner(prepared, nz, dvec, n)
+        res = inv_quad_logdet_forward(
+            None, None, nz, B.to_probe_major(rhs, wd), num_probes=opts.get("num_probes"), precond=pre, probes=opts.get("probes"),
+            generator=opts.get("generator"), tolerance=opts.get("tolerance"), max_iter=opts.get("max_iter"), group=opts.get("group"),
+            t_total=opts.get("t_total"), dvec=dvec, kv_partials=partials, nvec=n,
+        )
+        ctx.prepared, ctx.n, ctx.res = prepared, n, res
         ctx.members = members
+        ctx.group = opts.get("group")
+        ctx.t_total = opts.get("t_total") or res.zt.shape[0]
         ctx.save_for_backward(noise, rhs)
-        opts["_last_info"] = info
-        return inv_quad.to(rhs.dtype), logdet.to(rhs.dtype)
+        opts_in["_last_info"] = res.info
+        return res.inv_quad.to(rhs.dtype), res.logdet.to(rhs.dtype)
 
     @staticmethod
     def backward(ctx, g_iq, g_ld):
         noise, rhs = ctx.saved_tensors
-        n, t = ctx.n, ctx.t
-        wd = ctx.prepared[0][0].dtype
-        c = ctx.solves_t.shape[0] - t
-        g_iq = g_iq.to(wd).reshape(c, 1)
-        g_ld = g_ld.to(wd).reshape(())
-        s_z = ctx.solves_t[:t] * ctx.znorm.unsqueeze(-1)
-        s_y = ctx.solves_t[t:]
-        zr = ctx.zt * ctx.znorm.unsqueeze(-1)
-        left = torch.cat([s_z * (g_ld / t), -s_y * g_iq], 0).contiguous()
-        right = torch.cat([zr, s_y], 0).contiguous()
+        n, res = ctx.n, ctx.res
+        left, right, s_y = backward_vectors(res, g_iq, g_ld, ctx.t_total)
+        c = s_y.shape[0]
+        wd = left.dtype
         grads = []
-        for i, ((x, ls, os_), (xp, _)) in enumerate(zip(ctx.members, ctx.prepared)):
-            need_x = ctx.needs_input_grad[5 + 3 * i]
-            if need_x:
-                d_ls, d_os, gx1, gx2 = hyper_grads(xp, xp, ls, os_, left, right, want_x1=True, want_x2=True)
-                d_x = (gx1 + gx2).to(x.dtype)
-            else:
-                d_ls, d_os = hyper_grads(xp, xp, ls, os_, left, right)
-                d_x = None
-            grads += [d_x, d_ls if ls.requires_grad else None, d_os]
+        for i, ((x, ls, os_, kpar), (xp, _)) in enumerate(zip(ctx.members, ctx.prepared)):
+            need_x = ctx.needs_input_grad[5 + 4 * i]
+            kp = kpar if (kpar is not None and ctx.needs_input_grad[5 + 4 * i + 3]) else None
+            out = hyper_grads(xp, xp, ls, os_, left, right, want_x1=need_x, want_x2=need_x, kparam=kp)
+            d_ls, d_os = out[:2]
+            d_x = (out[2] + out[3]).to(x.dtype) if need_x else None
+            d_par = out[-1] if kp is not None else None
+            grads += [d_x, d_ls if ls.requires_grad else None, d_os, d_par]
         d_noise = B.coldot(left, right, n).sum().reshape(noise.shape).to(noise.dtype)
-        d_rhs = (2.0 * B.from_probe_major(s_y, n) * g_iq.reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[1] else None
+        allreduce_grads_([d_noise] + grads, ctx.group)
+        d_rhs = (2.0 * B.from_probe_major(s_y, n) * g_iq.to(wd).reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[1] else None
         return (d_noise, d_rhs, None, None, None, *grads)

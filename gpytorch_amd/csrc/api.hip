@@ -21,7 +21,6 @@ using namespace gpamd;
 
 namespace gpamd {
 thread_local char g_err[512] = "";  // shared by every translation unit of the library (gpamd_last_error)
-thread_local float g_kparam = 1.0f;  // shape parameter of parametrised covariance families (RQ: alpha), gpamd_set_kernel_param_f32
 }
 
 namespace {
@@ -52,13 +51,13 @@ int num_cus() {
   return cus;
 }
 
-float prep_coef(int kind) {
+float prep_coef(int kind, float kparam) {
   switch (kind) {
     case GPAMD_RBF: return sqrtf(0.5f * 1.4426950408889634f);  // exp(-0.5 s) = exp2(-(0.5 log2 e) s)
     case GPAMD_MATERN12: return 1.0f;
     case GPAMD_MATERN32: return sqrtf(3.0f);
     case GPAMD_MATERN52: return sqrtf(5.0f);
-    case GPAMD_RQ: return 1.0f / sqrtf(2.0f * g_kparam);   // (1 + |x - x'|^2 / (2 alpha l^2))^-alpha = (1 + |z - z'|^2)^-alpha
+    case GPAMD_RQ: return 1.0f / sqrtf(2.0f * kparam);   // (1 + |x - x'|^2 / (2 alpha l^2))^-alpha = (1 + |z - z'|^2)^-alpha
   }
   return 0.f;
 }
@@ -295,14 +294,9 @@ extern "C" {
 
 int gpamd_abi_version(void) { return GPAMD_ABI_VERSION; }
 
-int gpamd_set_kernel_param_f32(float value) {
-  if (!(value > 0.f)) return fail(GPAMD_EINVAL, "set_kernel_param: the shape parameter must be positive");
-  g_kparam = value;
-  return 0;
-}
 const char* gpamd_last_error(void) { return g_err; }
 
-int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, const float* ls, int nls,
+int gpamd_prep_points_f32(int kind, float kparam, const float* X, int n, int d, int64_t ldx, const float* ls, int nls,
                           const float* shift, float* Xp, int dp, void* stream) {
   if (kind < 0 || kind > GPAMD_RQ) return fail(GPAMD_EINVAL, "prep_points: unknown kind");
   if (n <= 0 || d <= 0 || dp < d || dp % 4 || (nls != 1 && nls != d)) return fail(GPAMD_EINVAL, "prep_points: bad shape");
@@ -310,7 +304,7 @@ int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, c
   long total = (long)n * dp;
   unsigned grid = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL(prep_points_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, n, d, ldx, ls, nls, shift,
-                     prep_coef(kind), Xp, dp);
+                     prep_coef(kind, kparam), Xp, dp);
   return check_launch("prep_points");
 }
 
@@ -328,7 +322,7 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
   return 0;
 }
 
-int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt,
+int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt,
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream) {
   if (kind < 0 || kind > GPAMD_RQ) return fail(GPAMD_EINVAL, "kv: unknown kind");
@@ -366,7 +360,7 @@ int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, i
     a.S = S; a.jchunk = jchunk;
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
-    a.kparam = g_kparam;
+    a.kparam = kparam;
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
     const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex, v.ni);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
@@ -409,7 +403,7 @@ int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const 
   return check_launch("kv_reduce");
 }
 
-int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt, int64_t ldv,
+int gpamd_kv_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt, int64_t ldv,
                  int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
                  int64_t ldo, float* workspace, int64_t workspace_floats, int flags, void* stream) {
   int S, jc;
@@ -419,7 +413,7 @@ int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int
   const SplitLayout L = split_layout(kind, flags, m, t, S, ldp);
   if (workspace_floats < (L.total ? L.base + L.total : (int64_t)S * t * ldp))
     return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4) and the same flags)");
-  int rc = gpamd_kv_partials_f32(kind, X1p, n, X2p, m, d, Vt, ldv, t, workspace, ldp, S, jc, flags, nullptr, stream);
+  int rc = gpamd_kv_partials_f32(kind, kparam, X1p, n, X2p, m, d, Vt, ldv, t, workspace, ldp, S, jc, flags, nullptr, stream);
   if (rc) return rc;
   return gpamd_kv_reduce_f32(workspace, S, ldp, t, n, scale, dscale, nullptr, Vd, ldd, Out, ldo, nullptr, stream);
 }
@@ -434,31 +428,31 @@ int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int
     default: return fail(GPAMD_EINVAL, "unknown kind"); \
   }
 
-int gpamd_kernel_rows_f32(int kind, const float* X1p, const int64_t* rows, int nrows, const float* X2p, int m, int dp,
+int gpamd_kernel_rows_f32(int kind, float kparam, const float* X1p, const int64_t* rows, int nrows, const float* X2p, int m, int dp,
                           const float* scale, float* out, int64_t ldo, void* stream) {
   if (nrows <= 0 || m <= 0) return fail(GPAMD_EINVAL, "kernel_rows: bad shape");
   dim3 grid((m + 255) / 256, nrows);
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_rows_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, rows, nrows,
-                                       X2p, m, dp, scale, out, ldo, g_kparam));
+                                       X2p, m, dp, scale, out, ldo, kparam));
   return check_launch("kernel_rows");
 }
 
-int gpamd_kernel_dense_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* scale,
+int gpamd_kernel_dense_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int dp, const float* scale,
                            float* out, int64_t ldo, void* stream) {
   if (n <= 0 || m <= 0) return fail(GPAMD_EINVAL, "kernel_dense: bad shape");
   if (n > 65535) return fail(GPAMD_EUNSUPPORTED, "kernel_dense: n > 65535 (materialising K is what this library avoids)");
   dim3 grid((m + 255) / 256, n);
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_dense_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, n, X2p, m,
-                                       dp, scale, out, ldo, g_kparam));
+                                       dp, scale, out, ldo, kparam));
   return check_launch("kernel_dense");
 }
 
-int gpamd_kernel_diag_f32(int kind, const float* X1p, const float* X2p, int n, int dp, const float* scale, float* out,
+int gpamd_kernel_diag_f32(int kind, float kparam, const float* X1p, const float* X2p, int n, int dp, const float* scale, float* out,
                           void* stream) {
   if (n <= 0) return fail(GPAMD_EINVAL, "kernel_diag: bad shape");
   dim3 grid((n + 255) / 256);
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_diag_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, X2p, n, dp,
-                                       scale, out, g_kparam));
+                                       scale, out, kparam));
   return check_launch("kernel_diag");
 }
 
@@ -641,7 +635,7 @@ int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream) {
 }
 
 // ----------------------------------------------------------------------------- pivoted Cholesky
-int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
+int gpamd_pivoted_cholesky_f32(int kind, float kparam, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
                                float* L, int64_t ldl, int64_t* pivots, float* fwork, int* iwork, void* stream) {
   if (n <= 0 || rank <= 0 || ldl < n) return fail(GPAMD_EINVAL, "pivoted_cholesky: bad shape");
   if (rank > 128) return fail(GPAMD_EUNSUPPORTED, "pivoted_cholesky: rank > 128");
@@ -656,12 +650,12 @@ int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const f
   s.perm = iwork + 2;
   s.pos = iwork + 2 + n;
   s.tol = tol;
-  s.kparam = g_kparam;
+  s.kparam = kparam;
   (void)hipMemsetAsync(iwork, 0, 2 * sizeof(int), st);
   hipLaunchKernelGGL(pc_init_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.perm, s.pos, n);
   // diagonal of the noise-free kernel matrix: scale * k(0)
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_diag_kernel<KK>), dim3((n + 255) / 256), dim3(256), 0, st, Xp, Xp, n, dp,
-                                       scale, s.dwork, g_kparam));
+                                       scale, s.dwork, kparam));
   for (int m = 0; m < rank; ++m) {
     hipLaunchKernelGGL(pc_pivot_kernel, dim3(1), dim3(1024), 0, st, s, m);
     KIND_SWITCH(kind, hipLaunchKernelGGL((pc_update_kernel<KK>), dim3((n + 255) / 256), dim3(256), 0, st, s, m, Xp, dp,

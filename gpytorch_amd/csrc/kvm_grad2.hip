@@ -13,7 +13,6 @@
 using namespace gpamd;
 namespace gpamd {
 extern thread_local char g_err[512];
-extern thread_local float g_kparam;
 }
 
 namespace {
@@ -133,7 +132,7 @@ int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d) {
   return (int64_t)g2_groups(t) * S * dp * ((n + 3) / 4 * 4);
 }
 
-int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Lt, int64_t ldl,
+int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Lt, int64_t ldl,
                        const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
                        int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, void* stream) {
   if (n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m || d < 1 || d > 16) {
@@ -168,7 +167,7 @@ int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int 
     a.th4 = ((tg + 1) / 2 + 3) / 4 * 4;
     a.rs = 2 * a.th4 + 4;   // = 4 * odd: eight lanes' 16-byte reads at this row stride cover all 32 banks exactly once
     a.part = workspace + (int64_t)g * units * (2 + dp);
-    a.kparam = gpamd::g_kparam;
+    a.kparam = kparam;
     a.Px = Gz1t ? xworkspace + (int64_t)g * S * dp * ldx : nullptr;
     a.ldx = ldx;
     a.pxstride = (int64_t)dp * ldx;

@@ -17,11 +17,11 @@ import torch
 
 from . import backend as B
 from . import settings
-from .bbmm import deterministic_probe_matrix, slq_logdet
-from .functions import KernelSpec, hyper_grads
+from .bbmm import allreduce_grads_, backward_vectors, build_preconditioner_rows, inv_quad_logdet_forward, structured_opts
+from .functions import KernelSpec, _prep, hyper_grads
 from .lanczos import root_inv_decomposition
 from .linear_cg import linear_cg
-from .operators import ConstantDiagLinearOperator, DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator
+from .operators import ConstantDiagLinearOperator, DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, split_diag
 
 
 class IndexedTaskCovar(LinearOperator):
@@ -127,10 +127,9 @@ class HadamardFusedLinearOperator(LinearOperator):
         return HadamardFusedLinearOperator(self.kx.detach(), self.tasks.detach())
 
     def __add__(self, other):
-        if isinstance(other, ConstantDiagLinearOperator) and self.is_square and not other.batch_shape:
-            return HadamardFusedAddedDiagLinearOperator(self, other.diag_values)
         if isinstance(other, DiagLinearOperator) and self.is_square and not other.batch_shape:
-            return HadamardFusedAddedDiagLinearOperator(self, torch.zeros(1, device=self.device, dtype=self.dtype), noise_vec=other._diag)
+            noise, vec = split_diag(other, self.device, self.dtype)
+            return HadamardFusedAddedDiagLinearOperator(self, noise, noise_vec=vec)
         return super().__add__(other)
 
 
@@ -173,11 +172,10 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
         return HadamardFusedAddedDiagLinearOperator(self.had.detach(), self.noise.detach(), self.noise_vec, self.bbmm_opts)
 
     def __add__(self, other):
-        if isinstance(other, ConstantDiagLinearOperator) and not other.batch_shape:
-            return HadamardFusedAddedDiagLinearOperator(self.had, self.noise + other.diag_values.reshape(-1)[:1], self.noise_vec, self.bbmm_opts)
         if isinstance(other, DiagLinearOperator) and not other.batch_shape:
-            nv = other._diag if self.noise_vec is None else self.noise_vec + other._diag
-            return HadamardFusedAddedDiagLinearOperator(self.had, self.noise, nv, self.bbmm_opts)
+            noise, vec = split_diag(other, self.device, self.dtype)
+            nv = self.noise_vec if vec is None else (vec if self.noise_vec is None else self.noise_vec + vec)
+            return HadamardFusedAddedDiagLinearOperator(self.had, self.noise + noise, nv, self.bbmm_opts)
         return super().__add__(other)
 
     def _use_cholesky(self, flag):
@@ -217,7 +215,7 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
             wd = B.work_dtype(kx.x1)
             nvec = None if self.noise_vec is None else self.noise_vec.detach().to(wd)
             iq, ld = HadamardInvQuadLogdetFn.apply(kx.x1, kx.lengthscale, kx.outputscale, self.had.tasks.ktt, self.noise, rhs, kx.spec,
-                                                   self.had.tasks.i1, nvec, self.bbmm_opts)
+                                                   self.had.tasks.i1, nvec, self.bbmm_opts, kx.spec.param)
             if drop:
                 iq = iq[:0]
         if reduce_inv_quad:
@@ -231,8 +229,12 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
             sol = torch.cholesky_solve(r.detach().to(torch.float64), torch.linalg.cholesky(self.to_dense().detach().to(torch.float64))).to(rhs.dtype)
         else:
             partials, wd = self._partials()
+            dv = self._dvec(wd)
+            if not hasattr(self, "_precond_cache"):
+                p1, _ = self.had.kx.prepared()
+                self._precond_cache = hadamard_preconditioner(p1, self.had.kx._os(), self.had.tasks.ktt, self.had.tasks.i1, dv, self.shape[-1])
             sol_t, _ = linear_cg(None, None, None, B.to_probe_major(r.detach(), wd), n_tridiag=0, tolerance=settings.cg_tolerance.value(),
-                                 kv_partials=partials, dvec=self._dvec(wd), nvec=self.shape[-1])
+                                 kv_partials=partials, dvec=dv, nvec=self.shape[-1], preconditioner=self._precond_cache)
             sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
         if lhs is not None:
             sol = lhs @ sol
@@ -253,32 +255,40 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
         return RootLinearOperator(B.from_probe_major(rt, n).to(self.dtype))
 
 
+def hadamard_preconditioner(xp, os_, ktt, ti, diag_total, n, rank=None, tol=None, min_size=None):
+    """Pivoted-Cholesky preconditioner of (theta k(x, x)) o K_TT[ti, ti] + diag: row p is the data-kernel row of point p
+    (``gpamd_kernel_rows_f32``) times K_TT[task_p, task_.] (the reference preconditions the product operator + diagonal like any other
+    ``AddedDiagLinearOperator``: ``kernels/index_kernel.py:101-112`` + ``settings.py:6-31``)."""
+    if not xp.fused:
+        return None
+    wd = xp.dtype
+    ktt_d = ktt.detach().to(wd)
+
+    def row_fn(p):
+        return B.kernel_rows(xp, p, xp, os_).reshape(-1) * ktt_d[ti[p]].reshape(-1)[ti]
+
+    kdiag = B.kernel_diag(xp, xp, os_) * ktt_d[ti, ti]
+    d = diag_total.detach()[:n].to(wd)
+    if bool((d == d[0]).all()):
+        return build_preconditioner_rows(row_fn, kdiag, d[:1], False, rank, tol, min_size)
+    return build_preconditioner_rows(row_fn, kdiag, d, True, rank, tol, min_size)
+
+
 class HadamardInvQuadLogdetFn(torch.autograd.Function):
-    """(inv_quad[c], logdet) of (theta k(x, x)) o K_TT[ti, ti] + noise I (+ diag(noise_vec)) by mBCG + SLQ."""
+    """(inv_quad[c], logdet) of (theta k(x, x)) o K_TT[ti, ti] + noise I (+ diag(noise_vec)) by preconditioned mBCG + SLQ
+    (``bbmm.inv_quad_logdet_forward`` on the masked-column product; probe columns shardable over ``opts["group"]``)."""
 
     @staticmethod
-    def forward(ctx, x, lengthscale, outputscale, ktt, noise, rhs, spec: KernelSpec, ti, noise_vec, opts):
+    def forward(ctx, x, lengthscale, outputscale, ktt, noise, rhs, spec: KernelSpec, ti, noise_vec, opts, kparam=None):
         n, T = x.shape[-2], ktt.shape[-1]
         dev = x.device
-        xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
+        xp = _prep(spec, x, lengthscale)
         wd = xp.dtype
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(wd).contiguous()
         ktt_d = ktt.detach().to(wd)
-        t = opts.get("num_probes") or settings.num_trace_samples.value()
+        opts_in = opts
+        opts = structured_opts(opts, dev)
         ld = B.round_up(n, 4)
-        probes = opts.get("probes")
-        if probes is None:
-            probes = deterministic_probe_matrix(n, t, dev, wd)
-        if probes is not None:
-            t = probes.shape[-1]
-        zt = torch.zeros(t, ld, device=dev, dtype=wd)
-        if probes is not None:
-            zt[:, :n] = probes.to(device=dev, dtype=wd).t()
-        else:
-            zt[:, :n] = torch.randint(0, 2, (t, n), device=dev, generator=opts.get("generator"), dtype=torch.int8).to(wd) * 2 - 1
-        znorm = B.coldot(zt, zt, n).sqrt()
-        zt.div_(znorm.unsqueeze(-1))
-        rhs_t = B.to_probe_major(rhs, wd)
         dv = torch.zeros(ld, device=dev, dtype=wd)
         dv[:n] = noise.detach().reshape(()).to(wd)
         if noise_vec is not None:
@@ -288,33 +298,33 @@ class HadamardInvQuadLogdetFn(torch.autograd.Function):
             out = hadamard_matvec(xp, xp, os_, ktt_d, ti, ti, dt)
             return out, 1, out.stride(0)
 
-        solves_t, info = linear_cg(None, None, None, torch.cat([zt, rhs_t], 0).contiguous(), n_tridiag=t, tolerance=opts.get("tolerance"),
-                                   max_iter=opts.get("max_iter"), kv_partials=partials, dvec=dv, nvec=n)
-        logdet = slq_logdet(info.t_mats, n).to(device=dev, dtype=wd)
-        c = rhs_t.shape[0]
-        inv_quad = B.coldot(solves_t[t : t + c], rhs_t, n)
-        ctx.xp, ctx.n, ctx.T, ctx.t, ctx.ti = xp, n, T, t, ti
-        ctx.solves_t, ctx.zt, ctx.znorm = solves_t, zt, znorm
+        pre = opts.get("precond", "auto")
+        if pre == "auto":
+            pre = hadamard_preconditioner(xp, os_, ktt_d, ti, dv, n)
+        res = inv_quad_logdet_forward(
+            None, None, None, B.to_probe_major(rhs, wd), num_probes=opts.get("num_probes"), precond=pre, probes=opts.get("probes"),
+            generator=opts.get("generator"), tolerance=opts.get("tolerance"), max_iter=opts.get("max_iter"), group=opts.get("group"),
+            t_total=opts.get("t_total"), dvec=dv, kv_partials=partials, nvec=n,
+        )
+        ctx.xp, ctx.n, ctx.T, ctx.ti, ctx.res = xp, n, T, ti, res
+        ctx.kparam = kparam
+        ctx.group = opts.get("group")
+        ctx.t_total = opts.get("t_total") or res.zt.shape[0]
         ctx.has_os = outputscale is not None
         ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0), ktt, noise, rhs)
-        opts["_last_info"] = info
-        return inv_quad.to(rhs.dtype), logdet.to(rhs.dtype)
+        opts_in["_last_info"] = res.info
+        return res.inv_quad.to(rhs.dtype), res.logdet.to(rhs.dtype)
 
     @staticmethod
     def backward(ctx, g_iq, g_ld):
         lengthscale, outputscale, ktt, noise, rhs = ctx.saved_tensors
         outputscale = outputscale if ctx.has_os else None
-        xp, n, T, t, ti = ctx.xp, ctx.n, ctx.T, ctx.t, ctx.ti
+        xp, n, T, ti, res = ctx.xp, ctx.n, ctx.T, ctx.ti, ctx.res
         wd = xp.dtype
-        c = ctx.solves_t.shape[0] - t
-        tc = t + c
-        g_iq = g_iq.to(wd).reshape(c, 1)
-        g_ld = g_ld.to(wd).reshape(())
-        s_z = ctx.solves_t[:t] * ctx.znorm.unsqueeze(-1)
-        s_y = ctx.solves_t[t:]
-        zr = ctx.zt * ctx.znorm.unsqueeze(-1)
-        left = torch.cat([s_z * (g_ld / t), -s_y * g_iq], 0)[:, :n]
-        right = torch.cat([zr, s_y], 0)[:, :n]
+        left, right, s_y = backward_vectors(res, g_iq, g_ld, ctx.t_total)
+        c = s_y.shape[0]
+        tc = left.shape[0]
+        left, right = left[:, :n], right[:, :n]
         ktt_d = ktt.detach().to(wd)
         mask = torch.nn.functional.one_hot(ti, T).t().to(wd)            # [T, n]
         ld = B.round_up(n, 4)
@@ -326,11 +336,15 @@ class HadamardInvQuadLogdetFn(torch.autograd.Function):
 
         l_m = left[:, None, :] * mask[None]                             # L_c o 1[task = tau]
         r_b = right[:, None, :] * ktt_d[:, ti][None]                    # R_c[j] * K_TT[tau, task_j]
-        d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, pad(l_m), pad(r_b))
+        kp = ctx.kparam if (ctx.kparam is not None and ctx.needs_input_grad[10]) else None
+        out = hyper_grads(xp, xp, lengthscale, outputscale, pad(l_m), pad(r_b), kparam=kp)
+        d_ls, d_os = out[:2]
+        d_par = out[-1] if kp is not None else None
         # d/dK_TT[tau, tau'] = sum_c (L_c o 1[tau])^T (theta K) (R_c o 1[tau'])
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(wd).contiguous()
         mq = B.kv(xp, xp, pad(right[:, None, :] * mask[None]), scale=os_)[:, :n].reshape(tc, T, n)
         d_ktt = torch.einsum("cti,csi->ts", l_m, mq).to(ktt.dtype)
         d_noise = (left * right).sum().reshape(noise.shape).to(noise.dtype)
-        d_rhs = (2.0 * B.from_probe_major(s_y, n) * g_iq.reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[5] else None
-        return None, d_ls, d_os, d_ktt, d_noise, d_rhs, None, None, None, None
+        allreduce_grads_([d_ls, d_os, d_ktt, d_noise, d_par], ctx.group)
+        d_rhs = (2.0 * B.from_probe_major(s_y, n) * g_iq.to(wd).reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[5] else None
+        return None, d_ls, d_os, d_ktt, d_noise, d_rhs, None, None, None, None, d_par

@@ -11,7 +11,7 @@ from . import settings
 from .distributions import MultivariateNormal
 from .linear_cg import NumericalWarning
 from .module import GreaterThan, Module
-from .operators import ConstantDiagLinearOperator, DiagLinearOperator, ZeroLinearOperator
+from .operators import ConstantDiagLinearOperator, DiagLinearOperator, FixedPlusConstantDiagLinearOperator, ZeroLinearOperator
 
 
 class GPInputWarning(UserWarning):
@@ -157,4 +157,9 @@ def _add_diags(a, b):
     """Sum of two diagonal operators as ONE diagonal operator (so the fused K + D path still applies)."""
     if isinstance(a, ConstantDiagLinearOperator) and isinstance(b, ConstantDiagLinearOperator):
         return ConstantDiagLinearOperator(a.diag_values.reshape(-1)[:1] + b.diag_values.reshape(-1)[:1], a.diag_shape)
+    # fixed vector + learned scalar: kept apart so that the scalar stays on the autograd path of the fused operators
+    if isinstance(b, ConstantDiagLinearOperator) and not b.batch_shape and a._diag.dim() == 1:
+        return FixedPlusConstantDiagLinearOperator(a._diag, b.diag_values)
+    if isinstance(a, ConstantDiagLinearOperator) and not a.batch_shape and b._diag.dim() == 1:
+        return FixedPlusConstantDiagLinearOperator(b._diag, a.diag_values)
     return DiagLinearOperator(a._diag + b._diag)

@@ -83,14 +83,25 @@ class Preconditioner:
 
     ``q1t``: [k, ld] (rows = columns of Q1), ``sigma2``: 1-element device tensor."""
 
-    def __init__(self, q1t: torch.Tensor, sigma2: torch.Tensor, logdet: torch.Tensor, lt: torch.Tensor, reduce=None):
+    def __init__(self, q1t: torch.Tensor, sigma2: torch.Tensor, logdet: torch.Tensor, lt: torch.Tensor, reduce=None, dinv_sqrt=None):
         self.q1t, self.sigma2, self.logdet, self.lt = q1t, sigma2, logdet, lt
         self.reduce = reduce  # row-sharded: in-place sum over ranks of the k x t coefficients R Q1
+        # NON-constant diagonal D (fixed heteroskedastic noise, per-task noise of a multitask likelihood; the reference's
+        # ``_init_cache_for_non_constant_diag``): P = L L^T + D = D^1/2 (Lt Lt^T + I) D^1/2 with Lt = D^-1/2 L, so Q1 is the thin-QR
+        # factor of [Lt; I], ``sigma2`` is 1 and the apply is D^-1/2 (I - Q1 Q1^T) D^-1/2.  ``dinv_sqrt``: [ld] (zeros beyond n), or None.
+        self.dinv_sqrt = dinv_sqrt
+
+    def noise_sqrt(self, n: int, dtype):
+        """sqrt of the diagonal part of P as something that broadcasts against [t, n] (probe sampling z = L e1 + D^1/2 e2)."""
+        if self.dinv_sqrt is None:
+            return self.sigma2.to(dtype).sqrt()
+        return (1.0 / self.dinv_sqrt[:n]).to(dtype).unsqueeze(0)
 
     def row_sharded(self, row_shard) -> "Preconditioner":
         """The same preconditioner acting on vectors of which every rank holds a block of rows: Q1 is sliced to the local
         rows and the k x t inner products R Q1 are all-reduced per apply (k <= 128, t small: a few KB over xGMI)."""
-        return Preconditioner(row_shard.local(self.q1t), self.sigma2, self.logdet, row_shard.local(self.lt), reduce=row_shard.allreduce)
+        di = None if self.dinv_sqrt is None else row_shard.local(self.dinv_sqrt.unsqueeze(0))[0]
+        return Preconditioner(row_shard.local(self.q1t), self.sigma2, self.logdet, row_shard.local(self.lt), reduce=row_shard.allreduce, dinv_sqrt=di)
 
     def apply_(self, rt: torch.Tensor, out: torch.Tensor):
         """out = (R - (R Q1) Q1^T) / s2 in probe-major form (rows are vectors), evaluated in FLOAT64 whatever the dtype of the
@@ -99,6 +110,14 @@ class Preconditioner:
         stall at a relative residual of 4 after 2000 iterations (profiles/r02_s5_posterior_profile_precond_fp32_stalls.json).
         Cost: two kernels per CG iteration (the k x t coefficients, then the fused subtraction / division), < 1 ms against a
         >= 19 ms K*V at n = 5e5 and ~25 us at n = 2000 (the four torch float64 operations they replaced took 280 us there)."""
+        if self.dinv_sqrt is not None:
+            di = self.dinv_sqrt[: rt.shape[1]].to(rt.dtype).unsqueeze(0)
+            self._apply_core(rt * di, out)
+            out[:, : di.shape[1]].mul_(di)
+            return out
+        return self._apply_core(rt, out)
+
+    def _apply_core(self, rt: torch.Tensor, out: torch.Tensor):
         q1t = self.q1t if self.q1t.dtype == torch.float64 else self.q1t.to(torch.float64)
         k = q1t.shape[0]
         fast = rt.dtype == torch.float32 and rt.is_cuda and k <= 128 and rt.stride(1) == 1 and q1t.stride(1) == 1
@@ -259,7 +278,7 @@ def linear_cg(
             flags = B.kv_flags(x, x, t)
             S, jc, wsn = B.kv_plan(x.kind, n, n, x.d, t, flags, ld)
             P = B.workspace(dev, wsn)
-            kind_id = B.kind_id(x)
+            kind_args = B.kind_args(x)
         ldp = ld
         min_iter = min(10, max_iter - 1)
         tri_floor = min(n_tri_iter, max_iter - 1) if n_tridiag else 0
@@ -286,7 +305,7 @@ def linear_cg(
             if kv_partials is None:
                 check(
                     L.gpamd_kv_partials_f32(
-                        kind_id, B._ptr(x.xp), n, B._ptr(x.xp), n, x.d, B._ptr(Dt), ld, t, B._ptr(P), ld, S, jc,
+                        *kind_args, B._ptr(x.xp), n, B._ptr(x.xp), n, x.d, B._ptr(Dt), ld, t, B._ptr(P), ld, S, jc,
                         flags, done_ptr, st,
                     ),
                     "kv_partials",

@@ -18,9 +18,9 @@ import torch
 
 from . import backend as B
 from . import settings
-from .bbmm import deterministic_probe_matrix, slq_logdet
+from .bbmm import allreduce_grads_, backward_vectors, build_preconditioner_rows, inv_quad_logdet_forward, structured_opts
 from .distributions import MultivariateNormal
-from .functions import KernelSpec, hyper_grads
+from .functions import KernelSpec, _prep, hyper_grads
 from .kernels import Kernel
 from .lanczos import root_inv_decomposition
 from .likelihoods import _GaussianLikelihoodBase
@@ -165,6 +165,13 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
     def _use_cholesky(self, flag):
         return flag.off() or self.shape[-1] <= settings.max_cholesky_size.value()
 
+    def _precond(self):
+        """The pivoted-Cholesky preconditioner of this operator (``kron_preconditioner``), built once per operator."""
+        if "precond" not in self._cache:
+            p1, _ = self.kron.kx.prepared()
+            self._cache["precond"] = kron_preconditioner(p1, self.kron.kx._os(), self.kron.ktt, self.task_noise) if p1.fused else None
+        return self._cache["precond"]
+
     def _cg(self, rhs_t, n_tridiag=0, tolerance=None):
         p1, _ = self.kron.kx.prepared()
         ktt, os_ = self.kron.ktt.detach(), self.kron.kx._os()
@@ -175,7 +182,7 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
             return out, 1, out.stride(0)
 
         return linear_cg(None, None, None, rhs_t, n_tridiag=n_tridiag, tolerance=tolerance, kv_partials=partials,
-                         dvec=self._dvec(), nvec=N, group=self.bbmm_opts.get("group"))
+                         dvec=self._dvec(), nvec=N, group=self.bbmm_opts.get("group"), preconditioner=self._precond())
 
     def solve(self, rhs, lhs=None):
         squeeze = rhs.dim() == 1
@@ -202,7 +209,7 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
             ld = (2.0 * Lc.diagonal().log().sum()).to(rhs.dtype)
         else:
             iq, ld = KroneckerInvQuadLogdetFn.apply(kx.x1, kx.lengthscale, kx.outputscale, self.kron.ktt, self.task_noise, rhs,
-                                                    kx.spec, self.bbmm_opts)
+                                                    kx.spec, self.bbmm_opts, kx.spec.param)
         if reduce_inv_quad:
             iq = iq.sum(-1)
         _ = N
@@ -215,6 +222,9 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
         d2 = (z1.unsqueeze(-2) - z1.unsqueeze(-3)).pow(2).sum(-1)
         if kx.spec.kind == "rbf":
             kmat = torch.exp(-0.5 * d2)
+        elif kx.spec.kind == "rq":
+            alpha = kx.spec.param.reshape(())
+            kmat = (1 + d2 / (2 * alpha)).pow(-alpha)
         else:
             nu = {"matern12": 0.5, "matern32": 1.5, "matern52": 2.5}[kx.spec.kind]
             r = (d2 + 1e-20).sqrt() * (2 * nu) ** 0.5
@@ -238,34 +248,47 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
         return RootLinearOperator(B.from_probe_major(rt, N).to(self.dtype))
 
 
+def kron_preconditioner(xp, os_, ktt, task_noise, rank=None, tol=None, min_size=None):
+    """Pivoted-Cholesky preconditioner of K_XX (x) K_TT + I (x) diag(task_noise) (the reference preconditions this operator like any
+    other ``AddedDiagLinearOperator``: ``kernels/multitask_kernel.py:46-54`` + ``settings.py:6-31``).  Row (i, tau) of the Kronecker
+    product is theta k(x_i, .) (x) K_TT[tau, :] -- one ``gpamd_kernel_rows_f32`` row per step; the per-task noise makes the diagonal
+    non-constant unless all task noises agree (``Preconditioner.dinv_sqrt``)."""
+    n, T = xp.n, ktt.shape[-1]
+    wd = xp.dtype
+    ktt_d = ktt.detach().to(wd)
+    theta = 1.0 if os_ is None else os_.reshape(())
+
+    def row_fn(p):
+        i, tau = torch.div(p, T, rounding_mode="floor"), p % T
+        kr = B.kernel_rows(xp, i, xp, os_).reshape(n, 1)             # theta k(x_i, x_j), j = 0..n-1
+        return (kr * ktt_d[tau].reshape(1, T)).reshape(-1)           # interleaved (j T + tau')
+
+    kdiag = (B.kernel_diag(xp, xp, os_).reshape(n, 1) * ktt_d.diagonal().reshape(1, T)).reshape(-1)
+    _ = theta
+    tn = task_noise.detach().to(wd).reshape(-1)
+    if bool((tn == tn[0]).all()):
+        return build_preconditioner_rows(row_fn, kdiag, tn[:1], False, rank, tol, min_size)
+    return build_preconditioner_rows(row_fn, kdiag, tn.repeat(n), True, rank, tol, min_size)
+
+
 class KroneckerInvQuadLogdetFn(torch.autograd.Function):
-    """inv_quad / log-det of K_XX (x) K_TT + I (x) diag(task_noise) by mBCG + SLQ, with the A.6 backward
-    specialised to the Kronecker structure (one fused bilinear-derivative launch + one fused K*V launch)."""
+    """inv_quad / log-det of K_XX (x) K_TT + I (x) diag(task_noise) by preconditioned mBCG + SLQ (``bbmm.inv_quad_logdet_forward`` on
+    the Kronecker product -- probe columns sharded over ``opts["group"]`` exactly like the single-kernel operator: BASELINE C5,
+    "batched CG over task blocks, 4 x MI355X"), with the A.6 backward specialised to the Kronecker structure (one fused
+    bilinear-derivative launch + one fused K*V launch; gradients summed over the probe group in one packed all-reduce)."""
 
     @staticmethod
-    def forward(ctx, x, lengthscale, outputscale, ktt, task_noise, rhs, spec: KernelSpec, opts: dict):
+    def forward(ctx, x, lengthscale, outputscale, ktt, task_noise, rhs, spec: KernelSpec, opts: dict, kparam=None):
         n, T = x.shape[-2], ktt.shape[-1]
         N = n * T
         dev = x.device
-        xp = B.prep_points(spec.kind, x, lengthscale, spec.shift)
+        xp = _prep(spec, x, lengthscale)
         wd = xp.dtype
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(wd).contiguous()
         ktt_d = ktt.detach().to(wd)
-        t = opts.get("num_probes") or settings.num_trace_samples.value()
+        opts_in = opts
+        opts = structured_opts(opts, dev)
         ld = B.round_up(N, 4)
-        zt = torch.zeros(t, ld, device=dev, dtype=wd)
-        probes = opts.get("probes")
-        if probes is None:
-            probes = deterministic_probe_matrix(N, t, dev, wd)
-        if probes is not None:
-            t = probes.shape[-1]
-            zt = torch.zeros(t, ld, device=dev, dtype=wd)
-            zt[:, :N] = probes.to(device=dev, dtype=wd).t()
-        else:
-            zt[:, :N] = torch.randint(0, 2, (t, N), device=dev, generator=opts.get("generator"), dtype=torch.int8).to(wd) * 2 - 1
-        znorm = B.coldot(zt, zt, N).sqrt()
-        zt.div_(znorm.unsqueeze(-1))
-        rhs_t = B.to_probe_major(rhs, wd)
         dv = torch.zeros(ld, device=dev, dtype=wd)
         dv[:N] = task_noise.detach().to(wd).repeat(n)
 
@@ -273,34 +296,33 @@ class KroneckerInvQuadLogdetFn(torch.autograd.Function):
             out = kron_matvec(xp, xp, ktt_d, dt, os_)
             return out, 1, out.stride(0)
 
-        solves_t, info = linear_cg(None, None, None, torch.cat([zt, rhs_t], 0).contiguous(), n_tridiag=t, tolerance=opts.get("tolerance"),
-                                   kv_partials=partials, dvec=dv, nvec=N)
-        logdet = slq_logdet(info.t_mats, N).to(device=dev, dtype=wd)
-        c = rhs_t.shape[0]
-        inv_quad = B.coldot(solves_t[t : t + c], rhs_t, N)
-        ctx.xp, ctx.n, ctx.T, ctx.t = xp, n, T, t
-        ctx.solves_t, ctx.zt, ctx.znorm = solves_t, zt, znorm
+        pre = opts.get("precond", "auto")
+        if pre == "auto":
+            pre = kron_preconditioner(xp, os_, ktt_d, task_noise)
+        res = inv_quad_logdet_forward(
+            None, None, None, B.to_probe_major(rhs, wd), num_probes=opts.get("num_probes"), precond=pre, probes=opts.get("probes"),
+            generator=opts.get("generator"), tolerance=opts.get("tolerance"), max_iter=opts.get("max_iter"), group=opts.get("group"),
+            t_total=opts.get("t_total"), dvec=dv, kv_partials=partials, nvec=N,
+        )
+        ctx.xp, ctx.n, ctx.T, ctx.res = xp, n, T, res
+        ctx.kparam = kparam
+        ctx.group = opts.get("group")
+        ctx.t_total = opts.get("t_total") or res.zt.shape[0]
         ctx.has_os = outputscale is not None
         ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0), ktt, task_noise, rhs)
-        opts["_last_info"] = info
-        return inv_quad.to(rhs.dtype), logdet.to(rhs.dtype)
+        opts_in["_last_info"] = res.info
+        return res.inv_quad.to(rhs.dtype), res.logdet.to(rhs.dtype)
 
     @staticmethod
     def backward(ctx, g_iq, g_ld):
         lengthscale, outputscale, ktt, task_noise, rhs = ctx.saved_tensors
         outputscale = outputscale if ctx.has_os else None
-        xp, n, T, t = ctx.xp, ctx.n, ctx.T, ctx.t
+        xp, n, T, res = ctx.xp, ctx.n, ctx.T, ctx.res
         N = n * T
-        c = ctx.solves_t.shape[0] - t
         wd = xp.dtype
-        g_iq = g_iq.to(wd).reshape(c, 1)
-        g_ld = g_ld.to(wd).reshape(())
-        s_z = ctx.solves_t[:t] * ctx.znorm.unsqueeze(-1)
-        s_y = ctx.solves_t[t:]
-        zr = ctx.zt * ctx.znorm.unsqueeze(-1)
-        left = torch.cat([s_z * (g_ld / t), -s_y * g_iq], 0)
-        right = torch.cat([zr, s_y], 0)
-        tc = t + c
+        left, right, s_y = backward_vectors(res, g_iq, g_ld, ctx.t_total)
+        c = s_y.shape[0]
+        tc = left.shape[0]
         l3 = left[:, :N].reshape(tc, n, T).permute(0, 2, 1).contiguous()   # [tc, T, n]
         r3 = right[:, :N].reshape(tc, n, T).permute(0, 2, 1).contiguous()
         ktt32 = ktt.detach().to(wd)
@@ -313,13 +335,17 @@ class KroneckerInvQuadLogdetFn(torch.autograd.Function):
             return out
 
         lp = pad(l3)
-        d_ls, d_os = hyper_grads(xp, xp, lengthscale, outputscale, lp, pad(r3k))
+        kp = ctx.kparam if (ctx.kparam is not None and ctx.needs_input_grad[8]) else None
+        out = hyper_grads(xp, xp, lengthscale, outputscale, lp, pad(r3k), kparam=kp)
+        d_ls, d_os = out[:2]
+        d_par = out[-1] if kp is not None else None
         os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(wd).contiguous()
         m3 = B.kv(xp, xp, pad(r3), scale=os_)[:, :n].reshape(tc, T, n)
         d_ktt = torch.einsum("ctn,csn->ts", l3, m3).to(ktt.dtype)
         d_noise = (l3 * r3).sum(dim=(0, 2)).to(task_noise.dtype)
-        d_rhs = (2.0 * B.from_probe_major(s_y, N) * g_iq.reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[5] else None
-        return None, d_ls, d_os, d_ktt, d_noise, d_rhs, None, None
+        allreduce_grads_([d_ls, d_os, d_ktt, d_noise, d_par], ctx.group)
+        d_rhs = (2.0 * B.from_probe_major(s_y, N) * g_iq.to(wd).reshape(1, c)).to(rhs.dtype) if ctx.needs_input_grad[5] else None
+        return None, d_ls, d_os, d_ktt, d_noise, d_rhs, None, None, d_par
 
 
 # ------------------------------------------------------------------------------------------------ modules

@@ -331,6 +331,32 @@ class ConstantDiagLinearOperator(DiagLinearOperator):
         return self.diag_values.shape[:-1]
 
 
+class FixedPlusConstantDiagLinearOperator(DiagLinearOperator):
+    """diag(fixed) + c I with the two parts kept APART: the fixed per-point noise of ``FixedNoiseGaussianLikelihood`` plus its learned
+    ``second_noise`` (``gaussian_likelihood.py:337-352``).  Folding them into one vector would cut the autograd path to the learned scalar
+    (the fused operators carry the vector as a non-learnable epilogue diagonal and differentiate the scalar)."""
+
+    def __init__(self, fixed: torch.Tensor, const: torch.Tensor):
+        self.fixed = fixed
+        self.const = const.reshape(-1)[:1]
+
+    @property
+    def _diag(self):
+        return self.fixed + self.const
+
+
+def split_diag(other: DiagLinearOperator, device, dtype):
+    """(scalar noise [1] -- the differentiable part --, fixed per-point vector or None) of a diagonal operator added to a kernel operator."""
+    if isinstance(other, FixedPlusConstantDiagLinearOperator):
+        return other.const, other.fixed
+    if isinstance(other, ConstantDiagLinearOperator):
+        return other.diag_values.reshape(-1)[:1], None
+    d = other._diag
+    if d.numel() > 0 and bool((d == d.reshape(-1)[0]).all()):
+        return d.reshape(-1)[:1], None
+    return torch.zeros(1, device=device, dtype=dtype), d
+
+
 class RootLinearOperator(LinearOperator):
     def __init__(self, root: torch.Tensor):
         self.root = root
@@ -502,14 +528,11 @@ class FusedKernelLinearOperator(LinearOperator):
     def __add__(self, other):
         if isinstance(other, DiagLinearOperator) and other.batch_shape:
             return BatchLinearOperator.replicate(self, other.batch_shape) + other
-        if isinstance(other, ConstantDiagLinearOperator) and self.is_square:
-            return FusedKernelAddedDiagLinearOperator(self, other.diag_values)
         if isinstance(other, DiagLinearOperator) and self.is_square:
-            if bool((other._diag == other._diag[0]).all()):
-                return FusedKernelAddedDiagLinearOperator(self, other._diag[:1])
-            # heteroskedastic fixed noise (FixedNoiseGaussianLikelihood): rides in the fused epilogue as a vector
-            zero = torch.zeros(1, device=self.device, dtype=self.dtype)
-            return FusedKernelAddedDiagLinearOperator(self, zero, noise_vec=other._diag)
+            # heteroskedastic fixed noise (FixedNoiseGaussianLikelihood) rides in the fused epilogue as a vector; the scalar part
+            # (homoskedastic noise, or the learned second noise) stays a differentiable scalar
+            noise, vec = split_diag(other, self.device, self.dtype)
+            return FusedKernelAddedDiagLinearOperator(self, noise, noise_vec=vec)
         return super().__add__(other)
 
     def detach(self):
@@ -610,12 +633,10 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         return K if self.noise_vec is None else K + torch.diag(self.noise_vec.to(K.dtype))
 
     def __add__(self, other):
-        if isinstance(other, ConstantDiagLinearOperator):
-            return FusedKernelAddedDiagLinearOperator(self.kernel_op, self.noise + other.diag_values.reshape(-1)[:1], self.bbmm_opts,
-                                                      self.noise_vec)
-        if isinstance(other, DiagLinearOperator):
-            nv = other._diag if self.noise_vec is None else self.noise_vec + other._diag
-            return FusedKernelAddedDiagLinearOperator(self.kernel_op, self.noise, self.bbmm_opts, nv)
+        if isinstance(other, DiagLinearOperator) and not other.batch_shape:
+            noise, vec = split_diag(other, self.device, self.dtype)
+            nv = self.noise_vec if vec is None else (vec if self.noise_vec is None else self.noise_vec + vec)
+            return FusedKernelAddedDiagLinearOperator(self.kernel_op, self.noise + noise, self.bbmm_opts, nv)
         return super().__add__(other)
 
     def detach(self):
@@ -680,7 +701,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
 
         if "precond" not in self._cache:
             p1, _ = self.kernel_op.prepared()
-            self._cache["precond"] = None if self.noise_vec is not None else build_preconditioner(p1, self.kernel_op._os(), self._nz())
+            self._cache["precond"] = build_preconditioner(p1, self.kernel_op._os(), self._nz(), dvec=self._dvec())
         pre = self._cache["precond"]
         if pre is None:
             return None, None, None
@@ -712,7 +733,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         else:
             p1, _ = self.kernel_op.prepared()
             if "precond" not in self._cache:
-                self._cache["precond"] = None if self.noise_vec is not None else build_preconditioner(p1, self.kernel_op._os(), self._nz())
+                self._cache["precond"] = build_preconditioner(p1, self.kernel_op._os(), self._nz(), dvec=self._dvec())
             sol_t, info = linear_cg(
                 p1, self.kernel_op._os(), self._nz(), B.to_probe_major(r.detach(), p1.dtype), n_tridiag=0,
                 tolerance=settings.cg_tolerance.value(), preconditioner=self._cache["precond"], dvec=self._dvec(),
@@ -833,13 +854,13 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             if state["result"] is not None:   # Lanczos finished first: plain one-column products from here on
                 S1, jc1, ws1 = B.kv_plan(p1.kind, n, n, p1.d, 1, B.kv_flags(p1, p1, 1), ld)
                 P1 = B.workspace(dev, wsn + ws1)[wsn:]
-                check(L.gpamd_kv_partials_f32(B.kind_id(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(dt), ld, 1, B._ptr(P1), ld,
+                check(L.gpamd_kv_partials_f32(*B.kind_args(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(dt), ld, 1, B._ptr(P1), ld,
                                               S1, jc1, B.kv_flags(p1, p1, 1), None, st), "kv_partials")
                 return P1, S1, ld
             q = state["q"]
             W[0].copy_(dt[0])
             W[1].copy_(q[0])
-            check(L.gpamd_kv_partials_f32(B.kind_id(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(W), ld, 2, B._ptr(P), ld, S, jc,
+            check(L.gpamd_kv_partials_f32(*B.kind_args(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(W), ld, 2, B._ptr(P), ld, S, jc,
                                           flags, None, st), "kv_partials")
             # Lanczos column: slab row 1 of every split, rows 2 ld apart -> "t = 1 with ldp = 2 ld" for the reduction
             p_col1 = C.c_void_p(P.data_ptr() + 4 * ld)

@@ -241,7 +241,8 @@ class deterministic_probes(_feature_flag):
     """Re-use one fixed set of probe vectors (``linear_operator.settings.deterministic_probes``).
     ``deterministic_probes.probe_vectors`` may be pre-set to an (n, t) tensor to inject Z."""
     _default = False
-    probe_vectors = None
+    probe_vectors = None   # the most recently used / user-injected matrix
+    _drawn = {}            # (n, t) -> matrix drawn by the library: alternating between models of different size keeps each one's probes
 
 
 class cg_graph(_feature_flag):

@@ -24,15 +24,15 @@
 extern "C" {
 #endif
 
-#define GPAMD_ABI_VERSION 1
+#define GPAMD_ABI_VERSION 2
 
 /* covariance families: gpytorch/kernels/rbf_kernel.py:68-85, matern_kernel.py:85-110 (nu = 1/2, 3/2, 5/2) */
 enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3,
        GPAMD_RQ = 4 /* rational quadratic (gpytorch/kernels/rq_kernel.py:60-74): k = (1 + |z - z'|^2)^-alpha on points prepared as
-                       x / (l sqrt(2 alpha)); alpha is set per calling thread with gpamd_set_kernel_param_f32 BEFORE prep_points and
-                       every kernel-evaluating call; float32 fused path only */ };
-/* Shape parameter of the parametrised covariance families (RQ: alpha > 0), thread-local host state read at launch time. */
-int gpamd_set_kernel_param_f32(float value);
+                       x / (l sqrt(2 alpha)); float32 fused path only */ };
+/* `kparam`: shape parameter of the parametrised covariance families (RQ: alpha > 0; ignored by the others), an EXPLICIT argument of
+ * every entry point that evaluates the covariance or prepares points for it (ABI version 2: the library holds no per-thread kernel
+ * state, so operators with different alpha may interleave freely on one thread -- AdditiveKernel(RQ, RQ)). */
 
 enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 
@@ -58,7 +58,7 @@ const char* gpamd_last_error(void);
 /* x / lengthscale (+ Matern mean-centring) -- gpytorch/kernels/rbf_kernel.py:78-79,
  * gpytorch/kernels/keops/rbf_kernel.py:45-46, keops/matern_kernel.py:69-71.
  * ls: nls = 1 (isotropic) or d (ARD) lengthscales; shift: d-vector or NULL. */
-int gpamd_prep_points_f32(int kind, const float* X, int n, int d, int64_t ldx, const float* ls, int nls,
+int gpamd_prep_points_f32(int kind, float kparam, const float* X, int n, int d, int64_t ldx, const float* ls, int nls,
                           const float* shift, float* Xp, int dp, void* stream);
 
 /* Launch plan for one fused K*V: split count S and j-chunk so the grid is a whole number of chip fills of the
@@ -72,7 +72,7 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
  * LazyEvaluatedKernelTensor._matmul (gpytorch/lazy/lazy_evaluated_kernel_tensor.py:245-275).
  * d: input dimension (1..16; the prepared clouds have stride dp = 4*ceil(d/4)).
  * P: float[S][t][ldo].  done: optional device int; non-zero turns the launch into a no-op. */
-int gpamd_kv_partials_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt,
+int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt,
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream);
 
@@ -85,17 +85,17 @@ int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const 
                         void* stream);
 
 /* One-call  Out = scale * K(X1p, X2p) Vt + dscale * Vd  using caller workspace (>= plan's workspace_floats). */
-int gpamd_kv_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt, int64_t ldv,
+int gpamd_kv_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt, int64_t ldv,
                  int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
                  int64_t ldo, float* workspace, int64_t workspace_floats, int flags, void* stream);
 
 /* Explicit entries (LinearOperator._getitem / _diagonal / to_dense on a kernel operator):
  * rows: out[r][j] = scale*k(X1p[rows[r]], X2p[j]);  dense: out[i][j] (row-major, ldo);  diag: out[i]. */
-int gpamd_kernel_rows_f32(int kind, const float* X1p, const int64_t* rows, int nrows, const float* X2p, int m, int dp,
+int gpamd_kernel_rows_f32(int kind, float kparam, const float* X1p, const int64_t* rows, int nrows, const float* X2p, int m, int dp,
                           const float* scale, float* out, int64_t ldo, void* stream);
-int gpamd_kernel_dense_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* scale,
+int gpamd_kernel_dense_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int dp, const float* scale,
                            float* out, int64_t ldo, void* stream);
-int gpamd_kernel_diag_f32(int kind, const float* X1p, const float* X2p, int n, int dp, const float* scale, float* out,
+int gpamd_kernel_diag_f32(int kind, float kparam, const float* X1p, const float* X2p, int n, int dp, const float* scale, float* out,
                           void* stream);
 
 /* out[c] = sum_i A[c][i] * B[c][i]  (per-column inner products; scratch: float[t*256]) */
@@ -157,7 +157,7 @@ int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream);
  * (zero-filled by the caller), rank <= 128; fwork: float[n + 4]; iwork: int[2 + 2n]; pivots: int64[rank].
  * Runs `rank` (pivot, update) steps without host synchronisation; steps after the error tolerance is
  * met are no-ops.  On completion iwork[0] = number of columns produced. ---- */
-int gpamd_pivoted_cholesky_f32(int kind, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
+int gpamd_pivoted_cholesky_f32(int kind, float kparam, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
                                float* L, int64_t ldl, int64_t* pivots, float* fwork, int* iwork, void* stream);
 
 /* ---- Lanczos tridiagonalisation with full re-orthogonalisation: the vector work of one step (float32 vectors of length n,
@@ -210,7 +210,7 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
  * fixed s for the family's shape parameter (RQ alpha; 0 otherwise).  Gz1t == NULL: hyper-parameters only (xworkspace unused). ---- */
 int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d);
 int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d);
-int gpamd_kv_grad2_f32(int kind, const float* X1p, int n, const float* X2p, int m, int d, const float* Lt, int64_t ldl,
+int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Lt, int64_t ldl,
                        const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
                        int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, void* stream);
 

@@ -77,6 +77,45 @@ def test_fixed_heteroskedastic_noise(dev):
     assert (pred.variance.double().cpu() - var_ref).abs().max() < 5e-4
 
 
+@pytest.mark.parametrize("branch", ["cholesky", "bbmm"])
+def test_fixed_noise_learn_additional_noise_gets_a_gradient(branch, dev):
+    """FixedNoiseGaussianLikelihood(learn_additional_noise=True) with a NON-constant fixed noise vector (gaussian_likelihood.py:337-352):
+    the learned second noise stays a differentiable scalar beside the fixed vector (FixedPlusConstantDiagLinearOperator), so the MLL has a
+    gradient w.r.t. second_noise_covar.raw_noise -- value and gradient against dense float64 autograd."""
+    import gpytorch_amd as g
+
+    n, d, ls = 900, 2, 0.3
+    X, y = make_data(n, d)
+    fixed = 0.05 + 0.2 * torch.rand(n, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    lik = g.likelihoods.FixedNoiseGaussianLikelihood(fixed.float().to(dev), learn_additional_noise=True).to(dev)
+    lik.second_noise = 0.07
+    m = _make_model(g, X, y, lik, dev)
+    m.covar_module.base_kernel.lengthscale = ls
+    m.covar_module.outputscale = 1.2
+    m.mean_module.initialize(constant=0.0)
+    m.train()
+    lik.train()
+    op = lik(m(m.train_inputs[0])).lazy_covariance_matrix
+    assert op.noise_vec is not None and op.noise.requires_grad
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    S = g.settings
+    torch.manual_seed(0)
+    with S.max_cholesky_size(10_000 if branch == "cholesky" else 0), S.cg_tolerance(1e-4), S.num_trace_samples(256), S.max_preconditioner_size(0):
+        val = mll(m(m.train_inputs[0]), m.train_targets)
+        val.backward()
+    s2 = torch.tensor(0.07, dtype=torch.float64, requires_grad=True)
+    Kh = OK.kernel_matrix("rbf", X, X, ls, 1.2, x1_eq_x2=True) + torch.diag(fixed) + s2 * torch.eye(n, dtype=torch.float64)
+    ref = OG.dense_log_prob(Kh, y) / n
+    (gref,) = torch.autograd.grad(ref, s2)
+    graw = lik.second_noise_covar.raw_noise.grad
+    assert graw is not None and float(graw.abs().sum()) > 0
+    chain = 1.0 - math.exp(-(0.07 - 1e-4))   # d softplus / d raw at noise = 0.07 (GreaterThan(1e-4) constraint)
+    want = float(gref) * chain
+    tol_v, tol_g = (2e-4, 3e-3) if branch == "cholesky" else (2e-2, 0.1)
+    assert abs(float(val) - float(ref)) < tol_v * max(1.0, abs(float(ref)))
+    assert abs(float(graw.sum()) - want) < tol_g * abs(want), (float(graw.sum()), want)
+
+
 def test_training_loop_with_cg_forced(dev):
     """25 Adam steps on the BBMM path (max_cholesky_size(0)): the loss decreases and the fitted model predicts
     the test function (reference: MAE < 0.15 on the KeOps example, test_keops_gp_regression.py:77)."""

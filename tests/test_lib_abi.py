@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
     for name in declared:
         assert hasattr(h, name), f"{name} declared in gpamd.h but not exported"
     assert sorted(SIGNATURES) == declared, "ctypes table and gpamd.h disagree"
-    assert h.gpamd_abi_version() == 1
+    assert h.gpamd_abi_version() == 2
 
 
 def test_library_exports_nothing_beyond_the_header():
@@ -76,10 +76,10 @@ def test_argument_validation_without_gpu():
     assert h.gpamd_kv_plan(0, 0, 10, 3, 1, 0, 12, None, None, None) == -1
     assert b"bad shape" in h.gpamd_last_error()
     # input dimensions beyond 16 are refused before any launch
-    rc = h.gpamd_kv_partials_f32(0, None, 10, None, 10, 20, None, 12, 1, None, 12, 1, 128, 0, None, None)
+    rc = h.gpamd_kv_partials_f32(0, 0.0, None, 10, None, 10, 20, None, 12, 1, None, 12, 1, 128, 0, None, None)
     assert rc == -2
     # split-operand contraction: the j chunk must be the plan's (a multiple of the 128-row LDS tile) -- refused before any launch
-    rc = h.gpamd_kv_partials_f32(0, None, 1000, None, 1000, 3, None, 1000, 11, None, 1000, 1, 1004, 1 | 8, None, None)
+    rc = h.gpamd_kv_partials_f32(0, 0.0, None, 1000, None, 1000, 3, None, 1000, 11, None, 1000, 1, 1004, 1 | 8, None, None)
     assert rc == -1 and b"jchunk % 128" in h.gpamd_last_error()
 
 
@@ -140,7 +140,7 @@ def test_integration_stub_matches_the_abi():
     from gpytorch_amd._lib import SIGNATURES
 
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    names = {"_i": C.c_int, "_p": C.c_void_p, "_l": C.c_int64, "C.POINTER(_i)": C.POINTER(C.c_int), "C.POINTER(_l)": C.POINTER(C.c_int64)}
+    names = {"_i": C.c_int, "_p": C.c_void_p, "_l": C.c_int64, "_f": C.c_float, "C.POINTER(_i)": C.POINTER(C.c_int), "C.POINTER(_l)": C.POINTER(C.c_int64)}
     found = re.findall(r"_lib\.(gpamd_\w+)\.argtypes\s*=\s*\[([^\]]*)\]", text)
     assert len(found) >= 3
     for fn, args in found:
