@@ -19,6 +19,10 @@ configs[1] itself.  Inputs are resident in HBM before the timed region.
   parity     = rows of the benchmarked K*V (same kernel instantiation, same n and column count, probe-like V) compared
                with the float64 oracle OUTSIDE the timed region: max |GPU - oracle| / max |oracle|
 
+`--config c3` = BASELINE configs[2] (Matern-5/2, n = 500 000, d = 10, rank-100 pivoted-Cholesky preconditioner; the preconditioner build
+is inside the timed step, as in a real MLL evaluation); `--config c5` = BASELINE configs[4] (multitask, 4 tasks, RBF (x) index kernel,
+n = 200 000, d = 6: mBCG over the Kronecker MVM -- ONE fused launch with 4 x columns -- 64 probes IN TOTAL split over the ranks).
+
 N > 1: one process per GPU.  Default (`--config metric`): each rank owns 64 probes of a 64*N global probe set (WEAK scaling;
 the y column is solved on rank 0 only).  `--config c4` = BASELINE configs[3]: n = 1 000 000, 256 probes in total split over
 the N ranks (32 + y on rank 0 at N = 8; STRONG scaling over the probe set).  The only data-path collectives are the 2-float
@@ -50,7 +54,7 @@ def synth(n, d, seed=0):
     return X, y
 
 
-def cpu_baseline(n, d, t, ls, budget_s=12.0):
+def cpu_baseline(n, d, t, ls, budget_s=12.0, kind="rbf"):
     """The reference's matrix-free K*V on the host cores, as SURVEY.md 8(d) prescribes: float32 (the reference computes in the
     dtype of its inputs), row chunks of 4096 (`lazy_evaluated_kernel_tensor.py:245-275`: split x1, build the chunk of K with
     the kernel's own forward -- the mean-centred Gram-trick `sq_dist` of `kernels/kernel.py:26-49` -- multiply, cat), restated
@@ -68,7 +72,10 @@ def cpu_baseline(n, d, t, ls, budget_s=12.0):
     rows_done, t0 = 0, time.perf_counter()
     while rows_done < n and (rows_done == 0 or time.perf_counter() - t0 < budget_s):
         xc = X[rows_done : rows_done + chunk]
-        kc = OK.rbf(xc, X, ls, x1_eq_x2=False)      # functions/rbf_covariance.py:14-19 on kernels/kernel.py:26-49
+        if kind == "rbf":
+            kc = OK.rbf(xc, X, ls, x1_eq_x2=False)      # functions/rbf_covariance.py:14-19 on kernels/kernel.py:26-49
+        else:
+            kc = OK.matern(xc, X, ls, OK.KINDS[kind], x1_eq_x2=False)   # functions/matern_covariance.py:18-50
         _ = kc @ V
         rows_done += xc.shape[0]
     dt = time.perf_counter() - t0
@@ -83,7 +90,7 @@ def cpu_baseline(n, d, t, ls, budget_s=12.0):
     }
 
 
-def parity_block(xp, Xcpu, n, d, t, ls, dev, nrows=2048):
+def parity_block(xp, Xcpu, n, d, t, ls, dev, nrows=2048, kind="rbf"):
     """Rows of the benchmarked product vs the float64 oracle (reference formulas: oracle.kernels.kernel_matmul_rows)."""
     from gpytorch_amd import backend as B
     from oracle import kernels as OK
@@ -95,12 +102,12 @@ def parity_block(xp, Xcpu, n, d, t, ls, dev, nrows=2048):
     q = nrows // 4
     rows = torch.cat([torch.arange(q), torch.randint(q, n - q, (nrows - 2 * q,), generator=g), torch.arange(n - q, n)]).unique()
     got = out_t[:, rows.to(dev)].t().double().cpu()
-    ref = OK.kernel_matmul_rows("rbf", Xcpu.double(), rows, ls, 1.0, V.double())
+    ref = OK.kernel_matmul_rows(kind, Xcpu.double(), rows, ls, 1.0, V.double())
     return {
         "kv_rel_err": float((got - ref).abs().max() / ref.abs().max()),
         "rows": int(rows.numel()),
         "columns": t,
-        "vs": "oracle fp64 (reference dense formulas, kernels/kernel.py:26-49 + functions/rbf_covariance.py:14-19)",
+        "vs": "oracle fp64 (reference dense formulas, kernels/kernel.py:26-49 + functions/" + ("rbf_covariance.py:14-19)" if kind == "rbf" else "matern_covariance.py:18-50)"),
         "tolerance": 2e-5,
     }
 
@@ -183,11 +190,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["metric", "c2", "c4"], default="metric",
+    ap.add_argument("--config", choices=["metric", "c2", "c3", "c4", "c5"], default="metric",
                     help="metric: n=500k, 64 probes/GPU + y (weak scaling; the configuration BASELINE.json's metric is quoted on); "
-                         "c2: configs[1] (n=100k); c4: configs[3], n=1e6 with 256 probes IN TOTAL split over the ranks (strong scaling)")
+                         "c2: configs[1] (n=100k); c3: configs[2] (Matern-5/2, n=500k, d=10, rank-100 preconditioner); "
+                         "c4: configs[3], n=1e6 with 256 probes IN TOTAL split over the ranks (strong scaling); "
+                         "c5: configs[4], 4-task Kronecker multitask GP, n=200k, d=6, 64 probes IN TOTAL split over the ranks")
     ap.add_argument("--size", type=int, default=None, help="override the number of training points n (not --n: torch.distributed.run's parser treats that as an ambiguous prefix)")
-    ap.add_argument("--dims", type=int, default=3)
+    ap.add_argument("--dims", type=int, default=None)
     ap.add_argument("--probes", type=int, default=None, help="override: probes per GPU (metric / c2) or in total (c4)")
     ap.add_argument("--contraction", choices=["f32", "split"], default="f32",
                     help="K*V contraction of the TIMED steps: f32 = v_mfma_f32_32x32x2_f32 (the metric's fp32-MFMA roofline; default), "
@@ -223,17 +232,20 @@ def main():
     from gpytorch_amd import backend as B
     from gpytorch_amd import linear_cg as LCG
     from gpytorch_amd import settings as gsettings
-    from gpytorch_amd.bbmm import LOG_2PI, inv_quad_logdet_forward
+    from gpytorch_amd.bbmm import LOG_2PI, build_preconditioner, inv_quad_logdet_forward
 
     gsettings.split_contraction._set_state(args.contraction == "split")
 
-    strong = args.config == "c4"
-    n = args.size if args.size is not None else {"metric": 500_000, "c2": 100_000, "c4": 1_000_000}[args.config]
-    d = args.dims
+    strong = args.config in ("c4", "c5")
+    n = args.size if args.size is not None else {"metric": 500_000, "c2": 100_000, "c3": 500_000, "c4": 1_000_000, "c5": 200_000}[args.config]
+    d = args.dims if args.dims is not None else {"c3": 10, "c5": 6}.get(args.config, 3)
+    kind = "matern52" if args.config == "c3" else "rbf"
+    precond_rank = 100 if args.config == "c3" else 0
+    T = 4 if args.config == "c5" else 1
     if strong:
         from gpytorch_amd.distributed import probe_shard
 
-        t_total = args.probes if args.probes is not None else 256
+        t_total = args.probes if args.probes is not None else (256 if args.config == "c4" else 64)
         a_, b_ = probe_shard(t_total, world, rank)
         t = b_ - a_
     else:
@@ -248,13 +260,35 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     rhs_t = B.to_probe_major(yd.unsqueeze(-1))
     shift = Xd.mean(dim=0)
+    nvec = n * T
+
+    if args.config == "c5":
+        # task matrix B = randn(4, 1, seed 2), v = 0.5 -> K_TT = B B^T + 0.5 I; targets: four phase-shifted copies of the
+        # synthetic function in the interleaved layout (row = i T + tau, multitask_multivariate_normal.py:66-70); task noise 0.1
+        from gpytorch_amd.multitask import kron_matvec
+
+        Bf = torch.randn(T, 1, generator=torch.Generator().manual_seed(2))
+        ktt = (Bf @ Bf.t() + 0.5 * torch.eye(T)).to(dev)
+        Ymat = torch.stack([yd * math.cos(0.4 * k_) + torch.roll(yd, k_) * math.sin(0.4 * k_) for k_ in range(T)], -1)   # [n, T]
+        rhs_t = B.to_probe_major(Ymat.reshape(-1, 1))
+        dv = torch.zeros(B.round_up(nvec, 4), device=dev)
+        dv[:nvec] = 0.1
 
     def step():
-        xp = B.prep_points("rbf", Xd, lengthscale, shift)  # centred, as RBFKernel.forward does
-        res = inv_quad_logdet_forward(
-            xp, outputscale, noise, rhs_t, num_probes=t, precond=None, generator=gen, group=group, t_total=t_total
-        )
-        mll = -0.5 * (res.inv_quad.sum() + res.logdet + n * LOG_2PI) / n
+        xp = B.prep_points(kind, Xd, lengthscale, shift)  # centred, as the kernels' forward does
+        if args.config == "c5":
+            def partials(dt):
+                out = kron_matvec(xp, xp, ktt, dt, outputscale)
+                return out, 1, out.stride(0)
+
+            res = inv_quad_logdet_forward(None, None, None, rhs_t, num_probes=t, precond=None, generator=gen, group=group, t_total=t_total,
+                                          dvec=dv, kv_partials=partials, nvec=nvec)
+        else:
+            pre = build_preconditioner(xp, outputscale, noise, rank=precond_rank, min_size=0) if precond_rank else None
+            res = inv_quad_logdet_forward(
+                xp, outputscale, noise, rhs_t, num_probes=t, precond=pre, generator=gen, group=group, t_total=t_total
+            )
+        mll = -0.5 * (res.inv_quad.sum() + res.logdet + nvec * LOG_2PI) / nvec
         return mll, res.info.iterations
 
     def barrier():
@@ -288,7 +322,7 @@ def main():
     live = [x for x in durs if x > 0.2 * med]  # launches issued after convergence are device-side no-ops
     kv_ms = sum(live) / len(live)
     cols = t + (1 if rank == 0 else 0)      # the y column is solved by rank 0 only
-    flop_per_launch = 2.0 * n * n * cols
+    flop_per_launch = 2.0 * n * n * cols * T   # c5: the fused launch of the Kronecker MVM carries T x columns (+ O(n T t) glue, inside the events)
     achieved = flop_per_launch / (kv_ms * 1e-3) / 1e12
 
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the
@@ -311,11 +345,11 @@ def main():
         split_traffic = None
 
     # whole-job algorithmic flops of the timed region: every rank's columns (t_total probes + one y) x CG iterations
-    flops_job = 2.0 * n * n * (t_total + 1) * iters_total
+    flops_job = 2.0 * n * n * (t_total + 1) * T * iters_total
     value = flops_job / elapsed / 1e12
     parity = None
     if rank == 0 and not args.skip_parity:
-        parity = parity_block(B.prep_points("rbf", Xd, lengthscale, shift), X, n, d, cols, ls, dev)
+        parity = parity_block(B.prep_points(kind, Xd, lengthscale, shift), X, n, d, cols * T, ls, dev, kind=kind)
 
     # the other contraction path: one untimed step on the same inputs (same probe stream), its kernel timed the same way
     other = None
@@ -354,10 +388,10 @@ def main():
                 other["roofline"] = {"bound": "mfma", "achieved": ex, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s (f16, executed = 3 x algorithmic)",
                                      "frac": ex / PEAK_F16_MFMA_TFLOPS, "traffic": split_traffic, "kernel": "kv_gramh_kernel (csrc/kv_gramh.hpp)"}
             if not args.skip_parity:
-                other["parity"] = parity_block(B.prep_points("rbf", Xd, lengthscale, shift), X, n, d, cols, ls, dev)
+                other["parity"] = parity_block(B.prep_points(kind, Xd, lengthscale, shift), X, n, d, cols * T, ls, dev, kind=kind)
 
     extras = None
-    if world == 1 and not args.skip_extras:
+    if world == 1 and not args.skip_extras and args.config in ("metric", "c2"):
         gsettings.split_contraction._set_state(None)   # API-level timings on the library defaults (split contraction on)
         extras = api_level_extras(Xd, yd, ls, t, dev)
         extras["kv_contraction"] = "library default: split" if gsettings.split_contraction.on() else "f32"
@@ -371,7 +405,7 @@ def main():
             "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic,
             "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
-            "kernel": f"kv_gram_kernel<RBF,D=3,CT={(cols - 1) // 32 if cols % 32 == 1 else (cols + 31) // 32},EX={1 if cols % 32 == 1 else 0}> on rank 0 (Gram-form generation "
+            "kernel": f"kv_gram_kernel<{kind},D={d},CT={(cols * T - 1) // 32 if (cols * T) % 32 == 1 else (cols * T + 31) // 32},EX={1 if (cols * T) % 32 == 1 else 0}> on rank 0 (Gram-form generation "
                       "on split-f16 MFMA + fp32 MFMA contraction; kv_mfma_kernel when max|z|^2 > 32)",
             "kernel_ms": kv_ms,
             "launches_timed": len(live),
@@ -387,7 +421,7 @@ def main():
             "frac": 3.0 * achieved / PEAK_F16_MFMA_TFLOPS,
             "traffic": split_traffic,
             "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
-            "kernel": "kv_gramh_kernel<RBF,D=3> on rank 0 (Gram-form generation and hi/lo-split contraction on v_mfma_f32_32x32x16_f16)",
+            "kernel": f"kv_gramh_kernel<{kind},D={d}> on rank 0 (Gram-form generation and hi/lo-split contraction on v_mfma_f32_32x32x16_f16)",
             "kernel_ms": kv_ms,
             "launches_timed": len(live),
             "flop_per_launch": flop_per_launch,
@@ -408,11 +442,14 @@ def main():
             "dtype": "f32" if args.contraction == "f32" else "f32 emulated on f16 MFMA (hi/lo-split operands, 21-22 bits, f32 accumulate)",
             "data": "synthetic",
             "config": {
-                "workload": f"ExactGP MLL evaluation (mBCG + SLQ), RBF, n={n}, d={d}, {t_total} probes in total ({t} on rank 0) + y column, "
-                            f"fused K*V HIP kernel ({args.contraction} contraction), no preconditioner, cg_tolerance=1.0 (--config {args.config}: "
+                "workload": f"ExactGP MLL evaluation (mBCG + SLQ), {'4-task Kronecker multitask RBF (x) index kernel' if T > 1 else kind}, n={n}, d={d}, "
+                            f"{t_total} probes in total ({t} on rank 0) + y column, fused K*V HIP kernel ({args.contraction} contraction), "
+                            + (f"rank-{precond_rank} pivoted-Cholesky preconditioner (built inside the step)" if precond_rank else "no preconditioner")
+                            + f", cg_tolerance=1.0 (--config {args.config}: "
                             + {"metric": "the configuration BASELINE.json's metric is quoted on", "c2": "BASELINE configs[1]",
-                               "c4": "BASELINE configs[3], 256 probes split over the ranks"}[args.config] + ")",
-                "name": args.config, "n": n, "d": d, "probes_total": t_total, "probes_rank0": t, "rhs_columns_rank0": cols,
+                               "c3": "BASELINE configs[2]", "c4": "BASELINE configs[3], 256 probes split over the ranks",
+                               "c5": "BASELINE configs[4], 64 probes split over the ranks, one fused launch with 4 x columns per Kronecker MVM"}[args.config] + ")",
+                "name": args.config, "kind": kind, "tasks": T, "n": n, "d": d, "probes_total": t_total, "probes_rank0": t, "rhs_columns_rank0": cols,
                 "cg_iterations_per_step": iters_total / args.steps,
                 "parallelism": f"probe-sharded x{world}, y column on rank 0",
             },
@@ -426,7 +463,7 @@ def main():
         if extras is not None:
             out["extras"] = extras
         if not args.skip_cpu_baseline and world == 1:  # timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(n, d, cols, ls)
+            out["cpu_baseline"] = cpu_baseline(n, d, cols * T, ls, kind=kind)
         print(json.dumps(out))
     if group is not None:
         torch.distributed.barrier()   # rank 0 may still be in the (untimed) parity check
