@@ -25,9 +25,9 @@ SIGNATURES = {
     "gpamd_last_error": (C.c_char_p, []),
     "gpamd_prep_points_f32": (_i, [_i, _f, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
     "gpamd_kv_plan": (_i, [_i, _i, _i, _i, _i, _i, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
-    "gpamd_kv_partials_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _p]),
+    "gpamd_kv_partials_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _p]),
     "gpamd_kv_reduce_f32": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
-    "gpamd_kv_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
+    "gpamd_kv_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "gpamd_kernel_rows_f32": (_i, [_i, _f, _p, _p, _i, _p, _i, _i, _p, _p, _i64, _p]),
     "gpamd_kernel_dense_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _p]),
     "gpamd_kernel_diag_f32": (_i, [_i, _f, _p, _p, _i, _i, _p, _p, _p]),
@@ -86,7 +86,7 @@ SIGNATURES = {
     "gpamd_kv_grad_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p]),
     "gpamd_kv_grad2_workspace_doubles": (_i64, [_i, _i, _i, _i]),
     "gpamd_kv_grad2_xworkspace_floats": (_i64, [_i, _i, _i, _i]),
-    "gpamd_kv_grad2_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p, _i64, _p, _i64, _p]),
+    "gpamd_kv_grad2_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p, _i64, _p, _i64, _p]),
 }
 
 

@@ -51,6 +51,13 @@ KV_G4 = 4                # with KV_GRAM, tuning / A-B only: 9..12 columns on kv_
 KV_SPLIT = 8             # with KV_GRAM, >= 5 columns: contraction of hi/lo-split operands on the f16 matrix pipe (kv_gramh.hpp)
 SPLIT_CONTRACTION = None  # tests / tuning: force True / False; None -> settings.split_contraction
 GRAM_MAX_SQNORM = 32.0   # max |z|^2 for which the split-f16 quadratic expansion keeps K within 2e-5 (gram_f16.hpp)
+# block-centred expansion: error of S ~ 2^-22 (sqrt(S) + 2 r)^2 with r the radius of the workgroup's row block: blocks within the radius the
+# cloud-centred rule accepts for EVERY point (relative error <= 2e-5 in K, worst case) run on the Gram-form kernels, the rows of wider
+# blocks (sparse tails) on the direct-difference kernel; beyond GRAM_MAX_WIDE_FRACTION of the rows the whole product falls back
+GRAM_MAX_BLOCK_SQRADIUS = 32.0
+GRAM_MAX_WIDE_FRACTION = 0.25
+GRAM_MAX_EXTENT_SQ = 60000.0    # block-centred expansion: (max |z1| + max |z2|)^2 must stay inside the f16 range of the split norms
+_warned_fallback = set()
 FORCE_GENERIC = False    # tests: send float32 / d <= 16 problems down the generic (row-block + GEMM) path too
 FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or KV_GRAM regardless of |z|
 
@@ -58,12 +65,21 @@ FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or
 class PreparedPoints:
     """A point cloud converted for the fused kernels: float32 [n, dp], scaled by 1/lengthscale."""
 
-    __slots__ = ("xp", "n", "d", "dp", "kind", "_zmax2", "param")
+    __slots__ = ("xp", "n", "d", "dp", "kind", "_zmax2", "param", "_sorted")
 
     def __init__(self, xp, n, d, dp, kind, param=None):
         self.xp, self.n, self.d, self.dp, self.kind = xp, n, d, dp, kind
         self._zmax2 = None
         self.param = param   # shape parameter of the covariance family (RQ: alpha, a Python float) or None
+        self._sorted = None  # lazily: SortedView (Hilbert order + chunk centres) for the block-centred Gram expansion
+
+    def sorted_view(self):
+        """The rows of ``xp`` along a Hilbert curve, with the centre of every 128-row chunk and the largest block radius: what the
+        Gram-form kernels need once the cloud as a whole is too wide for the cloud-centred expansion (max |z|^2 > 32).  Computed once
+        per prepared cloud (a dozen elementwise passes + one sort of n keys)."""
+        if self._sorted is None:
+            self._sorted = SortedView(self)
+        return self._sorted
 
     @property
     def dtype(self):
@@ -83,6 +99,107 @@ class PreparedPoints:
         return self._zmax2
 
 
+def hilbert_order(z: torch.Tensor, bits: int | None = None) -> torch.Tensor:
+    """Permutation that sorts the rows of ``z`` [n, d] along a Hilbert curve (Skilling, "Programming the Hilbert curve", AIP Conf. Proc.
+    707, 2004: axes -> transposed index with O(bits * d) elementwise integer passes, then one sort of n keys).  Unlike the Z-order
+    (Hilbert) curve the Hilbert curve has no jumps -- consecutive cells are face neighbours -- so EVERY run of consecutive points is
+    spatially compact, which is what the block-centred Gram expansion needs."""
+    n, d = z.shape
+    if bits is None:
+        bits = max(1, min(16, 62 // d))
+    lo = z.min(0).values
+    span = (z.max(0).values - lo).max().clamp_min(1e-30)
+    top = 2 ** bits - 1
+    X = [((z[:, k] - lo[k]) / span * top).round().to(torch.int64).clamp_(0, top) for k in range(d)]
+    Q = 1 << (bits - 1)
+    while Q > 1:                                    # inverse undo
+        P = Q - 1
+        for i in range(d):
+            hit = (X[i] & Q) != 0
+            t = (X[0] ^ X[i]) & P
+            x0_inv = X[0] ^ P                       # invert low bits of X[0]
+            x0_exc = X[0] ^ t                       # exchange low bits of X[0] and X[i]
+            xi_exc = X[i] ^ t
+            X[0] = torch.where(hit, x0_inv, x0_exc)
+            if i:
+                X[i] = torch.where(hit, X[i], xi_exc)
+        Q >>= 1
+    for i in range(1, d):                           # Gray encode
+        X[i] = X[i] ^ X[i - 1]
+    t = torch.zeros_like(X[0])
+    Q = 1 << (bits - 1)
+    while Q > 1:
+        t = torch.where((X[d - 1] & Q) != 0, t ^ (Q - 1), t)
+        Q >>= 1
+    X = [x ^ t for x in X]
+    key = torch.zeros_like(X[0])
+    for b in range(bits - 1, -1, -1):               # interleave: bit b of X[0], X[1], ..., then bit b - 1 ...
+        for k in range(d):
+            key = (key << 1) | ((X[k] >> b) & 1)
+    return torch.argsort(key)
+
+
+class SortedView:
+    """Hilbert-sorted copy of a prepared cloud for the block-centred Gram expansion (csrc/gram_f16.hpp ``load_center``).
+
+    Rows are grouped in runs of 512 consecutive points of the Hilbert order (the largest row block of any Gram-form kernel).  A group is
+    COMPACT when every 128 / 256 / 512-row block inside it stays within ``GRAM_MAX_BLOCK_SQRADIUS`` of its own centre -- the radius
+    the cloud-centred rule accepts for every point, i.e. <= 2e-5 relative error in K.  The sparse tails of a cloud (outlying points many
+    lengthscales from everything: Gaussian inputs, short lengthscales) form WIDE groups whatever the order; they are moved behind the
+    compact ones and their rows are produced by the direct-difference kernel in a second launch into the same slabs (2-3x slower per row,
+    a few percent of the rows), so the accuracy bound holds for every entry.
+
+    ``perm``: sorted row k is original row perm[k];  ``inv_pad``: [round_up(n, 4)] gather index that takes a probe-major row in sorted
+    order back to the original order (identity on the padding);  ``centers``: [ceil(n / 128), dp] chunk means of the sorted rows;
+    ``n_compact``: rows [0, n_compact) are the compact groups;  ``r2``: the largest block radius^2 among them."""
+
+    def __init__(self, x: "PreparedPoints"):
+        n, dp = x.n, x.dp
+        dev = x.xp.device
+        perm = hilbert_order(x.xp[:, : x.d])
+        xs = x.xp.index_select(0, perm)
+        ng = (n + 511) // 512
+        wide = torch.zeros(ng, device=dev, dtype=torch.bool)
+        r2c = torch.zeros(ng, device=dev, dtype=xs.dtype)
+        for bm in (128, 256, 512):
+            nb = (n + bm - 1) // bm
+            padb = nb * bm - n
+            xb = torch.cat([xs, xs[-1:].expand(padb, -1)], 0) if padb else xs
+            # block centre = mean of the means of its 128-row chunks (csrc/gram_f16.hpp load_center; equal to the block mean for full blocks)
+            bc = xb.reshape(nb * (bm // 128), 128, dp).mean(1).reshape(nb, bm // 128, dp).mean(1, keepdim=True)
+            rb = (xb.reshape(nb, bm, dp) - bc).pow(2).sum(-1).max(1).values                       # [nb]
+            per_group = torch.nn.functional.pad(rb, (0, ng * (512 // bm) - nb)).reshape(ng, 512 // bm).max(1).values
+            r2c = torch.maximum(r2c, per_group)
+        wide = r2c > GRAM_MAX_BLOCK_SQRADIUS
+        n_wide_groups = int(wide.sum().item())
+        if n_wide_groups:
+            # compact groups first (Hilbert order kept), wide groups behind them; a ragged last group goes with the wide ones unless
+            # nothing follows it (the compact region must consist of whole 512-row groups followed by at most one ragged group)
+            ragged = n % 512 != 0
+            if ragged and not bool(wide[-1]):
+                wide[-1] = True
+                n_wide_groups += 1
+            order = torch.cat([torch.nonzero(~wide).reshape(-1), torch.nonzero(wide).reshape(-1)])
+            rows = (order.unsqueeze(1) * 512 + torch.arange(512, device=dev).unsqueeze(0)).reshape(-1)
+            rows = rows[rows < n]
+            perm = perm[rows]
+            xs = xs[rows]
+            self.n_compact = int((~wide).sum().item()) * 512
+        else:
+            self.n_compact = n
+        self.r2 = float(r2c[~wide].max().item()) if self.n_compact else 0.0
+        self.perm = perm
+        self.xs = xs.contiguous()
+        ld = round_up(n, 4)
+        inv = torch.arange(ld, device=dev, dtype=torch.int64)
+        inv[perm] = torch.arange(n, device=dev, dtype=torch.int64)
+        self.inv_pad = inv
+        nch = (n + 127) // 128
+        pad = nch * 128 - n
+        xs_pad = torch.cat([self.xs, self.xs[-1:].expand(pad, -1)], 0) if pad else self.xs
+        self.centers = xs_pad.reshape(nch, 128, dp).mean(1).contiguous()
+
+
 def kind_id(xp: PreparedPoints) -> int:
     """Integer id of the covariance family of ``xp`` for the C ABI."""
     return KIND_IDS[xp.kind]
@@ -94,6 +211,33 @@ def kind_args(xp: PreparedPoints):
     return KIND_IDS[xp.kind], float(xp.param) if xp.param is not None else 0.0
 
 
+def gram_mode(x1: PreparedPoints, x2: PreparedPoints) -> int:
+    """How the Gram-form kernels may evaluate the squared distances of k(x1, x2): 1 = cloud-centred quadratic expansion (both clouds
+    within max |z|^2 <= 32 of the common origin), 2 = BLOCK-centred expansion on the Hilbert-sorted rows of x1 (any cloud width: the
+    error scales with the radius of a 128..512-row block of x1, the reference's Gram-trick distance has no scale limit either,
+    ``gpytorch/kernels/kernel.py:26-49``), 0 = neither (direct-difference kernels; a warning is issued once per reason)."""
+    z1 = x1.zmax2
+    z2 = x2.zmax2 if x2 is not x1 else z1
+    if max(z1, z2) <= GRAM_MAX_SQNORM:
+        return 1
+    if (math.sqrt(z1) + math.sqrt(z2)) ** 2 <= GRAM_MAX_EXTENT_SQ and x1.n >= 128:
+        sv = x1.sorted_view()
+        if x1.n - sv.n_compact <= GRAM_MAX_WIDE_FRACTION * x1.n:
+            return 2
+        reason = (f"{x1.n - sv.n_compact} of {x1.n} points (d = {x1.d}) lie in 512-point runs of the Hilbert order wider than "
+                  f"|z - centre|^2 = {GRAM_MAX_BLOCK_SQRADIUS}")
+    else:
+        reason = f"cloud extent (max |x / lengthscale|^2 = {max(z1, z2):.0f}) outside the range of the split-f16 expansion"
+    key = (x1.kind, x1.d, reason[:24])
+    if key not in _warned_fallback:
+        import warnings
+
+        _warned_fallback.add(key)
+        warnings.warn("gpytorch_amd: kernel products fall back to the direct-difference kernels (2-3x slower than the Gram-form / "
+                      f"split-contraction kernels): {reason}", RuntimeWarning)
+    return 0
+
+
 def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
     """Select the Gram-form generation kernel when it is both applicable and accurate (see kv_gram.hpp)."""
     if not (x1.fused and x2.fused):
@@ -102,7 +246,7 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
         return FORCE_KV_FLAGS
     if x1.kind == "matern12":
         return 0
-    if max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) > GRAM_MAX_SQNORM:
+    if gram_mode(x1, x2) == 0:
         return 0
     if SPLIT_CONTRACTION is None:
         from . import settings
@@ -178,6 +322,41 @@ def kv_plan(kind: str, n: int, m: int, d: int, t: int, flags: int, ldo: int):
     return S.value, jc.value, ws.value
 
 
+def gram_operands(x1: PreparedPoints, x2: PreparedPoints, flags: int):
+    """(X1 array, chunk centres or None, un-sort index or None, rows of the compact region) for a Gram-form launch of k(x1, x2).
+    Block-centred mode: the OUTPUT rows come out in x1's sorted order -- ``unsort`` (an index for ``index_select(1, .)`` on a probe-major
+    [t, round_up(n, 4)] block) takes them back; x2 and the right-hand sides stay in their original order."""
+    if (flags & KV_GRAM) and FORCE_KV_FLAGS is None and gram_mode(x1, x2) == 2:
+        sv = x1.sorted_view()
+        return sv.xs, sv.centers, sv.inv_pad, sv.n_compact
+    return x1.xp, None, None, x1.n
+
+
+def kv_partials_sorted(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, t: int, flags: int, P, ldo: int, S: int, jc: int, done_ptr, st):
+    """One fused K*V launch group into the partial slabs P; returns the un-sort index of the output rows (None: original order).
+    Block-centred mode: the compact rows on the Gram-form kernels, the rows of the wide groups (``SortedView``) on the direct-difference
+    kernel -- a second launch into the same slabs, same split count and chunk length."""
+    X1, Xc, unsort, n_c = gram_operands(x1, x2, flags)
+    L = lib()
+    if n_c:
+        check(
+            L.gpamd_kv_partials_f32(
+                *kind_args(x1), _ptr(X1), n_c, _ptr(x2.xp), x2.n, x1.d, _ptr(Xc), _ptr(vt), vt.stride(0), t, _ptr(P), ldo, S, jc,
+                flags, done_ptr, st
+            ),
+            "kv_partials",
+        )
+    if n_c < x1.n:
+        check(
+            L.gpamd_kv_partials_f32(
+                *kind_args(x1), C.c_void_p(X1.data_ptr() + 4 * x1.dp * n_c), x1.n - n_c, _ptr(x2.xp), x2.n, x1.d, None, _ptr(vt), vt.stride(0), t,
+                C.c_void_p(P.data_ptr() + 4 * n_c), ldo, S, jc, 0, done_ptr, st
+            ),
+            "kv_partials (wide rows)",
+        )
+    return unsort
+
+
 def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dscale=None, vd=None, out=None, dvec=None):
     """out[t, ld_n] = scale * k(x1, x2) @ V + (dscale + dvec) .* Vd in probe-major layout.
 
@@ -201,13 +380,24 @@ def kv(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, scale=None, dsc
     ws = workspace(vt.device, wsn)
     st = _stream(vt.device)
     L = lib()
-    check(
-        L.gpamd_kv_partials_f32(
-            *kind_args(x1), _ptr(x1.xp), n, _ptr(x2.xp), m, x1.d, _ptr(vt), ldv, t, _ptr(ws), ldo, S, jc,
-            flags, None, st
-        ),
-        "kv_partials",
-    )
+    unsort = kv_partials_sorted(x1, x2, vt, t, flags, ws, ldo, S, jc, None, st)
+    if unsort is not None:
+        # block-centred Gram expansion: the slabs hold the rows in x1's Hilbert order -> sum them, take the rows back (one gather of
+        # t x n floats against n m t pair evaluations), then apply the diagonal epilogue in the original order
+        tmp = torch.empty(t, ldo, device=vt.device, dtype=torch.float32)
+        check(L.gpamd_kv_reduce_f32(_ptr(ws), S, ldo, t, n, _ptr(scale), None, None, None, 0, _ptr(tmp), ldo, None, st), "kv_reduce")
+        res = tmp.index_select(1, unsort)
+        if vd is not None and (dscale is not None or dvec is not None):
+            dtot = torch.zeros(n, device=vt.device, dtype=res.dtype)
+            if dscale is not None:
+                dtot += dscale.reshape(())
+            if dvec is not None:
+                dtot += dvec[:n]
+            res[:, :n].addcmul_(vd[:, :n], dtot)
+        if out.shape == res.shape and out.stride(1) == 1:
+            out.copy_(res)
+            return out
+        return res
     check(
         L.gpamd_kv_reduce_f32(
             _ptr(ws), S, ldo, t, n, _ptr(scale), _ptr(dscale), _ptr(dvec), _ptr(vd), 0 if vd is None else vd.stride(0),
@@ -423,10 +613,11 @@ FORCE_GRAD_DIRECT = False  # tests: keep the bilinear derivative on the direct-d
 
 
 def grad_gram_ok(x1: PreparedPoints, x2: PreparedPoints) -> bool:
-    """The Gram-form derivative kernel (kv_grad2.hpp) applies: fused float32 clouds, not Matern-1/2, max |z|^2 <= 32."""
+    """The Gram-form derivative kernel (kv_grad2.hpp) applies: fused float32 clouds, not Matern-1/2, cloud- or block-centred expansion
+    within its accuracy policy (``gram_mode``)."""
     if not (x1.fused and x2.fused) or x1.kind == "matern12" or (FORCE_GRAD_DIRECT and x1.kind != "rq"):
         return False
-    return max(x1.zmax2, x2.zmax2 if x2 is not x1 else 0.0) <= GRAM_MAX_SQNORM
+    return gram_mode(x1, x2) != 0
 
 
 def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor, iso: bool = False, want_gz1: bool = False):
@@ -447,13 +638,21 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
         nx = int(L.gpamd_kv_grad2_xworkspace_floats(x1.n, x2.n, t, x1.d))
         xws = torch.empty(nx, device=dev, dtype=torch.float32)
         gzt = torch.empty(x1.d, ldg, device=dev, dtype=torch.float32)
+    X1, Xc, unsort, _ = gram_operands(x1, x2, KV_GRAM)
+    if unsort is not None:
+        # block-centred expansion: the left vectors follow x1's Hilbert order (one gather of t x n floats per backward pass)
+        lt = lt[:, : x1.n].index_select(1, x1.sorted_view().perm).contiguous()
+        if lt.shape[1] % 4:
+            lt = torch.nn.functional.pad(lt, (0, 4 - lt.shape[1] % 4))
     check(
         L.gpamd_kv_grad2_f32(
-            *kind_args(x1), _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.d, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
+            *kind_args(x1), _ptr(X1), x1.n, _ptr(x2.xp), x2.n, x1.d, _ptr(Xc), _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
             1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, _stream(dev),
         ),
         "kv_grad2",
     )
+    if unsort is not None and gzt is not None:
+        gzt = gzt.index_select(1, unsort)
     if iso and want_gz1:  # the kernel ran in per-dimension mode: fold to the single-lengthscale convention of kv_grad
         out = torch.cat([out[:1], out[1 : 1 + x1.d].sum().reshape(1), torch.zeros(x1.dp - 1, device=dev), out[1 + x1.dp :]])
     return out, (None if gzt is None else gzt[:, : x1.n].t().contiguous())

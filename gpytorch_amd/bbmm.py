@@ -36,8 +36,11 @@ def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=
     tol = settings.preconditioner_tolerance.value() if tol is None else tol
     min_size = settings.min_preconditioning_size.value() if min_size is None else min_size
     n = x.n
-    if rank == 0 or n < min_size or float(sigma2.detach().reshape(-1)[0]) <= 0.0:
-        return None  # (P = L L^T + s2 I is singular without a positive diagonal)
+    if rank == 0 or n < min_size:
+        return None
+    s2v = float(sigma2.detach().reshape(-1)[0])
+    if (s2v <= 0.0 and dvec is None) or (dvec is not None and not bool((dvec.detach()[:n] + s2v > 0).all())):
+        return None  # (P = L L^T + D is singular without a positive diagonal)
     lt, _, k = B.pivoted_cholesky(x, scale, rank, tol)  # [k, n]
     if not bool(torch.isfinite(lt).all()):
         import warnings

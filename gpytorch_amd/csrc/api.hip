@@ -322,7 +322,7 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
   return 0;
 }
 
-int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt,
+int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt,
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream) {
   if (kind < 0 || kind > GPAMD_RQ) return fail(GPAMD_EINVAL, "kv: unknown kind");
@@ -332,7 +332,7 @@ int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const
   // (same padded stride, the extra coordinates are the zeros written by prep_points)
   const int dk = kernel_dims(d);
   if (ldv % 4 || ldv < m || ldo < n) return fail(GPAMD_EINVAL, "kv: leading dimensions must be >= extent and ldv % 4 == 0");
-  if (!aligned16(Vt) || !aligned16(X1p) || !aligned16(X2p)) return fail(GPAMD_EINVAL, "kv: buffers must be 16-byte aligned");
+  if (!aligned16(Vt) || !aligned16(X1p) || !aligned16(X2p) || !aligned16(X1c)) return fail(GPAMD_EINVAL, "kv: buffers must be 16-byte aligned");
   if (jchunk % 4 || (int64_t)jchunk * S < m) return fail(GPAMD_EINVAL, "kv: jchunk*S must cover m and jchunk % 4 == 0");
   hipStream_t st = (hipStream_t)stream;
   const int cap = group_cap(kind, flags);
@@ -361,6 +361,7 @@ int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const
     a.nrb = (n + v.bm - 1) / v.bm;
     a.done = done;
     a.kparam = kparam;
+    a.Xc = X1c;
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
     const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex, v.ni);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");
@@ -403,7 +404,7 @@ int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const 
   return check_launch("kv_reduce");
 }
 
-int gpamd_kv_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt, int64_t ldv,
+int gpamd_kv_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt, int64_t ldv,
                  int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
                  int64_t ldo, float* workspace, int64_t workspace_floats, int flags, void* stream) {
   int S, jc;
@@ -413,7 +414,7 @@ int gpamd_kv_f32(int kind, float kparam, const float* X1p, int n, const float* X
   const SplitLayout L = split_layout(kind, flags, m, t, S, ldp);
   if (workspace_floats < (L.total ? L.base + L.total : (int64_t)S * t * ldp))
     return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4) and the same flags)");
-  int rc = gpamd_kv_partials_f32(kind, kparam, X1p, n, X2p, m, d, Vt, ldv, t, workspace, ldp, S, jc, flags, nullptr, stream);
+  int rc = gpamd_kv_partials_f32(kind, kparam, X1p, n, X2p, m, d, X1c, Vt, ldv, t, workspace, ldp, S, jc, flags, nullptr, stream);
   if (rc) return rc;
   return gpamd_kv_reduce_f32(workspace, S, ldp, t, n, scale, dscale, nullptr, Vd, ldd, Out, ldo, nullptr, stream);
 }

@@ -40,6 +40,40 @@ __device__ __forceinline__ void f16_split(float v, _Float16& hi, _Float16& lo) {
   lo = (_Float16)(v - hf);
 }
 
+// Block-centred expansion (GPAMD "recentre" mode).  The cancellation error of the quadratic expansion is ~2^-22 (|z_i| + |z_j|)^2: with
+// the cloud centred as a whole it grows with the CLOUD radius (host limit max |z|^2 <= 32).  Squared distances are translation
+// invariant, so a workgroup may subtract ANY common point c from both operands before the hi/lo split; with the rows sorted along a
+// space-filling curve a block of output rows is compact, c = the centre of the block, |z_i - c| <= block radius, and
+// |z_j - c| <= |z_j - z_i| + radius: the error is ~2^-22 (sqrt(S) + 2 radius)^2, i.e. small wherever the covariance is not (far pairs:
+// k ~ 0 for RBF / Matern, relative error 2^-22 in S for the heavy-tailed RQ).  Xc: [ceil(n / 128)][DP] chunk centres of X1 or nullptr.
+template <int DP>
+__device__ __forceinline__ void load_center(const float* __restrict__ Xc, int row0, int rows, int n, float* cz) {
+  // centre of the row block [row0, row0 + rows): the mean of the centres of its 128-row chunks (rows = 128, 256 or 512; chunk indices
+  // are clamped to the last chunk, so a ragged last block still gets a point inside it).  The host evaluates the SAME formula when it
+  // bounds the block radii (backend.SortedView).
+#pragma unroll
+  for (int k = 0; k < DP; ++k) cz[k] = 0.f;
+  if (Xc) {
+    const int last = (n - 1) >> 7, nch = rows >> 7;
+    for (int c = 0; c < nch; ++c) {
+      const int ch = min((row0 >> 7) + c, last);
+#pragma unroll
+      for (int q = 0; q < DP / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Xc + (int64_t)ch * DP + 4 * q);
+        cz[4 * q + 0] += v[0]; cz[4 * q + 1] += v[1]; cz[4 * q + 2] += v[2]; cz[4 * q + 3] += v[3];
+      }
+    }
+    const float inv = 1.0f / (float)nch;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) cz[k] *= inv;
+  }
+}
+template <int DP>
+__device__ __forceinline__ void sub_center(float* z, const float* cz) {
+#pragma unroll
+  for (int k = 0; k < DP; ++k) z[k] -= cz[k];
+}
+
 // A side (contracted points x_j): slot s of a row with coordinates split into zh/zl and |z|^2 into nh/nl
 template <int D>
 __device__ __forceinline__ _Float16 gram_slot_a(int s, const _Float16* zh, const _Float16* zl, _Float16 nh, _Float16 nl,

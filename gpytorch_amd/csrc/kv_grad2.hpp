@@ -27,6 +27,7 @@ namespace gpamd {
 struct Grad2Args {
   const float* X1;  // [n][DP] prepared
   const float* X2;  // [m][DP]
+  const float* Xc = nullptr;  // optional [ceil(n / 128)][DP] chunk centres of X1 (block-centred Gram expansion, gram_f16.hpp) or nullptr
   const float* Lt;  // [t][ldl] left vectors (index i, with X1)
   const float* Rt;  // [t][ldr] right vectors (index j, with X2)
   int64_t ldl, ldr;
@@ -112,6 +113,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       zi[4 * q + 0] = v[0]; zi[4 * q + 1] = v[1]; zi[4 * q + 2] = v[2]; zi[4 * q + 3] = v[3];
     }
   }
+  float cz[DP];   // centre of this workgroup's 128 rows (zero unless the host passed chunk centres): every use of z_i / z_j below is
+  load_center<DP>(a.Xc, rb * 128, 128, a.n, cz);   // translation invariant, so the centred coordinates serve the sums as well
+  sub_center<DP>(zi, cz);
   f16x8 bq[KH];
   gram_pack_b<D>(zi, h, bq);
   double g[2 + DP];
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
     if (tid < BN) {
       const int j = j0 + tid;
+      if (j < jend) sub_center<DP>(zreg, cz);
       gram_pack_a<D>(zreg, j < jend, Xh, tid, BN);
       if constexpr (MODE == 1) {
         Zs[tid] = j < jend ? 1.f : 0.f;

@@ -50,6 +50,8 @@ void kv_gram_kernel(KvArgs a) {
   const int jbeg = s * a.jchunk;
   const int jend = min(a.m, jbeg + a.jchunk);
   const int ibase = rb * (4 * NI * 32) + wave * (NI * 32);
+  float cz[DP];   // centre of this workgroup's row block (zero unless the host passed chunk centres: gram_f16.hpp)
+  load_center<DP>(a.Xc, ibase - wave * (NI * 32), 4 * NI * 32, a.n, cz);
 
   // B operands of the Gram MFMAs (this lane's output row, k-group h), kept in registers for the whole kernel
   f16x8 bq[NI][KH];
@@ -62,6 +64,7 @@ void kv_gram_kernel(KvArgs a) {
       f32x4 v = *reinterpret_cast<const f32x4*>(a.X1 + (int64_t)i * DP + 4 * q);
       z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
     }
+    sub_center<DP>(z, cz);
     gram_pack_b<D>(z, h, bq[ni]);
   }
 
@@ -119,6 +122,7 @@ void kv_gram_kernel(KvArgs a) {
         if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP + 4 * q);
         z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
       }
+      if (j < jend) sub_center<DP>(z, cz);
       gram_pack_a<D>(z, j < jend, Xh, tid, BN);
     }
     if constexpr (EX) {

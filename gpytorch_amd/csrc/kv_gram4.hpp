@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void kv_gram4_kernel(KvArgs a) {
   const int jbeg = s * a.jchunk;
   const int jend = min(a.m, jbeg + a.jchunk);
   const int ibase = rb * (4 * NI * 32) + wave * (NI * 32);
+  float cz[DP];   // centre of this workgroup's row block (zero unless the host passed chunk centres: gram_f16.hpp)
+  load_center<DP>(a.Xc, ibase - wave * (NI * 32), 4 * NI * 32, a.n, cz);
 
   f16x8 bq[NI][KH];
 #pragma unroll
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(256) void kv_gram4_kernel(KvArgs a) {
       f32x4 v = *reinterpret_cast<const f32x4*>(a.X1 + (int64_t)i * DP + 4 * q);
       z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
     }
+    sub_center<DP>(z, cz);
     gram_pack_b<D>(z, h, bq[ni]);
   }
   f32x4 acc[NI][G];
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(256) void kv_gram4_kernel(KvArgs a) {
         if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP + 4 * q);
         z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
       }
+      if (j < jend) sub_center<DP>(z, cz);
       gram_pack_a<D>(z, j < jend, Xh, tid, BN);
     }
     __syncthreads();

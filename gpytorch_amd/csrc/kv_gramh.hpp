@@ -108,6 +108,8 @@ void kv_gramh_kernel(KvhArgs ka) {
   const int jbeg = s * a.jchunk;                  // multiple of BN
   const int jend = min(a.m, jbeg + a.jchunk);
   const int ibase = rb * (4 * NI * 32) + wave * (NI * 32);
+  float cz[DP];   // centre of this workgroup's row block (zero unless the host passed chunk centres: gram_f16.hpp)
+  load_center<DP>(a.Xc, ibase - wave * (NI * 32), 4 * NI * 32, a.n, cz);
 
   f16x8 bq[NI][KH];
 #pragma unroll
@@ -119,6 +121,7 @@ void kv_gramh_kernel(KvhArgs ka) {
       f32x4 v = *reinterpret_cast<const f32x4*>(a.X1 + (int64_t)i * DP + 4 * q);
       z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
     }
+    sub_center<DP>(z, cz);
     gram_pack_b<D>(z, h, bq[ni], KIND == KIND_RBF ? (float)KGH_KSHIFT : 0.f);
   }
 
@@ -166,7 +169,10 @@ void kv_gramh_kernel(KvhArgs ka) {
     }
   };
   auto store_x = [&](int buf) {
-    if (tid < BN) gram_pack_a<D>(xz, xvalid, Xh + buf * XHS, tid, BN);
+    if (tid < BN) {
+      if (xvalid) sub_center<DP>(xz, cz);
+      gram_pack_a<D>(xz, xvalid, Xh + buf * XHS, tid, BN);
+    }
     if constexpr (EX) {
       if (tid >= BN && tid < BN + BN / 4) *reinterpret_cast<f32x4*>(&Es[buf * BN + 4 * (tid - BN)]) = xe;
     }

@@ -36,6 +36,7 @@ struct KvArgs {
   int S, jchunk, nrb;  // split count, j-chunk length (multiple of BN), row-block count
   const int* done;     // optional device flag: non-zero -> the launch is a no-op (converged CG)
   float kparam;        // shape parameter of the covariance family (RQ: alpha); 0 otherwise
+  const float* Xc = nullptr;   // Gram-form kernels: optional [ceil(n / 128)][DP] chunk centres of X1 (gram_f16.hpp) or nullptr
 };
 
 constexpr int KV_BN = 128;           // j-tile staged in LDS per iteration

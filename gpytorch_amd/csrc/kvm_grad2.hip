@@ -132,7 +132,7 @@ int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d) {
   return (int64_t)g2_groups(t) * S * dp * ((n + 3) / 4 * 4);
 }
 
-int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Lt, int64_t ldl,
+int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Lt, int64_t ldl,
                        const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
                        int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, void* stream) {
   if (n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m || d < 1 || d > 16) {
@@ -158,7 +158,7 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
     const int rem = t - c0;
     const int tg = g2_take(rem);
     Grad2Args a;
-    a.X1 = X1p; a.X2 = X2p;
+    a.X1 = X1p; a.X2 = X2p; a.Xc = X1c;
     a.Lt = Lt + (int64_t)c0 * ldl;
     a.Rt = Rt + (int64_t)c0 * ldr;
     a.ldl = ldl; a.ldr = ldr;

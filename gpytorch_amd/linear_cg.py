@@ -278,7 +278,9 @@ def linear_cg(
             flags = B.kv_flags(x, x, t)
             S, jc, wsn = B.kv_plan(x.kind, n, n, x.d, t, flags, ld)
             P = B.workspace(dev, wsn)
-            kind_args = B.kind_args(x)
+            if B.gram_operands(x, x, flags)[2] is not None:
+                Psum = torch.zeros(t, ld, device=dev, dtype=torch.float32)
+                Pq1 = torch.zeros(t, ld, device=dev, dtype=torch.float32)
         ldp = ld
         min_iter = min(10, max_iter - 1)
         tri_floor = min(n_tri_iter, max_iter - 1) if n_tridiag else 0
@@ -302,20 +304,22 @@ def linear_cg(
             if KV_EVENT_LOG is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(torch.cuda.current_stream(dev))
+            Pq, Sq = P, S
             if kv_partials is None:
-                check(
-                    L.gpamd_kv_partials_f32(
-                        *kind_args, B._ptr(x.xp), n, B._ptr(x.xp), n, x.d, B._ptr(Dt), ld, t, B._ptr(P), ld, S, jc,
-                        flags, done_ptr, st,
-                    ),
-                    "kv_partials",
-                )
+                unsort = B.kv_partials_sorted(x, x, Dt, t, flags, P, ld, S, jc, done_ptr, st)
+                if unsort is not None:
+                    # block-centred Gram expansion (wide clouds): the slabs hold the rows in Hilbert order -> sum them, take the rows back to
+                    # the original order (t x n floats per iteration against n^2 t pair evaluations), hand ONE slab to the solver
+                    check(L.gpamd_kv_reduce_f32(B._ptr(P), S, ld, t, n, None, None, None, None, 0, B._ptr(Psum), ld, done_ptr, st), "kv_reduce")
+                    torch.index_select(Psum, 1, unsort, out=Pq1)
+                    Pq, Sq = Pq1, 1
             else:
                 P, S, ldp = kv_partials(Dt)
+                Pq, Sq = P, S
             if ev is not None:
                 ev[1].record(torch.cuda.current_stream(dev))
                 KV_EVENT_LOG.append((ev[0], ev[1], n, t, k))
-            check(F["reduce_q"](h, B._ptr(P), S, ldp, B._ptr(scale), B._ptr(dscale), B._ptr(dvec), st), "cg_reduce_q")
+            check(F["reduce_q"](h, B._ptr(Pq), Sq, ldp, B._ptr(scale), B._ptr(dscale), B._ptr(dvec), st), "cg_reduce_q")
             if row_shard is not None:
                 ar(0)
             check(F["update_xr"](h, k, st), "cg_update_xr")

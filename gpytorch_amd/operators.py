@@ -837,6 +837,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         self._preconditioner()
         L, st = lib(), B._stream(dev)
         flags = B.kv_flags(p1, p1, 2)
+        sorted_rows = B.gram_operands(p1, p1, flags)[2] is not None
         S, jc, wsn = B.kv_plan(p1.kind, n, n, p1.d, 2, flags, ld)
         P = B.workspace(dev, wsn)
         W = torch.zeros(2, ld, device=dev, dtype=torch.float32)
@@ -852,15 +853,27 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
 
         def hook(dt):
             if state["result"] is not None:   # Lanczos finished first: plain one-column products from here on
+                if sorted_rows:
+                    out1 = B.kv(p1, p1, dt)
+                    return out1, 1, out1.stride(0)
                 S1, jc1, ws1 = B.kv_plan(p1.kind, n, n, p1.d, 1, B.kv_flags(p1, p1, 1), ld)
                 P1 = B.workspace(dev, wsn + ws1)[wsn:]
-                check(L.gpamd_kv_partials_f32(*B.kind_args(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(dt), ld, 1, B._ptr(P1), ld,
+                check(L.gpamd_kv_partials_f32(*B.kind_args(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, None, B._ptr(dt), ld, 1, B._ptr(P1), ld,
                                               S1, jc1, B.kv_flags(p1, p1, 1), None, st), "kv_partials")
                 return P1, S1, ld
             q = state["q"]
             W[0].copy_(dt[0])
             W[1].copy_(q[0])
-            check(L.gpamd_kv_partials_f32(*B.kind_args(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, B._ptr(W), ld, 2, B._ptr(P), ld, S, jc,
+            if sorted_rows:
+                # block-centred Gram expansion (wide clouds, backend.gram_mode 2): B.kv takes the Hilbert-ordered output rows back
+                both = B.kv(p1, p1, W)
+                wl.copy_(both[1:2])
+                if os_ is not None:
+                    wl.mul_(os_.reshape(()))
+                wl[:, :n].addcmul_(q[:, :n], (nz.reshape(()) + (dv[:n] if dv is not None else 0.0)).expand(n))
+                feed(wl)
+                return both[0:1], 1, both.stride(0)
+            check(L.gpamd_kv_partials_f32(*B.kind_args(p1), B._ptr(p1.xp), n, B._ptr(p1.xp), n, p1.d, None, B._ptr(W), ld, 2, B._ptr(P), ld, S, jc,
                                           flags, None, st), "kv_partials")
             # Lanczos column: slab row 1 of every split, rows 2 ld apart -> "t = 1 with ldp = 2 ld" for the reduction
             p_col1 = C.c_void_p(P.data_ptr() + 4 * ld)

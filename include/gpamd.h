@@ -36,7 +36,7 @@ enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3
 
 enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 
-/* kv flags.  GPAMD_KV_GRAM: the caller asserts max |z|^2 <= 32 over both prepared clouds (after centring), so
+/* kv flags.  GPAMD_KV_GRAM: the caller asserts max |z|^2 <= 32 over both prepared clouds (after centring) -- or passes block centres X1c, see gpamd_kv_partials_f32 --, so
  * the squared distances may be formed by the quadratic expansion on the matrix pipe (kv_gram.hpp; the expansion
  * the reference itself uses, gpytorch/kernels/kernel.py:26-49) with <= 2e-5 relative error in K (worst case at the limit; typically 5e-6).  Ignored for
  * Matern nu = 1/2. */
@@ -71,8 +71,14 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
  * KernelLinearOperator._matmul (gpytorch/kernels/keops/rbf_kernel.py:44-55) and
  * LazyEvaluatedKernelTensor._matmul (gpytorch/lazy/lazy_evaluated_kernel_tensor.py:245-275).
  * d: input dimension (1..16; the prepared clouds have stride dp = 4*ceil(d/4)).
- * P: float[S][t][ldo].  done: optional device int; non-zero turns the launch into a no-op. */
-int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt,
+ * P: float[S][t][ldo].  done: optional device int; non-zero turns the launch into a no-op.
+ * X1c (with GPAMD_KV_GRAM; NULL otherwise): float[ceil(n / 128)][dp], the centre of every 128-row chunk of X1p.  The Gram expansion is
+ *   then taken relative to the centre of the workgroup's row block (squared distances are translation invariant), so its cancellation
+ *   error scales with the BLOCK radius instead of the cloud radius -- the reference's Gram-trick distance has no scale limit
+ *   (gpytorch/kernels/kernel.py:26-49).  The caller sorts the rows of X1p along a space-filling curve so that blocks are compact and
+ *   asserts: max over 128 / 256 / 512-row aligned blocks of |z - centre|^2 <= 8 and (max |z1| + max |z2|)^2 <= 60000 (f16 range of
+ *   the split norms).  With X1c = NULL the GPAMD_KV_GRAM contract is the cloud-centred one (max |z|^2 <= 32). */
+int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt,
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream);
 
@@ -85,7 +91,7 @@ int gpamd_kv_reduce_f32(const float* P, int S, int64_t ldp, int t, int n, const 
                         void* stream);
 
 /* One-call  Out = scale * K(X1p, X2p) Vt + dscale * Vd  using caller workspace (>= plan's workspace_floats). */
-int gpamd_kv_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Vt, int64_t ldv,
+int gpamd_kv_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt, int64_t ldv,
                  int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
                  int64_t ldo, float* workspace, int64_t workspace_floats, int flags, void* stream);
 
@@ -205,12 +211,13 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
  * the gradient with respect to the PREPARED left points:  Gz1t[q][i] = sum_j W_ij dk/ds_ij * 2 (z_iq - z_jq)  (probe-major
  * [d][ldg]; the caller applies dz/dx = coef / lengthscale_q and theta -- the input gradients the KeOps precedent provides,
  * gpytorch/test/base_keops_test_case.py:105-132; the reference's dense Functions refuse them, rbf_covariance.py:9-10).
- * RBF / Matern 3/2 / Matern 5/2 only, accurate while max |z|^2 <= 32 (the host's policy for every Gram-form kernel); d = valid
+ * RBF / Matern 3/2 / Matern 5/2 / RQ only, accurate while max |z|^2 <= 32 or, with block centres X1c (as for gpamd_kv_partials_f32), while the
+ * block radius^2 <= 8 (the host's policy for every Gram-form kernel); d = valid
  * dimensions (points are [n][round_up(d,4)]).  out: float[2 + round_up(d,4)]: [0 .. dp] as gpamd_kv_grad_f32, [1 + dp] = sum_ij W_ij dk/dp_ij at
  * fixed s for the family's shape parameter (RQ alpha; 0 otherwise).  Gz1t == NULL: hyper-parameters only (xworkspace unused). ---- */
 int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d);
 int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d);
-int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* Lt, int64_t ldl,
+int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Lt, int64_t ldl,
                        const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
                        int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, void* stream);
 

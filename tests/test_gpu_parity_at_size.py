@@ -27,6 +27,10 @@ CONFIGS = {
     "metric_default_t": ("rbf", 500_000, 3, 0.25, 11),   # reference default num_trace_samples = 10 (+ y)
     "c3": ("matern52", 500_000, 10, 0.8, 65),
     "c4_share": ("rbf", 1_000_000, 3, 0.25, 33),
+    # outside the cloud-centred Gram bound (max |x / l|^2 ~ 200): block-centred expansion on the Hilbert-sorted rows (tests/test_gpu_recenter.py);
+    # the reference's Gram-trick distance has no scale limit (kernels/kernel.py:26-49)
+    "metric_l0.05": ("rbf", 500_000, 3, 0.05, 65),
+    "normal_inputs_l0.3": ("rbf", 500_000, 3, 0.3, 65, "normal"),
 }
 
 
@@ -53,14 +57,17 @@ def test_kv_rows_vs_oracle_at_config(name, split, dev, monkeypatch):
 
     monkeypatch.setattr(B, "SPLIT_CONTRACTION", split)
 
-    kind, n, d, ls, t = CONFIGS[name]
+    kind, n, d, ls, t = CONFIGS[name][:5]
     X, _ = synth(n, d)
+    if len(CONFIGS[name]) > 5:
+        X = torch.randn(n, d, generator=torch.Generator().manual_seed(0), dtype=torch.float32)   # standardised inputs
     V = torch.randn(n, t, generator=torch.Generator().manual_seed(1), dtype=torch.float32)
     Xd = X.to(dev)
     xp = B.prep_points(kind, Xd, torch.tensor([ls]), Xd.mean(0))
     if kind != "matern12":
         # the Gram-form instantiation (what bench.py / scale_check.py launch), with / without the split contraction
         assert B.kv_flags(xp, xp, t) == (B.KV_GRAM | (B.KV_SPLIT if split else 0))
+        assert B.gram_mode(xp, xp) == (2 if name in ("metric_l0.05", "normal_inputs_l0.3") else 1)
     out_t = B.kv(xp, xp, B.to_probe_major(V.to(dev)))
     rows = sample_rows(n)
     got = out_t[:, rows.to(dev)].t().double().cpu()

@@ -1,0 +1,207 @@
+"""GPU: the BLOCK-CENTRED Gram expansion -- the fast kernels beyond max |x / lengthscale|^2 <= 32.
+
+Round 2 kept the Gram-form generation and the split-operand contraction inside the accuracy bound of a CLOUD-centred quadratic expansion
+(max |z|^2 <= 32) and dropped to the direct-difference kernel (2.4-3x slower) outside it: short lengthscales on U[0,1]^d, standardised
+inputs at l < 0.8 sqrt(d) -- most real training runs.  The reference's Gram-trick distance has no scale limit
+(``gpytorch/kernels/kernel.py:26-49``; KeOps twin ``kernels/keops/rbf_kernel.py:12-15``).  Now the rows of x1 are sorted along a Hilbert curve
+and every workgroup expands the squared distances around the centre of its own row block (csrc/gram_f16.hpp ``load_center``;
+``backend.gram_mode`` = 2), so the cancellation error scales with the block radius.  Ground truth: the float64 oracle
+(reference dense formulas) and dense float64 algebra.
+"""
+import math
+import warnings
+
+import pytest
+import torch
+
+from oracle import exact_gp as OG
+from oracle import kernels as OK
+from tests.util import make_data, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(name, n, d=3, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    if name == "uniform":
+        return torch.rand(n, d, generator=g, dtype=torch.float32)
+    return torch.randn(n, d, generator=g, dtype=torch.float32)       # "standardised" inputs
+
+
+CASES = {
+    # name: cloud, kind, lengthscale        (n = 60 000, d = 3: max |z|^2 ~ 200 -- far outside the cloud-centred bound of 32)
+    "uniform_rbf_l0.05": ("uniform", "rbf", 0.05),            # every 512-point run of the Hilbert order is compact
+    "normal_rbf_l0.3": ("normal", "rbf", 0.3),                # Gaussian tails: ~12 % of the rows on the direct-difference kernel
+    "normal_matern52_l0.8": ("normal", "matern52", 0.8),
+    "uniform_matern32_l0.08": ("uniform", "matern32", 0.08),
+}
+N_CASE = 60_000
+_KROWS = {}
+
+
+def _rows_and_kernel(case):
+    """Sampled rows (first / last blocks + random) of the float64 reference kernel matrix, once per case."""
+    if case not in _KROWS:
+        cloud, kind, ls = CASES[case]
+        X = _cloud(cloud, N_CASE)
+        g = torch.Generator().manual_seed(7)
+        rows = torch.cat([torch.arange(200), torch.randint(200, N_CASE - 200, (300,), generator=g), torch.arange(N_CASE - 200, N_CASE)]).unique()
+        _KROWS[case] = (X, rows, OK.kernel_matrix(kind, X[rows].double(), X.double(), ls, 1.0, x1_eq_x2=False, direct=True))
+    return _KROWS[case]
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "split"])
+@pytest.mark.parametrize("case", list(CASES))
+def test_wide_clouds_stay_on_the_gram_kernels(case, split, dev, monkeypatch):
+    from gpytorch_amd import backend as B
+
+    monkeypatch.setattr(B, "SPLIT_CONTRACTION", split)
+    cloud, kind, ls = CASES[case]
+    n = N_CASE
+    X, rows, Krows = _rows_and_kernel(case)
+    Xd = X.to(dev)
+    xp = B.prep_points(kind, Xd, torch.tensor([ls]), Xd.mean(0))
+    assert xp.zmax2 > 32.0                                    # outside the cloud-centred bound ...
+    assert B.gram_mode(xp, xp) == 2                           # ... inside the block-centred one
+    sv = xp.sorted_view()
+    assert sv.r2 <= B.GRAM_MAX_BLOCK_SQRADIUS and (cloud == "uniform") == (sv.n_compact == n)
+    for t in (1, 2, 4, 8, 11, 16, 17, 33, 65):
+        assert B.kv_flags(xp, xp, t) == (B.KV_GRAM | (B.KV_SPLIT if split else 0))
+        V = torch.randn(n, t, generator=torch.Generator().manual_seed(t))
+        out_t = B.kv(xp, xp, B.to_probe_major(V.to(dev)))
+        got = out_t[:, rows.to(dev)].t().double().cpu()
+        ref = Krows @ V.double()
+        assert rel_err(got, ref) < 2e-5, (case, t, rel_err(got, ref))
+    # the K entries themselves (dense rows through the SAME fused product: V = unit vectors of a few columns j near the sampled rows)
+    cols = rows[:64]
+    E = torch.zeros(n, cols.numel())
+    E[cols, torch.arange(cols.numel())] = 1.0
+    got = B.kv(xp, xp, B.to_probe_major(E.to(dev)))[:, rows.to(dev)].t().double().cpu()
+    assert float((got - Krows[:, cols]).abs().max()) < 2e-5
+
+
+def test_rq_wide_cloud_and_rectangular_product(dev):
+    from gpytorch_amd import backend as B
+
+    n, m, ls, alpha = 9000, 5000, 0.06, 1.3
+    X1, X2 = _cloud("uniform", n, seed=1), _cloud("uniform", m, seed=2)
+    sh = X1.mean(0).to(dev)
+    p1 = B.prep_points("rq", X1.to(dev), torch.tensor([ls]), sh, alpha)
+    p2 = B.prep_points("rq", X2.to(dev), torch.tensor([ls]), sh, alpha)
+    assert B.gram_mode(p1, p2) == 2
+    for t in (3, 12, 40):
+        V = torch.randn(m, t, generator=torch.Generator().manual_seed(t))
+        got = B.from_probe_major(B.kv(p1, p2, B.to_probe_major(V.to(dev))), n)
+        ref = OK.rq(X1.double(), X2.double(), ls, alpha, x1_eq_x2=False, direct=True) @ V.double()
+        assert rel_err(got, ref) < 3e-5, t
+    # epilogue (scale, noise, per-point diagonal) after the rows were taken back to the original order
+    V = torch.randn(n, 6, generator=torch.Generator().manual_seed(9))
+    dvec = torch.rand(B.round_up(n, 4), generator=torch.Generator().manual_seed(3)).to(dev)
+    vt = B.to_probe_major(V.to(dev))
+    got = B.from_probe_major(B.kv(p1, p1, vt, scale=torch.tensor([1.7], device=dev), dscale=torch.tensor([0.3], device=dev), vd=vt, dvec=dvec), n)
+    Kd = OK.rq(X1.double(), X1.double(), ls, alpha, x1_eq_x2=True, direct=True)
+    ref = 1.7 * (Kd @ V.double()) + (0.3 + dvec[:n].double().cpu()).unsqueeze(-1) * V.double()
+    assert rel_err(got, ref) < 3e-5
+
+
+def test_cg_solve_and_mll_on_a_wide_cloud(dev):
+    """mBCG with the Hilbert-ordered slabs (linear_cg takes the rows back every iteration) and the whole MLL through the model API, with
+    gradients incl. the inputs (kv_grad2 on the sorted rows), against dense float64."""
+    import gpytorch_amd as g
+    from gpytorch_amd import backend as B
+
+    n, d, ls = 4096, 2, 0.06
+    X, y = make_data(n, d)
+    Xd = X.float().to(dev).requires_grad_(True)
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ZeroMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel())
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood().to(dev)
+    m = M(Xd, y.float().to(dev), lik).to(dev)
+    m.covar_module.base_kernel.lengthscale, m.covar_module.outputscale, lik.noise = ls, 1.2, 0.05
+    op = lik(m.train()(Xd)).lazy_covariance_matrix
+    p1, _ = op.kernel_op.prepared()
+    assert B.gram_mode(p1, p1) == 2
+    Kh = 1.2 * OK.rbf(X, X, ls, x1_eq_x2=True, direct=True) + 0.05 * torch.eye(n, dtype=torch.float64)
+    S = g.settings
+    with torch.no_grad(), S.max_cholesky_size(0), S.cg_tolerance(1e-4), S.max_preconditioner_size(0):
+        sol = op.solve(y.float().to(dev).unsqueeze(-1))
+    assert rel_err(sol, torch.linalg.solve(Kh, y.unsqueeze(-1))) < 1e-3
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    lik.train()
+    with S.max_cholesky_size(0), S.cg_tolerance(1e-5), S.num_trace_samples(300), S.max_preconditioner_size(0):
+        torch.manual_seed(0)
+        val = mll(m(Xd), m.train_targets)
+        val.backward()
+    p = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (ls, 1.2, 0.05)]
+    X64 = X.clone().requires_grad_(True)
+    ref = OG.dense_log_prob(p[1] * OK.rbf(X64, X64, p[0], x1_eq_x2=False, direct=True) + p[2] * torch.eye(n, dtype=torch.float64), y) / n
+    gref = torch.autograd.grad(ref, p + [X64])
+    assert abs(float(val) - float(ref)) < 5e-3 * max(1.0, abs(float(ref)))
+    sp = lambda v: 1.0 - math.exp(-v)  # noqa: E731
+    got = torch.tensor([float(m.covar_module.base_kernel.raw_lengthscale.grad.sum()), float(m.covar_module.raw_outputscale.grad.sum()),
+                        float(lik.noise_covar.raw_noise.grad.sum())], dtype=torch.float64)
+    want = torch.tensor([float(gref[0]) * sp(ls), float(gref[1]) * sp(1.2), float(gref[2]) * sp(0.05 - 1e-4)], dtype=torch.float64)
+    assert float((got - want).norm() / want.norm()) < 0.1, (got, want)
+    gx = Xd.grad.double().cpu()
+    assert float((gx - gref[3]).norm() / gref[3].norm()) < 0.1
+
+
+def test_posterior_with_love_on_a_wide_cloud(dev):
+    """Mean-cache CG + LOVE Lanczos fused into two-column products (operators.solve_and_root_inv) with block-centred slabs."""
+    import gpytorch_amd as g
+
+    n, ns, ls = 4096, 200, 0.06
+    X, y = make_data(n + ns, 2)
+    Xt, yt, Xs = X[:n], y[:n], X[n:]
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ZeroMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel())
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood().to(dev)
+    m = M(Xt.float().to(dev), yt.float().to(dev), lik).to(dev)
+    m.covar_module.base_kernel.lengthscale, m.covar_module.outputscale, lik.noise = ls, 1.0, 0.1
+    m.eval()
+    lik.eval()
+    S = g.settings
+    torch.manual_seed(1)
+    with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.fast_pred_var(), S.max_root_decomposition_size(300), S.max_preconditioner_size(0):
+        pred = m(Xs.float().to(dev))
+        mu, var = pred.mean, pred.variance
+    Kh = OK.rbf(Xt, Xt, ls, x1_eq_x2=True, direct=True) + 0.1 * torch.eye(n, dtype=torch.float64)
+    Ks = OK.rbf(Xs, Xt, ls, x1_eq_x2=False, direct=True)
+    Lc = torch.linalg.cholesky(Kh)
+    mu_ref = Ks @ torch.cholesky_solve(yt.unsqueeze(-1), Lc).squeeze(-1)
+    var_ref = 1.0 - torch.linalg.solve_triangular(Lc, Ks.t(), upper=False).pow(2).sum(0)
+    assert rel_err(mu, mu_ref) < 2e-3
+    assert float(((var.double().cpu() - var_ref).abs() / var_ref).max()) < 0.05
+
+
+def test_fallback_outside_the_block_bound_warns(dev):
+    """A handful of points spread over hundreds of lengthscales: no run of the Hilbert order is compact -> direct-difference kernels, with a warning."""
+    from gpytorch_amd import backend as B
+
+    B._warned_fallback.clear()
+    X = _cloud("uniform", 600)
+    xp = B.prep_points("rbf", X.to(dev), torch.tensor([0.002]), X.mean(0).to(dev))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert B.kv_flags(xp, xp, 11) == 0
+    assert any("direct-difference" in str(w.message) for w in rec)
+    V = torch.randn(600, 3, generator=torch.Generator().manual_seed(0))
+    got = B.from_probe_major(B.kv(xp, xp, B.to_probe_major(V.to(dev))), 600)
+    ref = OK.rbf(X.double(), X.double(), 0.002, x1_eq_x2=True, direct=True) @ V.double()
+    assert rel_err(got, ref) < 2e-5

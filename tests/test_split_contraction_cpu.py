@@ -147,3 +147,45 @@ def test_operand_layout_of_the_split_kernel():
         for h in range(2):
             rows = [16 * mf + 4 * h + q for q in range(4)] + [16 * mf + 8 + 4 * h + q for q in range(4)]
             assert rows == [((8 * mf + e) & 3) + 8 * ((8 * mf + e) >> 2) + 4 * h for e in range(8)]
+
+
+def test_sorted_view_host_logic():
+    """backend.SortedView (Hilbert order, un-sort index, chunk centres, block radius) on CPU tensors: the permutation round-trips, the
+    centres are the chunk means, a clustered cloud gets compact blocks while the same points in random order do not."""
+    from gpytorch_amd import backend as B
+
+    g = torch.Generator().manual_seed(0)
+    n, d = 5000, 3
+    z = torch.rand(n, d, generator=g) * 40.0
+    xp = torch.zeros(n, 4)
+    xp[:, :d] = z
+    pp = B.PreparedPoints(xp, n, d, 4, "rbf")
+    sv = pp.sorted_view()
+    assert torch.equal(sv.xs, xp[sv.perm])
+    ld = B.round_up(n, 4)
+    v = torch.randn(2, ld, generator=g)
+    v_sorted = torch.zeros_like(v)
+    v_sorted[:, :n] = v[:, :n][:, sv.perm]
+    assert torch.equal(v_sorted.index_select(1, sv.inv_pad)[:, :n], v[:, :n])
+    assert torch.allclose(sv.centers[3], sv.xs[3 * 128 : 4 * 128].mean(0))
+    # every compact group respects the radius bound; wide groups (if any) sit behind the compact region
+    assert sv.r2 <= B.GRAM_MAX_BLOCK_SQRADIUS and sv.n_compact % 512 == 0 or sv.n_compact == n
+    dense = torch.rand(200_000, 3, generator=g) * 17.0          # U[0,1]^3 at lengthscale 0.05: every 512-point run is compact
+    xpd = torch.zeros(200_000, 4)
+    xpd[:, :3] = dense
+    svd = B.PreparedPoints(xpd, 200_000, 3, 4, "rbf").sorted_view()
+    assert svd.n_compact == 200_000 and svd.r2 < B.GRAM_MAX_BLOCK_SQRADIUS
+    gauss = torch.randn(100_001, 3, generator=g) * 2.83         # N(0, 1) inputs at lengthscale 0.3: the tails are wide groups
+    xpg = torch.zeros(100_001, 4)
+    xpg[:, :3] = gauss
+    svg = B.PreparedPoints(xpg, 100_001, 3, 4, "rbf").sorted_view()
+    assert 0 < 100_001 - svg.n_compact < 0.2 * 100_001 and svg.n_compact % 512 == 0
+    assert sorted(svg.perm.tolist()) == list(range(100_001))
+    # compact region: the radius bound, recomputed here for the 512-row blocks with the kernels' centre formula
+    blk = svg.xs[: svg.n_compact].reshape(-1, 512, 4)
+    cen = svg.centers[: svg.n_compact // 128].reshape(-1, 4, 4).mean(1, keepdim=True)
+    assert float((blk - cen).pow(2).sum(-1).max()) <= B.GRAM_MAX_BLOCK_SQRADIUS * (1 + 1e-5)
+    # Hilbert order: consecutive cells of a full grid are face neighbours (no jumps, unlike the Z-order curve)
+    grid = torch.stack(torch.meshgrid(*[torch.arange(8.0)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    pg = grid[B.hilbert_order(grid, bits=3)]
+    assert float((pg[1:] - pg[:-1]).abs().sum(-1).max()) == 1.0
