@@ -81,9 +81,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // of a tile generates the first block of the next one.
 // ABL (ablation builds of libgpamd_tune.so only; 0 in the product; 6 = register prefetch of the next tile, 7 = one wave per SIMD, 8 = no sched_barrier pinning, 10 = Gram MFMA one step further ahead): 1 no generation VALU, 2 no contraction MFMAs, 3 V planes staged
 // once (no global loads / LDS writes per tile; barriers stay), 4 as 3 and no barriers, 5 A operands read once per tile
-template <int KIND, int D, int CT, int NI, int EX, int ABL = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ABL == 7 ? 1 : 2, ABL == 7 ? 1 : 2)))
+// NW: waves per workgroup (row block = NW * NI * 32 rows sharing one staged V tile); OCC: resident waves per SIMD the allocator is held to.
+template <int KIND, int D, int CT, int NI, int EX, int ABL = 0, int NW = 4, int OCC = 2>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(ABL == 7 ? 1 : OCC, ABL == 7 ? 1 : OCC)))
 void kv_gramh_kernel(KvhArgs ka) {
+  constexpr int NT = 64 * NW;   // threads per workgroup
   const KvArgs& a = ka.a;
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;
@@ -92,7 +94,7 @@ void kv_gramh_kernel(KvhArgs ka) {
   // V planes / x rows of the next tile prefetched into registers during compute: measured, no gain (86.2 vs 86.3 ms at n = 500 000,
   // 64 columns, profiles/r02_s22_kgh_ablate.json) -- what staging costs is LDS-write and L2 throughput, not latency; tune builds only
   constexpr bool VPF = (ABL == 6);
-  constexpr bool PF = NI * CT <= 4 && KH <= 2 && !VPF;   // A operands of block jb + 32 fetched during block jb (16 CT more registers)
+  constexpr bool PF = NI * CT <= 4 && KH <= 2 && !VPF && OCC <= 2;   // A operands of block jb + 32 fetched during block jb (16 CT more registers)
   __shared__ __attribute__((aligned(16))) _Float16 Vhs[TC * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 Vls[TC * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 Xh[2 * XHS];        // [buf][kh][j][16] split augmented x_j rows
@@ -107,9 +109,9 @@ void kv_gramh_kernel(KvhArgs ka) {
   const int s = unit / a.nrb, rb = unit - s * a.nrb;
   const int jbeg = s * a.jchunk;                  // multiple of BN
   const int jend = min(a.m, jbeg + a.jchunk);
-  const int ibase = rb * (4 * NI * 32) + wave * (NI * 32);
+  const int ibase = rb * (NW * NI * 32) + wave * (NI * 32);
   float cz[DP];   // centre of this workgroup's row block (zero unless the host passed chunk centres: gram_f16.hpp)
-  load_center<DP>(a.Xc, ibase - wave * (NI * 32), 4 * NI * 32, a.n, cz);
+  load_center<DP>(a.Xc, ibase - wave * (NI * 32), NW * NI * 32, a.n, cz);
 
   f16x8 bq[NI][KH];
 #pragma unroll
@@ -134,7 +136,7 @@ void kv_gramh_kernel(KvhArgs ka) {
       for (int r = 0; r < 16; ++r) acc[ni][ct][r] = 0.f;
   }
 
-  constexpr int VQ = TC * (BN / 8) / 256;   // 16-byte chunks per thread and plane (= 2 CT)
+  constexpr int VQ = TC * (BN / 8) / NT;   // 16-byte chunks per thread and plane (= 2 CT with four waves)
 
   // split x_j rows + extra column of the tile starting at j0 -> buffer `buf` (rows beyond jend: zero -> k = 2^KSHIFT, V = 0).
   // Two halves so that the global loads can be issued a whole tile of compute ahead of the LDS writes (VPF).
@@ -271,7 +273,7 @@ void kv_gramh_kernel(KvhArgs ka) {
     const int64_t jc = min((int64_t)j0, ka.ldh - BN);   // past the chunk end: any in-bounds tile (never consumed)
 #pragma unroll
     for (int rr = 0; rr < VQ; ++rr) {
-      const int idx = tid + 256 * rr;
+      const int idx = tid + NT * rr;
       const int c = idx / (BN / 8), q = idx % (BN / 8);
       const int64_t off = (int64_t)c * ka.ldh + jc + 8 * q;
       pvh[rr] = *reinterpret_cast<const u32x4*>(ka.Vh + off);
@@ -295,7 +297,7 @@ void kv_gramh_kernel(KvhArgs ka) {
       store_x(buf ^ 1);
 #pragma unroll
       for (int rr = 0; rr < VQ; ++rr) {
-        const int idx = tid + 256 * rr;
+        const int idx = tid + NT * rr;
         const int c = idx / (BN / 8), q = idx % (BN / 8);
         *reinterpret_cast<u32x4*>(&Vhs[c * LDH + 8 * q]) = pvh[rr];
         *reinterpret_cast<u32x4*>(&Vls[c * LDH + 8 * q]) = pvl[rr];

@@ -304,8 +304,8 @@ def linear_cg(
             if KV_EVENT_LOG is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(torch.cuda.current_stream(dev))
-            Pq, Sq = P, S
             if kv_partials is None:
+                Pq, Sq = P, S
                 unsort = B.kv_partials_sorted(x, x, Dt, t, flags, P, ld, S, jc, done_ptr, st)
                 if unsort is not None:
                     # block-centred Gram expansion (wide clouds): the slabs hold the rows in Hilbert order -> sum them, take the rows back to

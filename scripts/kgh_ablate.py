@@ -32,7 +32,8 @@ colmul = torch.ones(80, device=dev)
 S, jc, _ = B.kv_plan("rbf", n, n, 3, 64, B.KV_GRAM | B.KV_SPLIT, ld)
 P = torch.empty(S * 65 * ld, device=dev)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-names = {0: "full", 1: "no generation VALU", 2: "no contraction MFMAs", 3: "V planes staged once", 4: "staged once, no barriers", 5: "A operands from one block", 6: "next tile prefetched into registers", 7: "one wave per SIMD", 8: "no sched_barrier pinning", 10: "Gram MFMA one step further ahead"}
+names = {0: "full", 1: "no generation VALU", 2: "no contraction MFMAs", 3: "V planes staged once", 4: "staged once, no barriers", 5: "A operands from one block", 6: "next tile prefetched into registers", 7: "one wave per SIMD", 8: "no sched_barrier pinning", 10: "Gram MFMA one step further ahead",
+         110: "eight waves per workgroup", 120: "three waves per SIMD, one row tile per wave", 130: "eight waves per workgroup, four row tiles"}
 out = []
 for case in cases:
     abl, ni = case[0], case[1]

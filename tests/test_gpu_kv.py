@@ -233,3 +233,48 @@ def test_gram_split_is_consistent_on_rounding_ties(dev):
                 assert float((cols - K[:, idx]).abs().max()) < 3e-6, (flags, j0)
     finally:
         B.FORCE_KV_FLAGS = None
+
+
+_KROWS_CACHE = {}
+
+
+@pytest.mark.parametrize("d", [1, 3, 6, 10])
+@pytest.mark.parametrize("kind", ["rbf", "matern32", "matern52", "rq"])
+def test_every_family_on_every_column_count_kernel_at_a_full_chip_size(kind, d, dev):
+    """Every covariance family on EVERY column-count kernel (1, 2, 4, 8 VALU columns; the 4- and 16-column matrix-pipe tiles; the 32-column
+    tiles; both contraction paths) at n = 60 000 -- enough workgroups that several waves per SIMD contend for the matrix pipe.
+    Regression for a round-2 defect that the RBF-exhaustive shape sweep missed: kv_gramv_kernel<Matern, d = 3, t = 1> read its
+    VGPR-destination MFMA results too early (csrc/gram_f16.hpp ``mfma_result_fence``) and returned 4 % errors on a quarter of the rows,
+    differently on every run -- only at sizes where the chip is full, only for the families whose first consumer follows the MFMA at once."""
+    from gpytorch_amd import backend as B
+
+    n = 60_000
+    g = torch.Generator().manual_seed(d)
+    X = torch.rand(n, d, generator=g)
+    ls = {1: 0.25, 3: 0.6, 6: 1.0, 10: 1.4}[d]
+    par = 1.3 if kind == "rq" else None
+    rows = torch.arange(0, n, 127)
+    key = (kind, d)
+    if key not in _KROWS_CACHE:
+        _KROWS_CACHE.clear()
+        if kind == "rq":
+            _KROWS_CACHE[key] = OK.rq(X[rows].double(), X.double(), ls, par, x1_eq_x2=False, direct=True)
+        else:
+            _KROWS_CACHE[key] = OK.kernel_matrix(kind, X[rows].double(), X.double(), ls, 1.0, x1_eq_x2=False, direct=True)
+    Kr = _KROWS_CACHE[key]
+    Xd = X.to(dev)
+    xp = B.prep_points(kind, Xd, torch.tensor([ls]), Xd.mean(0), par)
+    assert B.gram_mode(xp, xp) == 1
+    for split in (True, False):
+        B.SPLIT_CONTRACTION = split
+        try:
+            for t in (1, 2, 3, 4, 5, 8, 9, 11, 12, 16, 17, 24, 32, 33):
+                if not split and t in (5, 9, 33):
+                    continue   # same kernels as the neighbouring counts on the f32 path
+                V = torch.randn(n, t, generator=torch.Generator().manual_seed(t))
+                ref = Kr @ V.double()
+                for rep in range(2):   # the defect was timing dependent
+                    out = B.kv(xp, xp, B.to_probe_major(V.to(dev)))[:, rows.to(dev)].t().double().cpu()
+                    assert rel_err(out, ref) < 2e-5, (kind, d, t, split, rep, rel_err(out, ref))
+        finally:
+            B.SPLIT_CONTRACTION = None
