@@ -32,7 +32,9 @@ namespace gpamd {
 // allocator is told to: left alone it parks the 16 distance registers in AGPRs (v_accvgpr_read before every v_exp)
 // and lands at 180.
 template <int KIND, int D, int CT, int NI, int EX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT <= 2 ? 3 : 2, CT <= 2 ? 3 : 2)))
+// (CT = 1 runs four row tiles per wave: 64 accumulators + 64 distance registers do not fit 168 registers -- 6..44 spilled, and with the extra
+// column the Matern-3/2 / RQ instantiations returned wrong rows on a full chip, tests/test_gpu_kv.py regression sweep -> two waves there)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 2 || (CT == 1 && NI < 4)) ? 3 : 2, (CT == 2 || (CT == 1 && NI < 4)) ? 3 : 2)))
 void kv_gram_kernel(KvArgs a) {
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;    // 32x32x16 f16 MFMAs per 32x32 block of squared distances
@@ -161,6 +163,7 @@ void kv_gram_kernel(KvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) kk[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq[ni][kh], kk[ni], 0, 0, 0);
       }
+      mfma_result_fence();   // with the register cap above the distance block lives in VGPRs and the VALU reads it next (gram_f16.hpp)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll

@@ -31,7 +31,9 @@ constexpr int KG16_NI = 4;               // 32-row tiles per wave
 constexpr int KG16_BM = 4 * KG16_NI * 32;
 
 template <int KIND, int D, int EX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GramF16<D>::KH == 1 ? 3 : 2, GramF16<D>::KH == 1 ? 3 : 2))) void kv_gram16_kernel(KvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GramF16<D>::KH == 1 && !EX) ? 3 : 2, (GramF16<D>::KH == 1 && !EX) ? 3 : 2))) void kv_gram16_kernel(KvArgs a) {
+  // (three waves per SIMD only where that fits WITHOUT spilling: the extra-column variants needed ~50 scratch registers under the 168-register
+  // cap, and the Matern instantiation of exactly that variant returned wrong rows on a full chip -- tests/test_gpu_kv.py regression sweep)
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;
   constexpr int BN = KG16_BN, LDT = KG16_LDT, NI = KG16_NI, T = 16;
