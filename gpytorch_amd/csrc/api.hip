@@ -85,14 +85,16 @@ bool gram_ok(int kind, int flags);
 // tile above), GPAMD_KV_G4 sends 9..12 columns to kv_gram4 with three groups
 // small: few output rows (n < KGH_SMALL_N) -- the split kernels then take ONE 32-row tile per wave (128 rows per workgroup) so that
 // the launch still spreads over the chip
-KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool small = false) {  // t <= 129 handled per launch group; light: RBF, d <= 3
+KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool small = false, int dk = 16) {   // dk: kernel dims (light: dk <= 3 and RBF)  // t <= 129 handled per launch group; light: RBF, d <= 3
   KvVariant v{};
   const bool wide = flags & GPAMD_KV_WIDE;
   if (gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KGH_GROUP + 1) {
     v.split = true;
     v.ex = (t % 32 == 1) ? 1 : 0;
     v.ct = (t - v.ex + 31) / 32;
-    v.ni = small ? 1 : kgh_ni(v.ct);
+    // four row tiles per wave with two column tiles ("lean", kv_gramh.hpp) where they fit: one Gram MFMA per block (dk <= 3) and, with the extra
+    // column, the light generation of the RBF only (the other families would spill 7..15 registers there)
+    v.ni = small ? 1 : kgh_ni(v.ct, (v.ex && !light) ? 16 : dk);
     v.bm = kgh_bm(v.ni);
     v.bn = KGH_BN;
   } else if (gram && !wide && t >= 5 && t <= 24) {
@@ -250,7 +252,7 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // full (efficiency = units / (rounds * slots)), keeping every chunk >= 16 LDS tiles (per-unit prologue
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
   const int cap = group_cap(kind, flags);
-  KvVariant v = pick_variant(t > cap + 1 ? cap : t, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3, n < KGH_SMALL_N);
+  KvVariant v = pick_variant(t > cap + 1 ? cap : t, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3, n < KGH_SMALL_N, kernel_dims(d));
   const int mode = kv_mode(kind, flags, d, v);
   variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
@@ -347,7 +349,7 @@ int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const
   int mulslot = 0;    // multiplier slots used so far
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0, cap);
-    KvVariant v = pick_variant(tg, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3, n < KGH_SMALL_N);
+    KvVariant v = pick_variant(tg, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3, n < KGH_SMALL_N, dk);
     const int mode = kv_mode(kind, flags, d, v);
     variant_geometry(mode, &v);
     KvhArgs ka;

@@ -42,7 +42,7 @@ constexpr int KGH_VEXP = 14;            // max |V_c| * scale_c in [2^13, 2^14)
 constexpr int KGH_GROUP = 64;           // columns per launch group (+ 1 extra VALU column)
 constexpr int KGH_SMALL_N = 16384;      // fewer output rows: one row tile per wave (NI = 1), four times as many workgroups
 constexpr int KGH_MIN_COLS = 5;         // fewer columns: the VALU-contraction kernel (kv_gramv.hpp) wins
-constexpr int kgh_ni(int ct) { return ct == 1 ? 4 : 2; }   // 32-row tiles per wave: 16 NI CT accumulators
+constexpr int kgh_ni(int ct, int d = 16) { return (ct == 1 || d <= 3) ? 4 : 2; }   // 32-row tiles per wave: 16 NI CT accumulators (d: kernel dims)
 inline int kgh_bm(int ni) { return 4 * ni * 32; }
 
 struct KvhArgs {
