@@ -211,6 +211,15 @@ def kind_args(xp: PreparedPoints):
     return KIND_IDS[xp.kind], float(xp.param) if xp.param is not None else 0.0
 
 
+def _split_on() -> bool:
+    """The split-operand contraction (f16 matrix pipe at f32 accuracy) is selected: ``settings.split_contraction`` unless a test forces it."""
+    if SPLIT_CONTRACTION is not None:
+        return bool(SPLIT_CONTRACTION)
+    from . import settings
+
+    return settings.split_contraction.on()
+
+
 def gram_mode(x1: PreparedPoints, x2: PreparedPoints) -> int:
     """How the Gram-form kernels may evaluate the squared distances of k(x1, x2): 1 = cloud-centred quadratic expansion (both clouds
     within max |z|^2 <= 32 of the common origin), 2 = BLOCK-centred expansion on the Hilbert-sorted rows of x1 (any cloud width: the
@@ -249,12 +258,10 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
     if gram_mode(x1, x2) == 0:
         return 0
     if SPLIT_CONTRACTION is None:
-        from . import settings
-
         # no size rule: the three extra launches of the pre-pass do not make small products slower -- measured, mBCG per iteration
         # with the fp32-MFMA contraction instead: 107 vs 57 us at n = 2000, 231 vs 105 us at n = 5000, 229 vs 144 us at n = 20 000
         # (eleven columns; profiles/r02_s33_cg_small_n_fp32_contraction.json vs r02_s30_*)
-        split = settings.split_contraction.on()
+        split = _split_on()
     else:
         split = SPLIT_CONTRACTION
     return KV_GRAM | (KV_SPLIT if split else 0)
@@ -644,10 +651,21 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
         lt = lt[:, : x1.n].index_select(1, x1.sorted_view().perm).contiguous()
         if lt.shape[1] % 4:
             lt = torch.nn.functional.pad(lt, (0, 4 - lt.shape[1] % 4))
+    # W = L^T R on the f16 matrix pipe at f32 accuracy (kv_grad2.hpp WSPLIT; the same switch as the K*V contraction).  The per-dimension
+    # mode keeps 40 more registers live and spills from d = 8 on: those shapes stay on the fp32-MFMA contraction
+    split = _split_on() and (x1.d <= 6 or (iso and not want_gz1))
+    sws, ns = None, 0
+    if split:
+        ns = int(L.gpamd_kv_grad2_split_workspace_floats(x1.n, x2.n))
+        sws = torch.empty(ns, device=dev, dtype=torch.float32)
+        if lt.stride(0) % 4 or lt.data_ptr() % 16:
+            lt = torch.nn.functional.pad(lt, (0, (-lt.shape[1]) % 4)).contiguous()
+        if rt.stride(0) % 4 or rt.data_ptr() % 16:
+            rt = torch.nn.functional.pad(rt, (0, (-rt.shape[1]) % 4)).contiguous()
     check(
         L.gpamd_kv_grad2_f32(
             *kind_args(x1), _ptr(X1), x1.n, _ptr(x2.xp), x2.n, x1.d, _ptr(Xc), _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
-            1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, _stream(dev),
+            1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, KV_SPLIT if split else 0, _ptr(sws), ns, _stream(dev),
         ),
         "kv_grad2",
     )

@@ -19,8 +19,15 @@
 //     (the host applies dz/dx = coef / l_q and theta).  The combination is carried in float64 per j tile.
 //   * single-lengthscale hyper-gradients without input gradients (MODE 0) need only sum A_ij S_ij: one fma per pair.
 // Host policy as for kv_gram.hpp: max |z|^2 <= 32, never Matern nu = 1/2 (kv_grad.hpp remains the fallback).
+//
+// WSPLIT = 1 (the library default, flag GPAMD_KV_SPLIT): the W^T = R L^T tiles run on the f16 matrix pipe at f32 accuracy, exactly like the
+// contraction of kv_gramh.hpp -- both vector blocks are split into hi/lo f16 planes by a pre-pass (kv_wsplit.hpp: row-major [row][80],
+// per-column power-of-two scales with a constant product) and a 32 x 32 tile costs 5 k-steps x 3 products = 15 v_mfma_f32_32x32x16_f16
+// (480 cycles) in place of 33 v_mfma_f32_32x32x2_f32 (2112 cycles) at 65 columns.  The L operands of a wave's 32 rows stay in registers
+// for the whole kernel (40 VGPRs); only the R planes of a 64-row j step go through LDS.
 #pragma once
 #include "gram_f16.hpp"
+#include "kv_wsplit.hpp"
 
 namespace gpamd {
 
@@ -39,7 +46,16 @@ struct Grad2Args {
   float kparam;        // covariance shape parameter (RQ: alpha)
   float* Px;           // optional [S][DP][ldx] partial slabs of Gz1 (probe-major: one coordinate per row) or nullptr
   int64_t ldx, pxstride;
+  // WSPLIT: hi / lo planes of the scaled vector blocks, row-major [rows_pad][WS_CP] (zero rows beyond n / m), and the device scalar that
+  // restores W (kv_wsplit.hpp)
+  const _Float16* Lh = nullptr;
+  const _Float16* Ll = nullptr;
+  const _Float16* Rh = nullptr;
+  const _Float16* Rl = nullptr;
+  const float* wscale = nullptr;
 };
+
+constexpr int G2_CPL = WS_CP + 8;   // LDS row stride (f16) of the R planes: 176 B -> conflict-free ds_read_b128
 
 constexpr int G2_BN = 64;    // j rows per step (two 32-row MFMA tiles)
 constexpr int G2_MAXT = 66;  // columns per launch (host: kvm_grad2.hip)
@@ -70,19 +86,21 @@ __device__ __forceinline__ void cov_and_dcov(float s, float p, float& k, float& 
 }
 
 // MODE 0: one lengthscale, no input gradients (VALU: sum A S).   MODE 1: per-dimension sums + optional input gradients.
-template <int KIND, int D, int MODE>
+template <int KIND, int D, int MODE, int WSPLIT = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void kv_grad2_kernel(Grad2Args a) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;
   constexpr int BN = G2_BN;
   constexpr int NZ = 1 + 2 * D, GZ = (NZ + 3) / 4, LDZ = BN + 4;
-  const int RS = a.rs, TH4 = a.th4;
+  constexpr int NK = WS_CP / 16, CPL = G2_CPL;                      // WSPLIT: k-steps of 16 columns, LDS row stride of the R planes
+  const int RS = WSPLIT ? 0 : a.rs, TH4 = a.th4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5, l3 = lane & 3;
   float* Ls = dyn + (size_t)wave * 32 * RS;                       // [32 i][RS]: this wave's L tile, [h][c2] within a row
   float* Rs = dyn + (size_t)4 * 32 * RS;                          // [BN j][RS]
-  _Float16* Xh = reinterpret_cast<_Float16*>(Rs + (size_t)BN * RS);  // [KH][BN][16]
+  _Float16* Rsh = reinterpret_cast<_Float16*>(dyn);               // WSPLIT: [2 planes][BN j][CPL]
+  _Float16* Xh = WSPLIT ? Rsh + 2 * BN * CPL : reinterpret_cast<_Float16*>(Rs + (size_t)BN * RS);  // [KH][BN][16]
   float* Zs = reinterpret_cast<float*>(Xh + KH * BN * 16);        // [4*GZ][LDZ]  (MODE 1)
   __shared__ double red[4][2 + DP];
 
@@ -94,15 +112,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   const int i = i0 + l31;
 
   // zero the padded tiles once (columns >= t and the k-step padding stay zero for the whole kernel)
-  for (int e = tid; e < (4 * 32 + BN) * RS; e += 256) dyn[e] = 0.f;
+  if constexpr (!WSPLIT)
+    for (int e = tid; e < (4 * 32 + BN) * RS; e += 256) dyn[e] = 0.f;
   if constexpr (MODE == 1)
     for (int e = tid; e < 4 * GZ * LDZ; e += 256) Zs[e] = 0.f;
   __syncthreads();
-  // this wave's L tile: Ls[ic][h_c][c2] = L[c][i0 + ic], c = 2 c2 + h_c   (128-B coalesced rows of Lt)
-  for (int c = h; c < a.t; c += 2) {
-    float v = 0.f;
-    if (i < a.n) v = a.Lt[(int64_t)c * a.ldl + i];
-    Ls[l31 * RS + (c & 1) * TH4 + (c >> 1)] = v;
+  f16x8 lbh[WSPLIT ? NK : 1], lbl[WSPLIT ? NK : 1];   // WSPLIT: B operands (this lane's row i, k-group h) of all k-steps, kept for the whole kernel
+  if constexpr (WSPLIT) {
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {   // (the planes are zero-padded to whole 128-row blocks: no bounds check)
+      lbh[ks] = *reinterpret_cast<const f16x8*>(a.Lh + (int64_t)i * WS_CP + 16 * ks + 8 * h);
+      lbl[ks] = *reinterpret_cast<const f16x8*>(a.Ll + (int64_t)i * WS_CP + 16 * ks + 8 * h);
+    }
+  } else {
+    // this wave's L tile: Ls[ic][h_c][c2] = L[c][i0 + ic], c = 2 c2 + h_c   (128-B coalesced rows of Lt)
+    for (int c = h; c < a.t; c += 2) {
+      float v = 0.f;
+      if (i < a.n) v = a.Lt[(int64_t)c * a.ldl + i];
+      Ls[l31 * RS + (c & 1) * TH4 + (c >> 1)] = v;
+    }
   }
   float zi[DP];
   {
@@ -129,27 +157,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   // one point per thread of the first wave) are issued BEFORE the MFMA phase of step k and land in LDS after it -- with two
   // workgroups per CU nothing else would hide the ~2 us L2 latency of a synchronous stage (first build: 391 ms vs 242 ms for
   // the K*V of equal flops, profiles/r02_s3_grad_timing_first.json).
-  constexpr int NR = (G2_MAXT * (BN / 4) + 255) / 256;
+  constexpr int NR = WSPLIT ? (2 * BN * (WS_CP / 8)) / 256 : (G2_MAXT * (BN / 4) + 255) / 256;   // WSPLIT: 16-byte chunks of both planes
   f32x4 rreg[NR];
   float zreg[DP];
   auto fetch = [&](int j0) {
+    if constexpr (WSPLIT) {
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-      const int idx = tid + 256 * rr;
-      const int c = idx / (BN / 4), q = idx % (BN / 4);
-      const int j = j0 + 4 * q;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (c < a.t) {
-        const float* src = a.Rt + (int64_t)c * a.ldr + j;
-        if (j + 4 <= jend && ((a.ldr & 3) == 0)) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (j + e < jend) v[e] = src[e];
-        }
+      for (int rr = 0; rr < NR; ++rr) {   // chunk q: plane q / 640, row (q % 640) / 10, 16-byte column chunk q % 10 (planes zero-padded to whole tiles)
+        const int q = tid + 256 * rr;
+        const int pl = q / (BN * (WS_CP / 8)), rem = q % (BN * (WS_CP / 8));
+        const int row = rem / (WS_CP / 8), ck = rem % (WS_CP / 8);
+        const _Float16* src = (pl ? a.Rl : a.Rh) + (int64_t)(j0 + row) * WS_CP + 8 * ck;
+        rreg[rr] = *reinterpret_cast<const f32x4*>(src);
       }
-      rreg[rr] = v;
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) {
+        const int idx = tid + 256 * rr;
+        const int c = idx / (BN / 4), q = idx % (BN / 4);
+        const int j = j0 + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < a.t) {
+          const float* src = a.Rt + (int64_t)c * a.ldr + j;
+          if (j + 4 <= jend && ((a.ldr & 3) == 0)) {
+            v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (j + e < jend) v[e] = src[e];
+          }
+        }
+        rreg[rr] = v;
+      }
     }
     if (tid < BN) {
       const int j = j0 + tid;
@@ -166,14 +205,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   for (int j0 = jbeg; j0 < jend; j0 += BN) {
     __syncthreads();
     // ---- registers -> LDS: the R tile transposed to Rs[j][k-half][c/2], the split augmented x_j rows, the [1 | z | z^2] columns
+    if constexpr (WSPLIT) {
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-      const int idx = tid + 256 * rr;
-      const int c = idx / (BN / 4), q = idx % (BN / 4);
-      if (c < a.t) {
-        float* dst = Rs + (size_t)(4 * q) * RS + (c & 1) * TH4 + (c >> 1);
+      for (int rr = 0; rr < NR; ++rr) {
+        const int q = tid + 256 * rr;
+        const int pl = q / (BN * (WS_CP / 8)), rem = q % (BN * (WS_CP / 8));
+        const int row = rem / (WS_CP / 8), ck = rem % (WS_CP / 8);
+        *reinterpret_cast<f32x4*>(&Rsh[(pl * BN + row) * CPL + 8 * ck]) = rreg[rr];
+      }
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[(size_t)e * RS] = rreg[rr][e];
+      for (int rr = 0; rr < NR; ++rr) {
+        const int idx = tid + 256 * rr;
+        const int c = idx / (BN / 4), q = idx % (BN / 4);
+        if (c < a.t) {
+          float* dst = Rs + (size_t)(4 * q) * RS + (c & 1) * TH4 + (c >> 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[(size_t)e * RS] = rreg[rr][e];
+        }
       }
     }
     if (tid < BN) {
@@ -199,16 +248,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const float* lrow = Ls + l31 * RS + h * TH4;
     const float* r0row = Rs + (size_t)l31 * RS + h * TH4;
     const float* r1row = Rs + (size_t)(32 + l31) * RS + h * TH4;
-    // (fetching the operands of the next four k-steps ahead of the eight MFMAs was measured SLOWER: 368 vs 349 ms,
-    // profiles/r02_s6_grad_timing_operand_prefetch_slower.json -- the second resident wave already covers the LDS latency)
-    for (int c4 = 0; c4 < TH4; c4 += 4) {
-      const f32x4 lb = *reinterpret_cast<const f32x4*>(lrow + c4);
-      const f32x4 ra = *reinterpret_cast<const f32x4*>(r0row + c4);
-      const f32x4 rbv = *reinterpret_cast<const f32x4*>(r1row + c4);
+    if constexpr (WSPLIT) {
+      // A = R planes (rows j of the two 32-row halves), B = L planes (registers); the two small products first, then the leading one
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        w0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[e], lb[e], w0, 0, 0, 0);
-        w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(rbv[e], lb[e], w1, 0, 0, 0);
+      for (int ks = 0; ks < NK; ++ks) {
+        const f16x8 ah0 = *reinterpret_cast<const f16x8*>(&Rsh[(l31) * CPL + 16 * ks + 8 * h]);
+        const f16x8 al0 = *reinterpret_cast<const f16x8*>(&Rsh[(BN + l31) * CPL + 16 * ks + 8 * h]);
+        const f16x8 ah1 = *reinterpret_cast<const f16x8*>(&Rsh[(32 + l31) * CPL + 16 * ks + 8 * h]);
+        const f16x8 al1 = *reinterpret_cast<const f16x8*>(&Rsh[(BN + 32 + l31) * CPL + 16 * ks + 8 * h]);
+        w0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, lbl[ks], w0, 0, 0, 0);
+        w1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, lbl[ks], w1, 0, 0, 0);
+        w0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, lbh[ks], w0, 0, 0, 0);
+        w1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, lbh[ks], w1, 0, 0, 0);
+        w0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, lbh[ks], w0, 0, 0, 0);
+        w1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, lbh[ks], w1, 0, 0, 0);
+      }
+    } else {
+      // (fetching the operands of the next four k-steps ahead of the eight MFMAs was measured SLOWER: 368 vs 349 ms,
+      // profiles/r02_s6_grad_timing_operand_prefetch_slower.json -- the second resident wave already covers the LDS latency)
+      for (int c4 = 0; c4 < TH4; c4 += 4) {
+        const f32x4 lb = *reinterpret_cast<const f32x4*>(lrow + c4);
+        const f32x4 ra = *reinterpret_cast<const f32x4*>(r0row + c4);
+        const f32x4 rbv = *reinterpret_cast<const f32x4*>(r1row + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          w0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[e], lb[e], w0, 0, 0, 0);
+          w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(rbv[e], lb[e], w1, 0, 0, 0);
+        }
       }
     }
     // ---- squared distances of the same two blocks (Gram form)
@@ -292,14 +358,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     if (lane == 0) red[wave][q] = v;
   }
   __syncthreads();
-  if (tid <= DP + 1) a.part[(int64_t)unit * (2 + DP) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  const double wsc = WSPLIT ? (double)*a.wscale : 1.0;   // WSPLIT: the planes carry scaled vectors (kv_wsplit.hpp)
+  if (tid <= DP + 1) a.part[(int64_t)unit * (2 + DP) + tid] = wsc * (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
   if constexpr (MODE == 1) {
     if (a.Px) {
       float* Pout = a.Px + (int64_t)s * a.pxstride;
 #pragma unroll
       for (int q = 0; q < D; ++q) {
         const float tot = gx[q] + __shfl_xor(gx[q], 32, 64);
-        if (h == 0 && i < a.n) Pout[(int64_t)q * a.ldx + i] = tot;
+        if (h == 0 && i < a.n) Pout[(int64_t)q * a.ldx + i] = tot * (float)wsc;
       }
     }
   }

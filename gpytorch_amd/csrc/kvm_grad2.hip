@@ -13,6 +13,7 @@
 using namespace gpamd;
 namespace gpamd {
 extern thread_local char g_err[512];
+int grad2_launch_split(int kind, int dk, int mode, const Grad2Args& a, unsigned grid, hipStream_t st);   // kvm_grad3.hip
 }
 
 namespace {
@@ -43,13 +44,18 @@ int g2_num_cus() {
   return cus;
 }
 
-// column groups: whole groups of (maxcols - 2), the last one may take up to maxcols (so 65 = 32 + 33, 66 = 32 + 34)
-int g2_take(int rem) { return rem > g2_maxcols() ? g2_maxcols() - 2 : rem; }
-int g2_groups(int t) {
+// column groups: whole groups of (maxcols - 2), the last one may take up to maxcols (so 65 = 32 + 33, 66 = 32 + 34);
+// split-operand contraction: up to WS_CP = 80 columns per launch (five k-steps of 16 column slots)
+int g2_take(int rem, bool split = false) {
+  if (split) return rem > WS_CP ? WS_CP : rem;
+  return rem > g2_maxcols() ? g2_maxcols() - 2 : rem;
+}
+int g2_groups(int t, bool split = false) {
   int g = 0;
-  for (int rem = t; rem > 0; ++g) rem -= g2_take(rem);
+  for (int rem = t; rem > 0; ++g) rem -= g2_take(rem, split);
   return g;
 }
+int64_t pad_to(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 void g2_plan(int n, int m, int* S, int* jchunk, int* nrb) {
   *nrb = (n + 127) / 128;
@@ -132,9 +138,16 @@ int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d) {
   return (int64_t)g2_groups(t) * S * dp * ((n + 3) / 4 * 4);
 }
 
+int64_t gpamd_kv_grad2_split_workspace_floats(int n, int m) {
+  if (n <= 0 || m <= 0) return 0;
+  // hi + lo planes of L (rows padded to 128) and R (rows padded to 64), WS_CP f16 each; column maxima (2 x WS_CP) and scales (2 WS_CP + 1)
+  return (pad_to(n, 128) + pad_to(m, G2_BN)) * WS_CP + 4 * WS_CP + 8;
+}
+
 int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Lt, int64_t ldl,
                        const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
-                       int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, void* stream) {
+                       int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, int flags, float* sworkspace,
+                       int64_t sworkspace_floats, void* stream) {
   if (n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m || d < 1 || d > 16) {
     snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: bad arguments");
     return GPAMD_EINVAL;
@@ -146,17 +159,31 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
   const int dp = (d + 3) / 4 * 4, dk = kdims(d);
   int S, jc, nrb;
   g2_plan(n, m, &S, &jc, &nrb);
-  const int groups = g2_groups(t);
+  const bool split = (flags & GPAMD_KV_SPLIT) != 0;
+  const int groups = g2_groups(t, split);
   const int64_t units = (int64_t)nrb * S;
   const int64_t ldx = (n + 3) / 4 * 4;
   if (workspace_doubles < groups * units * (2 + dp)) return GPAMD_EWORKSPACE;
   if (Gz1t && (xworkspace_floats < (int64_t)groups * S * dp * ldx || ldg < n || ldg % 4)) return GPAMD_EWORKSPACE;
+  if (split && (!sworkspace || sworkspace_floats < gpamd_kv_grad2_split_workspace_floats(n, m) ||
+                (reinterpret_cast<uintptr_t>(sworkspace) & 15))) {
+    snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: the split-operand contraction needs a 16-byte aligned sworkspace of gpamd_kv_grad2_split_workspace_floats");
+    return GPAMD_EWORKSPACE;
+  }
   const int mode = (iso && !Gz1t) ? 0 : 1;
   hipStream_t st = (hipStream_t)stream;
+  // split-operand workspace: [Lh | Ll | Rh | Rl | colmax L | colmax R | scales]
+  const int64_t npad = pad_to(n, 128), mpad = pad_to(m, G2_BN);
+  _Float16* Lh = reinterpret_cast<_Float16*>(sworkspace);
+  _Float16* Ll = Lh + npad * WS_CP;
+  _Float16* Rh = Ll + npad * WS_CP;
+  _Float16* Rl = Rh + mpad * WS_CP;
+  unsigned* cmax = reinterpret_cast<unsigned*>(Rl + mpad * WS_CP);
+  float* scales = reinterpret_cast<float*>(cmax + 2 * WS_CP);
   int c0 = 0;
   for (int g = 0; g < groups; ++g) {
     const int rem = t - c0;
-    const int tg = g2_take(rem);
+    const int tg = g2_take(rem, split);
     Grad2Args a;
     a.X1 = X1p; a.X2 = X2p; a.Xc = X1c;
     a.Lt = Lt + (int64_t)c0 * ldl;
@@ -172,11 +199,30 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
     a.ldx = ldx;
     a.pxstride = (int64_t)dp * ldx;
     int rc = -2;
-    switch (kind) {
-      case GPAMD_RBF: rc = launch_kind<KIND_RBF>(dk, mode, a, (unsigned)units, st); break;
-      case GPAMD_MATERN32: rc = launch_kind<KIND_MATERN32>(dk, mode, a, (unsigned)units, st); break;
-      case GPAMD_MATERN52: rc = launch_kind<KIND_MATERN52>(dk, mode, a, (unsigned)units, st); break;
-      case GPAMD_RQ: rc = launch_kind<KIND_RQ>(dk, mode, a, (unsigned)units, st); break;
+    if (split) {
+      // pre-pass (kv_wsplit.hpp): column maxima of both blocks, scales with a constant product, the four planes
+      (void)hipMemsetAsync(cmax, 0, sizeof(unsigned) * 2 * WS_CP, st);
+      unsigned nbn = (unsigned)((n + 4095) / 4096), nbm = (unsigned)((m + 4095) / 4096);
+      if (nbn > 64) nbn = 64;
+      if (nbm > 64) nbm = 64;
+      hipLaunchKernelGGL(wsplit_colmax_kernel<0>, dim3(nbn, tg), dim3(256), 0, st, a.Lt, ldl, n, cmax);
+      hipLaunchKernelGGL(wsplit_colmax_kernel<0>, dim3(nbm, tg), dim3(256), 0, st, a.Rt, ldr, m, cmax + WS_CP);
+      hipLaunchKernelGGL(wsplit_scales_kernel<0>, dim3(1), dim3(128), 0, st, (const unsigned*)cmax, (const unsigned*)(cmax + WS_CP), tg, scales);
+      hipLaunchKernelGGL(wsplit_planes_kernel<0>, dim3((unsigned)((npad + 255) / 256), WS_CP / 8), dim3(256), 0, st, a.Lt, ldl, n, (int)npad, tg,
+                         (const float*)scales, Lh, Ll);
+      hipLaunchKernelGGL(wsplit_planes_kernel<0>, dim3((unsigned)((mpad + 255) / 256), WS_CP / 8), dim3(256), 0, st, a.Rt, ldr, m, (int)mpad, tg,
+                         (const float*)(scales + WS_CP), Rh, Rl);
+      a.Lh = Lh; a.Ll = Ll; a.Rh = Rh; a.Rl = Rl;
+      a.wscale = scales + 2 * WS_CP;
+      const int kid = kind == GPAMD_RBF ? KIND_RBF : (kind == GPAMD_MATERN32 ? KIND_MATERN32 : (kind == GPAMD_MATERN52 ? KIND_MATERN52 : KIND_RQ));
+      rc = grad2_launch_split(kid, dk, mode, a, (unsigned)units, st);
+    } else {
+      switch (kind) {
+        case GPAMD_RBF: rc = launch_kind<KIND_RBF>(dk, mode, a, (unsigned)units, st); break;
+        case GPAMD_MATERN32: rc = launch_kind<KIND_MATERN32>(dk, mode, a, (unsigned)units, st); break;
+        case GPAMD_MATERN52: rc = launch_kind<KIND_MATERN52>(dk, mode, a, (unsigned)units, st); break;
+        case GPAMD_RQ: rc = launch_kind<KIND_RQ>(dk, mode, a, (unsigned)units, st); break;
+      }
     }
     if (rc) return GPAMD_EUNSUPPORTED;
     c0 += tg;

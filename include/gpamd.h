@@ -217,9 +217,15 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
  * fixed s for the family's shape parameter (RQ alpha; 0 otherwise).  Gz1t == NULL: hyper-parameters only (xworkspace unused). ---- */
 int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d);
 int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d);
+/* flags & GPAMD_KV_SPLIT: the W = L^T R contraction runs on the f16 matrix pipe at f32 accuracy (hi/lo-split planes of both vector blocks,
+ * per-column power-of-two scales with a constant product; kv_wsplit.hpp) -- 15 v_mfma_f32_32x32x16_f16 per 32 x 32 tile instead of 33
+ * v_mfma_f32_32x32x2_f32 at 65 columns.  Needs sworkspace (16-byte aligned, gpamd_kv_grad2_split_workspace_floats floats); the plain
+ * workspaces sized for the same t cover either path. */
+int64_t gpamd_kv_grad2_split_workspace_floats(int n, int m);
 int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Lt, int64_t ldl,
                        const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
-                       int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, void* stream);
+                       int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, int flags, float* sworkspace,
+                       int64_t sworkspace_floats, void* stream);
 
 /* ---- float64 (the reference honours float64 inputs).  Same conventions with double buffers.  The fused MFMA K*V
  * kernels are float32-only; in float64 K @ V is formed from dense row blocks of K generated by

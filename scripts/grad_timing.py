@@ -39,12 +39,18 @@ for kind, d, ls in (("rbf", 3, 0.25), ("matern52", 10, 0.8)):
     rec["kv_ms"] = timed(lambda: B.kv(xp, xp, rt))
     rec["grad_direct_iso_ms"] = timed(lambda: B.kv_grad(xp, xp, lt, rt, iso=True))
     rec["grad_direct_ard_ms"] = timed(lambda: B.kv_grad(xp, xp, lt, rt, iso=False))
-    rec["grad2_iso_ms"] = timed(lambda: B.kv_grad2(xp, xp, lt, rt, iso=True))
-    rec["grad2_ard_ms"] = timed(lambda: B.kv_grad2(xp, xp, lt, rt, iso=False))
-    rec["grad2_ard_xgrad_ms"] = timed(lambda: B.kv_grad2(xp, xp, lt, rt, iso=False, want_gz1=True))
-    a = B.kv_grad(xp, xp, lt, rt, iso=False)
-    b, _ = B.kv_grad2(xp, xp, lt, rt, iso=False)
-    rec["max_rel_dev_vs_direct"] = float(((a - b[: a.numel()]).abs() / a.abs().clamp_min(1e-30))[: 1 + d].max())
+    for split in (False, True):   # W = L^T R on the fp32 MFMAs / on hi-lo split f16 operands (kv_grad2.hpp WSPLIT)
+        B.SPLIT_CONTRACTION = split
+        sfx = "_split" if split else ""
+        rec["grad2_iso%s_ms" % sfx] = timed(lambda: B.kv_grad2(xp, xp, lt, rt, iso=True))
+        rec["grad2_ard%s_ms" % sfx] = timed(lambda: B.kv_grad2(xp, xp, lt, rt, iso=False))
+        rec["grad2_ard_xgrad%s_ms" % sfx] = timed(lambda: B.kv_grad2(xp, xp, lt, rt, iso=False, want_gz1=True))
+        a = B.kv_grad(xp, xp, lt, rt, iso=False)
+        b, _ = B.kv_grad2(xp, xp, lt, rt, iso=False)
+        rec["max_rel_dev_vs_direct" + sfx] = float(((a - b[: a.numel()]).abs() / a.abs().clamp_min(1e-30))[: 1 + d].max())
+        b0, _ = B.kv_grad2(xp, xp, lt, rt, iso=True)
+        rec["iso_rel_dev_vs_direct" + sfx] = float(abs(float(a[1 : 1 + d].sum()) - float(b0[1])) / abs(float(a[1 : 1 + d].sum())))
+    B.SPLIT_CONTRACTION = None
     for k in list(rec):
         if k.endswith("_ms"):
             rec[k.replace("_ms", "_tflops")] = flop / rec[k] / 1e9
