@@ -90,6 +90,45 @@ def cpu_baseline(n, d, t, ls, budget_s=12.0, kind="rbf"):
     }
 
 
+class ClockSampler:
+    """Samples the shader clock (rocm-smi --showclocks, sclk) twice a second in a background thread while a block of steps runs: the f16
+    matrix pipe at full load runs well below the 2.4 GHz the fp32 kernel sustains, and the split kernel's time follows that clock."""
+
+    def __init__(self):
+        import threading
+
+        self.samples, self._stop = [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                m = re.search(r"GPU\[0\]\s*:\s*sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", out)
+                if m:
+                    self.samples.append(int(m.group(1)))
+            except Exception:
+                pass
+            self._stop.wait(0.5)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=10)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1], "samples": len(v), "source": "rocm-smi --showclocks"}
+
+
 def parity_block(xp, Xcpu, n, d, t, ls, dev, nrows=2048, kind="rbf"):
     """Rows of the benchmarked product vs the float64 oracle (reference formulas: oracle.kernels.kernel_matmul_rows)."""
     from gpytorch_amd import backend as B
@@ -202,7 +241,8 @@ def main():
                     help="K*V contraction of the TIMED steps: f32 = v_mfma_f32_32x32x2_f32 (the metric's fp32-MFMA roofline; default), "
                          "split = hi/lo-split operands on the f16 matrix pipe (the library default, settings.split_contraction). "
                          "The other one is measured once, untimed, and reported beside it (block 'split_contraction').")
-    ap.add_argument("--skip-split", action="store_true", help="skip the untimed step on the other contraction path")
+    ap.add_argument("--skip-split", action="store_true", help="skip the steps on the other contraction path")
+    ap.add_argument("--other-steps", type=int, default=5, help="steps timed on the other contraction path (reported beside the headline, with spread and the sustained clock)")
     ap.add_argument("--skip-parity", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="skip the untimed API-level MLL fwd+bwd / posterior timings")
@@ -336,9 +376,9 @@ def main():
     except Exception:
         traffic = None
 
-    split_traffic = None   # the split kernel's PMC passes (same rules as above): profiles/r02_s24_pmc_split_t65.json
+    split_traffic = None   # the split kernel's PMC passes (same rules as above): profiles/kv_pmc_split_current.json
     try:
-        sp = json.load(open(os.path.join(ROOT, "profiles", "r02_s24_pmc_split_t65.json"))).get("_derived", {})
+        sp = json.load(open(os.path.join(ROOT, "profiles", "kv_pmc_split_current.json"))).get("_derived", {})
         if [n, d, cols] == [500_000, 3, 65]:
             split_traffic = sp.get("hbm_bytes_per_launch")
     except Exception:
@@ -351,7 +391,8 @@ def main():
     if rank == 0 and not args.skip_parity:
         parity = parity_block(B.prep_points(kind, Xd, lengthscale, shift), X, n, d, cols * T, ls, dev, kind=kind)
 
-    # the other contraction path: one untimed step on the same inputs (same probe stream), its kernel timed the same way
+    # the other contraction path: --other-steps steps (default 5) on the same inputs after one warm-up, the first of them on the probe draw of
+    # the last timed step; its kernel timed the same way (HIP events on the launch stream), the shader clock sampled alongside
     other = None
     if world == 1 and not args.skip_split:
         split_now = args.contraction != "split"
@@ -360,11 +401,19 @@ def main():
             step()
             LCG.KV_EVENT_LOG = []
             gen.set_state(gen_state)      # same probe vectors as the last timed step
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            mll_o, it_o = step()
-            torch.cuda.synchronize(dev)
-            el_o = time.perf_counter() - t1
+            step_ms, its_o = [], []
+            mll_o = it_o = None
+            with ClockSampler() as clk:
+                for k_ in range(max(1, args.other_steps)):
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    mll_k, it_k = step()
+                    torch.cuda.synchronize(dev)
+                    step_ms.append((time.perf_counter() - t1) * 1e3)
+                    its_o.append(it_k)
+                    if k_ == 0:
+                        mll_o, it_o = mll_k, it_k
+            el_o = step_ms[0] * 1e-3
             d_o = sorted(e0.elapsed_time(e1) for (e0, e1, _, _, _) in LCG.KV_EVENT_LOG)
             LCG.KV_EVENT_LOG = None
             live_o = [x for x in d_o if x > 0.2 * d_o[len(d_o) // 2]]
@@ -376,6 +425,11 @@ def main():
                 "kv_tflops_f32_equivalent": flop_per_launch / (ms_o * 1e-3) / 1e12,
                 "speedup_vs_timed_path": kv_ms / ms_o,
                 "ms_per_step": el_o * 1e3,
+                "steps_timed": len(step_ms),
+                "ms_per_step_all": step_ms,
+                "ms_per_cg_iteration_all": [a_ / max(b_, 1) for a_, b_ in zip(step_ms, its_o)],
+                "kernel_ms_min_median_max": [live_o[0], live_o[len(live_o) // 2], live_o[-1]],
+                "clock": clk.summary(),
                 "cg_iterations": it_o,
                 "cg_iterations_timed_path_same_probes": it,
                 "mll": float(mll_o),

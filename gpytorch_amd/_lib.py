@@ -59,6 +59,7 @@ SIGNATURES = {
     "gpamd_lanczos_coef_f32": (_i, [_p, _i, _i, _f, _p, _p, _p]),
     "gpamd_lanczos_subtract_f32": (_i, [_p, _i64, _i, _p, _p, _i, _p, _p]),
     "gpamd_lanczos_normalize_f32": (_i, [_p, _i, _p, _p, _p, _f, _p, _p]),
+    "gpamd_msminres_update_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _p]),
     "gpamd_precond_coef_workspace_doubles": (_i64, [_i, _i, _i]),
     "gpamd_precond_coef_f32f64": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _p, _p, _i64, _p]),
     "gpamd_precond_apply_f32f64": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _p, _p, _p, _i64, _p]),

@@ -44,6 +44,10 @@ def msminres(matvec, rhs_t: torch.Tensor, shifts: torch.Tensor, n: int, tol: flo
     relative residual over shifts and columns falls below ``tol``."""
     dev, dt = rhs_t.device, rhs_t.dtype
     Q, t = shifts.numel(), rhs_t.shape[0]
+    native = rhs_t.is_cuda and dt == torch.float32 and rhs_t.stride(1) == 1 and rhs_t.stride(0) % 4 == 0 and rhs_t.shape[1] == rhs_t.stride(0)
+    if native:
+        from . import backend as B
+        from ._lib import check, lib
     sh = shifts.to(device=dev, dtype=dt).reshape(Q, 1)
     beta1 = rhs_t[:, :n].norm(dim=-1).clamp_min(1e-30)                     # [t]
     v = rhs_t / beta1.unsqueeze(-1)
@@ -75,9 +79,17 @@ def msminres(matvec, rhs_t: torch.Tensor, shifts: torch.Tensor, n: int, tol: flo
         c, s = gbar / gamma, beta_next.unsqueeze(0) / gamma
         tau = c * phibar
         phibar = -s * phibar
-        d = (v.unsqueeze(0) - delta.unsqueeze(-1) * d1 - eps.unsqueeze(-1) * d2) / gamma.unsqueeze(-1)
-        X = X + tau.unsqueeze(-1) * d
-        d2, d1 = d1, d
+        if native:
+            # one fused pass over the [Q, t, n] state (csrc/lanczos_kernels.hpp msminres_update_kernel): the new direction overwrites d2
+            coef = torch.stack([delta.expand(Q, t), eps.expand(Q, t), 1.0 / gamma, tau]).contiguous()
+            vc = v.contiguous()
+            check(lib().gpamd_msminres_update_f32(B._ptr(vc), B._ptr(d1), B._ptr(d2), B._ptr(X), B._ptr(coef), Q, t, n, rhs_t.stride(0),
+                                                   B._stream(dev)), "msminres_update")
+            d2, d1 = d1, d2
+        else:
+            d = (v.unsqueeze(0) - delta.unsqueeze(-1) * d1 - eps.unsqueeze(-1) * d2) / gamma.unsqueeze(-1)
+            X = X + tau.unsqueeze(-1) * d
+            d2, d1 = d1, d
         c2, s2, c1, s1 = c1, s1, c, s
         if float((phibar.abs() / beta1.unsqueeze(0)).max()) < tol or float(beta_next.max()) < 1e-12:
             break
@@ -134,15 +146,94 @@ def contour_integral_quad(matvec, rhs_t, n, inverse=True, num_quad=None, lmin=No
     return res, dict(iterations=iters, lmin=lmin, lmax=lmax, num_quad=num_quad)
 
 
+class SqrtInvMatmulFn(torch.autograd.Function):
+    """K_hat^{-1/2} rhs for K_hat = outputscale k(x, x; lengthscale) + noise I with the BACKWARD pass the reference differentiates through
+    (``gpytorch/__init__.py:252-278`` "backward pass"; consumer ``variational/ciq_variational_strategy.py:217``).
+
+        K^{-1/2} b = sum_q w_q (K + s_q I)^-1 b        =>        d/dtheta [g^T K^{-1/2} b] = - sum_q w_q ((K + s_q)^-1 g)^T (dK/dtheta) ((K + s_q)^-1 b)
+
+    The forward keeps the Q shifted solves of b; the backward runs msMINRES once more for the incoming gradient g (same shifts) and feeds
+    the Q t (left, right) column pairs to ONE fused bilinear-derivative pass (``kv_grad2``); d/db = K^{-1/2} g is the weighted sum of the
+    same solves."""
+
+    @staticmethod
+    def forward(ctx, x, lengthscale, outputscale, noise, rhs, spec, kparam=None):
+        from . import backend as B
+        from .functions import _prep
+
+        n = x.shape[-2]
+        xp = _prep(spec, x, lengthscale)
+        wd = xp.dtype
+        os_ = None if outputscale is None else outputscale.detach().reshape(-1)[:1].to(wd).contiguous()
+        nz = noise.detach().reshape(-1)[:1].to(wd).contiguous()
+
+        def matvec(vt):
+            return B.kv(xp, xp, vt, scale=os_, dscale=nz, vd=vt, dvec=spec.dvec)
+
+        rhs_t = B.to_probe_major(rhs, wd)
+        from . import settings
+
+        lo, hi = lanczos_eig_bounds(matvec, n, rhs_t.device, rhs_t.dtype)
+        lmin, lmax = lo * 0.5, hi * 1.1
+        weights, shifts = ciq_weights_shifts(lmin, lmax, settings.num_contour_quadrature.value())
+        X, iters = msminres(matvec, rhs_t, shifts, n)
+        w = weights.to(device=X.device, dtype=X.dtype)
+        res = (w.reshape(-1, 1, 1) * X).sum(0)
+        ctx.xp, ctx.n, ctx.matvec, ctx.shifts, ctx.w, ctx.X = xp, n, matvec, shifts, w, X
+        ctx.kparam, ctx.has_os, ctx.x_dtype = kparam, outputscale is not None, x.dtype
+        ctx.save_for_backward(lengthscale, outputscale if outputscale is not None else torch.empty(0), noise, rhs)
+        ctx.info = dict(iterations=iters, lmin=lmin, lmax=lmax)
+        return B.from_probe_major(res, n).to(rhs.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import backend as B
+        from .functions import hyper_grads
+
+        lengthscale, outputscale, noise, rhs = ctx.saved_tensors
+        outputscale = outputscale if ctx.has_os else None
+        xp, n, w = ctx.xp, ctx.n, ctx.w
+        Q, t = ctx.X.shape[0], ctx.X.shape[1]
+        g_t = B.to_probe_major(grad_out, xp.dtype)
+        G, _ = msminres(ctx.matvec, g_t, ctx.shifts, n)                      # (K + s_q)^-1 g   [Q, t, ld]
+        d_rhs = B.from_probe_major((w.reshape(-1, 1, 1) * G).sum(0), n).to(rhs.dtype) if ctx.needs_input_grad[4] else None
+        left = (-(w.reshape(-1, 1, 1)) * G).reshape(Q * t, -1).contiguous()
+        right = ctx.X.reshape(Q * t, -1).contiguous()
+        kp = ctx.kparam if (ctx.kparam is not None and ctx.needs_input_grad[6]) else None
+        d_x = d_par = None
+        if ctx.needs_input_grad[0]:
+            out = hyper_grads(xp, xp, lengthscale, outputscale, left, right, want_x1=True, want_x2=True, kparam=kp)
+            d_ls, d_os = out[:2]
+            d_x = (out[2] + out[3]).to(ctx.x_dtype)
+        else:
+            out = hyper_grads(xp, xp, lengthscale, outputscale, left, right, kparam=kp)
+            d_ls, d_os = out[:2]
+        if kp is not None:
+            d_par = out[-1]
+        d_noise = B.coldot(left, right, n).sum().reshape(noise.shape).to(noise.dtype)
+        return d_x, d_ls, d_os, d_noise, d_rhs, None, d_par
+
+
 def sqrt_inv_matmul(op, rhs: torch.Tensor, lhs: torch.Tensor | None = None):
     """``gpytorch.sqrt_inv_matmul(mat, rhs, lhs=None)`` (``gpytorch/__init__.py:252-278``): K^{-1/2} rhs, or
     (lhs K^{-1/2} rhs, diag-free inverse quadratic  lhs K^{-1} lhs^T summed over columns) when ``lhs`` is given.
-    ``op``: any operator of this package (its ``_matmul`` is the matrix-free product).  No autograd (forward only)."""
+    ``op``: any operator of this package (its ``_matmul`` is the matrix-free product).  Differentiable (``SqrtInvMatmulFn``: hyper-
+    parameters, inputs, right-hand side) for the fused single-kernel operators when gradients are enabled; forward-only otherwise."""
     from . import backend as B
 
     n = op.shape[-1]
     squeeze = rhs.dim() == 1
     r = rhs.unsqueeze(-1) if squeeze else rhs
+    from .operators import FusedKernelAddedDiagLinearOperator, FusedKernelLinearOperator
+
+    fused = op if isinstance(op, FusedKernelAddedDiagLinearOperator) else None
+    if isinstance(op, FusedKernelLinearOperator) and op.is_square:
+        fused = op.add_jitter(0.0)
+    if (lhs is None and fused is not None and torch.is_grad_enabled() and (fused.requires_grad or r.requires_grad)
+            and fused.kernel_op.prepared()[0].fused):
+        k = fused.kernel_op
+        out = SqrtInvMatmulFn.apply(k.x1, k.lengthscale, k.outputscale, fused.noise, r, fused._spec(), k.spec.param)
+        return out.squeeze(-1) if squeeze else out
 
     def matvec(vt):
         out = op._matmul(vt[:, :n].t().to(op.dtype))

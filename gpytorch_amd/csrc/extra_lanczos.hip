@@ -107,4 +107,12 @@ int gpamd_precond_apply_f32f64(const float* R, int64_t ldr, int t, const double*
   return lz_check("precond_apply");
 }
 
+int gpamd_msminres_update_f32(const float* v, const float* d1, float* d2, float* x, const float* coef, int Q, int t, int n, int64_t ld,
+                              void* stream) {
+  if (!v || !d1 || !d2 || !x || !coef || Q <= 0 || t <= 0 || n <= 0 || ld < n || ld % 4 || Q > 65535 || t > 65535)
+    return lz_fail("msminres_update: bad arguments (ld % 4 == 0, ld >= n)");
+  hipLaunchKernelGGL(msminres_update_kernel, dim3(lz_blocks(n), t, Q), dim3(256), 0, (hipStream_t)stream, v, d1, d2, x, coef, Q, t, n, ld);
+  return lz_check("msminres_update");
+}
+
 }  // extern "C"

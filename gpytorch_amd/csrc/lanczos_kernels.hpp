@@ -206,4 +206,41 @@ __global__ __launch_bounds__(256) void pc_apply_kernel(const float* __restrict__
     if (c < nc) Out[(int64_t)(c0 + c) * ldo + i] = (float)(((double)R[(int64_t)(c0 + c) * ldr + i] - acc[c]) * inv);
 }
 
+// ---- multi-shift MINRES (contour-integral quadrature, gpytorch/__init__.py:252-278 -> linear_operator.utils.minres): the vector part of one
+// iteration for ALL shifts in one pass.  Per (shift q, column c):  d = (v_c - delta d1 - eps d2) / gamma  (written over d2: the caller swaps
+// the roles of the two direction buffers),  x += tau d.  v: [t][ld]; d1, d2, x: [Q][t][ld]; coef: [4][Q][t] = delta | eps | 1 / gamma | tau
+// (device, produced by the Givens recurrences on [Q, t] scalars).  HBM-bound: 4 reads + 2 writes of Q t n floats, one launch instead of the
+// ~8 elementwise torch passes (and as many [Q, t, n] temporaries) it replaces.
+__global__ __launch_bounds__(256) void msminres_update_kernel(const float* __restrict__ v, const float* __restrict__ d1, float* __restrict__ d2,
+                                                             float* __restrict__ x, const float* __restrict__ coef, int Q, int t, int n,
+                                                             int64_t ld) {
+  const int c = blockIdx.y, q = blockIdx.z;
+  const int qt = Q * t, k = q * t + c;
+  const float delta = coef[k], eps = coef[qt + k], ginv = coef[2 * qt + k], tau = coef[3 * qt + k];
+  const float* vc = v + (int64_t)c * ld;
+  const int64_t off = (int64_t)k * ld;
+  for (int i = 4 * (blockIdx.x * 256 + threadIdx.x); i < n; i += 4 * 256 * gridDim.x) {
+    if (i + 4 <= n) {
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(vc + i);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(d1 + off + i);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(d2 + off + i);
+      f32x4 xx = *reinterpret_cast<const f32x4*>(x + off + i);
+      f32x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d[e] = (vv[e] - delta * a[e] - eps * b[e]) * ginv;
+        xx[e] = __builtin_fmaf(tau, d[e], xx[e]);
+      }
+      *reinterpret_cast<f32x4*>(d2 + off + i) = d;
+      *reinterpret_cast<f32x4*>(x + off + i) = xx;
+    } else {
+      for (int e = 0; i + e < n; ++e) {
+        const float d = (vc[i + e] - delta * d1[off + i + e] - eps * d2[off + i + e]) * ginv;
+        d2[off + i + e] = d;
+        x[off + i + e] = __builtin_fmaf(tau, d, x[off + i + e]);
+      }
+    }
+  }
+}
+
 }  // namespace gpamd

@@ -185,6 +185,13 @@ int gpamd_lanczos_coef_f32(const float* part, int k, int nb, float tol, float* c
 int gpamd_lanczos_subtract_f32(const float* Q, int64_t ldq, int k, const float* coef, float* r, int n, float* part_rr, void* stream);
 int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* out, float* norm_out, float tiny, int* stop, void* stream);
 
+/* ---- multi-shift MINRES (contour-integral quadrature: gpytorch.sqrt_inv_matmul, gpytorch/__init__.py:252-278 ->
+ * linear_operator.utils.minres; consumer variational/ciq_variational_strategy.py:217): the vector part of ONE iteration for all Q shifts:
+ * d = (v_c - delta d1 - eps d2) / gamma written over d2 (the caller swaps the two direction buffers), x += tau d.
+ * v: [t][ld]; d1, d2, x: [Q][t][ld]; coef: float[4][Q][t] = delta | eps | 1 / gamma | tau (device). ---- */
+int gpamd_msminres_update_f32(const float* v, const float* d1, float* d2, float* x, const float* coef, int Q, int t, int n, int64_t ld,
+                              void* stream);
+
 /* ---- pivoted-Cholesky preconditioner apply, first half:  W[c][m] = sum_i R[c][i] * Q1[m][i]  with R float32 [t][ldr] (the CG
  * residuals), Q1 float64 [k][ldq] (k <= 128), W float64 [t][k], float64 accumulation -- the k x t coefficients of
  * AddedDiagLinearOperator._preconditioner's closure  P^-1 R = (R - Q1 Q1^T R) / sigma^2, whose cancellation float32 cannot carry

@@ -574,3 +574,65 @@ def test_sqrt_inv_matmul_ciq_on_the_fused_operator(dev):
     emp = (smp.double().cpu().t() @ smp.double().cpu()) / 3000
     assert float((emp.diagonal() - Kh.diagonal()).abs().max() / Kh.diagonal().max()) < 0.15
     assert float((emp - Kh).norm() / Kh.norm()) < 0.12
+
+
+def test_sqrt_inv_matmul_backward_against_dense_autograd(dev):
+    """The backward pass of ``gpytorch.sqrt_inv_matmul`` (gpytorch/__init__.py:252-278; consumer variational/ciq_variational_strategy.py:217):
+    gradients of g^T K_hat^{-1/2} b w.r.t. lengthscale, outputscale, noise, the right-hand side and the inputs (ciq.SqrtInvMatmulFn: the
+    shifted msMINRES solves re-used by one fused bilinear-derivative pass) against float64 autograd through the eigendecomposition."""
+    import gpytorch_amd as g
+
+    n, d = 700, 2
+    X, _ = make_data(n, d)
+    gen = torch.Generator().manual_seed(3)
+    b = torch.randn(n, 2, generator=gen, dtype=torch.float64)
+    gvec = torch.randn(n, 2, generator=gen, dtype=torch.float64)
+    kern = g.kernels.ScaleKernel(g.kernels.RBFKernel()).to(dev)
+    kern.base_kernel.lengthscale = 0.4
+    kern.outputscale = 1.3
+    noise = torch.tensor([0.3], device=dev, requires_grad=True)
+    xd = X.float().to(dev).requires_grad_(True)
+    bd = b.float().to(dev).requires_grad_(True)
+    with g.settings.max_cholesky_size(0):
+        op = kern(xd).add_diagonal(noise)
+        out = g.sqrt_inv_matmul(op, bd)
+        (out * gvec.float().to(dev)).sum().backward()
+    p = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (0.4, 1.3, 0.3)]
+    X64 = X.clone().requires_grad_(True)
+    b64 = b.clone().requires_grad_(True)
+    Kh = p[1] * OK.rbf(X64, X64, p[0], x1_eq_x2=False, direct=True) + p[2] * torch.eye(n, dtype=torch.float64)
+    ev, U = torch.linalg.eigh(Kh)
+    ref = (U @ torch.diag(ev.rsqrt()) @ U.t()) @ b64
+    assert rel_err(out, ref) < 2e-3
+    gref = torch.autograd.grad((ref * gvec).sum(), p + [b64, X64])
+    sp = lambda v: 1.0 - math.exp(-v)  # noqa: E731
+    got = torch.tensor([float(kern.base_kernel.raw_lengthscale.grad.sum()), float(kern.raw_outputscale.grad.sum()), float(noise.grad.sum())], dtype=torch.float64)
+    want = torch.tensor([float(gref[0]) * sp(0.4), float(gref[1]) * sp(1.3), float(gref[2])], dtype=torch.float64)
+    assert float((got - want).norm() / want.norm()) < 1e-2, (got, want)
+    assert float((bd.grad.double().cpu() - gref[3]).norm() / gref[3].norm()) < 5e-3
+    assert float((xd.grad.double().cpu() - gref[4]).norm() / gref[4].norm()) < 2e-2
+
+
+def test_ciq_square_root_at_size_against_a_tight_cg_solve(dev):
+    """K_hat^{-1/2} (K_hat^{-1/2} b) = K_hat^{-1} b at n = 100 000 (the native msMINRES update, 15 shifts x 2 columns x n state): the twice-applied
+    contour-integral square root against a tight mBCG solve of the same system."""
+    import gpytorch_amd as g
+    from gpytorch_amd import backend as B
+    from gpytorch_amd.linear_cg import linear_cg
+
+    n, d = 100_000, 3
+    X, y = make_data(n, d)
+    kern = g.kernels.ScaleKernel(g.kernels.RBFKernel()).to(dev)
+    kern.base_kernel.lengthscale = 0.25
+    kern.outputscale = 1.0
+    Xd = X.float().to(dev)
+    rhs = torch.stack([y.float(), torch.randn(n, generator=torch.Generator().manual_seed(2))], -1).to(dev)
+    with torch.no_grad(), g.settings.max_cholesky_size(0), g.settings.num_contour_quadrature(20):
+        op = kern(Xd).add_jitter(0.5)
+        half = g.sqrt_inv_matmul(op, rhs)
+        full = g.sqrt_inv_matmul(op, half)
+    xp = B.prep_points("rbf", Xd, torch.tensor([0.25]), Xd.mean(0))
+    sol_t, info = linear_cg(xp, torch.tensor([1.0], device=dev), torch.tensor([0.5], device=dev), B.to_probe_major(rhs), tolerance=1e-5, max_iter=3000)
+    assert info.tolerance_reached
+    ref = B.from_probe_major(sol_t, n)
+    assert rel_err(full, ref) < 2e-3, rel_err(full, ref)
