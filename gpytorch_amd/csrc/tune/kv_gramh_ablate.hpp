@@ -30,47 +30,11 @@
 //     16 g + 8h + e  holding  j = 16 g + (e&3) + 8(e>>2) + 4h   -> the operand is 16 contiguous bytes.
 // The optional extra column (EX: the "+ y" of [probes | y]) is carried on the VALU in f32 as in kv_gram.hpp.
 #pragma once
-#include "gram_f16.hpp"
-#include "kv_mfma.hpp"
+// TUNE-ONLY copy of kv_gramh.hpp as of round 3 with its ablation (ABL) and geometry (NW, OCC) switches: libgpamd_tune.so /
+// scripts/kgh_ablate.py.  The product kernel (../kv_gramh.hpp) carries none of these branches; shared constants and types come from it.
+#include "../kv_gramh.hpp"
 
 namespace gpamd {
-
-constexpr int KGH_BN = 128;             // j tile staged in LDS
-constexpr int KGH_LDH = KGH_BN + 8;     // f16 row stride of the V planes in LDS (272 B: conflict-free ds_read_b128)
-constexpr int KGH_KSHIFT = 12;          // K generated as 2^12 K
-constexpr int KGH_VEXP = 14;            // max |V_c| * scale_c in [2^13, 2^14)
-constexpr int KGH_GROUP = 64;           // columns per launch group (+ 1 extra VALU column)
-constexpr int KGH_SMALL_N = 16384;      // fewer output rows: one row tile per wave (NI = 1), four times as many workgroups
-constexpr int KGH_MIN_COLS = 5;         // fewer columns: the VALU-contraction kernel (kv_gramv.hpp) wins
-constexpr int kgh_ni(int ct, int d = 16) { return (ct == 1 || d <= 3) ? 4 : 2; }   // 32-row tiles per wave: 16 NI CT accumulators (d: kernel dims)
-inline int kgh_bm(int ni) { return 4 * ni * 32; }
-
-struct KvhArgs {
-  KvArgs a;               // Vt: the f32 columns (only the extra column is read from it)
-  const _Float16* Vh;     // [32 CT][ldh] split planes, permuted k-slot order, zero beyond m and beyond t
-  const _Float16* Vl;
-  int64_t ldh;
-  const float* colmul;    // [32 CT (+1)] per-column output multiplier
-};
-
-// covariance from the squared distance, times 2^KSHIFT (RBF: the shift is already inside s)
-template <int KIND>
-__device__ __forceinline__ float cov_scaled(float s, float p) {
-  constexpr float KS = (float)KGH_KSHIFT;
-  if constexpr (KIND == KIND_RBF) {
-    return __builtin_amdgcn_exp2f(-s);
-  } else if constexpr (KIND == KIND_RQ) {
-    return __builtin_amdgcn_exp2f(__builtin_fmaf(-p, __builtin_amdgcn_logf(1.0f + s), KS));
-  } else {
-    float r = __builtin_amdgcn_sqrtf(s);
-    float e = __builtin_amdgcn_exp2f(__builtin_fmaf(-r, LOG2E, KS));
-    if constexpr (KIND == KIND_MATERN12) return e;
-    if constexpr (KIND == KIND_MATERN32) return (1.0f + r) * e;
-    return __builtin_fmaf(s, 1.0f / 3.0f, 1.0f + r) * e;
-  }
-}
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Software pipeline.  One "step" = one 32x32 block of pairs of one row tile: generation (KH Gram MFMAs, then per element
 // v_exp_f32 + the hi/lo split: ~4 VALU instructions) and contraction (6 CT MFMAs of 8 passes).  A wave issues in order, and a
@@ -79,19 +43,22 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // written in that order -- one MFMA, then its share of the next step's VALU work -- and sched_barrier(0) pins it.  To keep the pipeline
 // full across LDS tiles the split x_j rows (and the extra column) are staged ONE TILE AHEAD (double-buffered): the last step
 // of a tile generates the first block of the next one.
-// (The ablation and geometry variants this loop was measured through -- no generation / no MFMAs / staged once / no barriers, one or three
-// waves per SIMD, eight waves per workgroup, register prefetch of the next tile, a deeper Gram look-ahead -- live in tune/kv_gramh_ablate.hpp
-// and libgpamd_tune.so; DESIGN.md 3.1b has the numbers.)
-template <int KIND, int D, int CT, int NI, int EX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void kv_gramh_kernel(KvhArgs ka) {
-  constexpr int NW = 4, NT = 64 * NW;   // four waves per workgroup: row block = NW * NI * 32 rows sharing one staged V tile
+// ABL (ablation builds of libgpamd_tune.so only; 0 in the product; 6 = register prefetch of the next tile, 7 = one wave per SIMD, 8 = no sched_barrier pinning, 10 = Gram MFMA one step further ahead): 1 no generation VALU, 2 no contraction MFMAs, 3 V planes staged
+// once (no global loads / LDS writes per tile; barriers stay), 4 as 3 and no barriers, 5 A operands read once per tile
+// NW: waves per workgroup (row block = NW * NI * 32 rows sharing one staged V tile); OCC: resident waves per SIMD the allocator is held to.
+template <int KIND, int D, int CT, int NI, int EX, int ABL = 0, int NW = 4, int OCC = 2>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(ABL == 7 ? 1 : OCC, ABL == 7 ? 1 : OCC)))
+void kv_gramh_ablate_kernel(KvhArgs ka) {
+  constexpr int NT = 64 * NW;   // threads per workgroup
   const KvArgs& a = ka.a;
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;
   constexpr int BN = KGH_BN, LDH = KGH_LDH, TC = 32 * CT;
   constexpr int XHS = KH * BN * 16;     // f16 elements of one Xh buffer
-  constexpr bool PF = NI * CT <= 4 && KH <= 2;   // A operands of block jb + 32 fetched during block jb (16 CT more registers)
+  // V planes / x rows of the next tile prefetched into registers during compute: measured, no gain (86.2 vs 86.3 ms at n = 500 000,
+  // 64 columns, profiles/r02_s22_kgh_ablate.json) -- what staging costs is LDS-write and L2 throughput, not latency; tune builds only
+  constexpr bool VPF = (ABL == 6);
+  constexpr bool PF = NI * CT <= 4 && KH <= 2 && !VPF && OCC <= 2;   // A operands of block jb + 32 fetched during block jb (16 CT more registers)
   __shared__ __attribute__((aligned(16))) _Float16 Vhs[TC * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 Vls[TC * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 Xh[2 * XHS];        // [buf][kh][j][16] split augmented x_j rows
@@ -136,7 +103,7 @@ void kv_gramh_kernel(KvhArgs ka) {
   constexpr int VQ = TC * (BN / 8) / NT;   // 16-byte chunks per thread and plane (= 2 CT with four waves)
 
   // split x_j rows + extra column of the tile starting at j0 -> buffer `buf` (rows beyond jend: zero -> k = 2^KSHIFT, V = 0).
-  // Two halves: global loads into registers (load_x), then the split rows into LDS (store_x) between the barriers.
+  // Two halves so that the global loads can be issued a whole tile of compute ahead of the LDS writes (VPF).
   float xz[DP];
   f32x4 xe = {0.f, 0.f, 0.f, 0.f};
   bool xvalid = false;
@@ -247,18 +214,24 @@ void kv_gramh_kernel(KvhArgs ka) {
   stage_x(jbeg, 0);
   __syncthreads();
   u32x4 bh[2], bl[2];
-  // LEAN (NI * CT > 4: four row tiles per wave and two column tiles, d <= 3): operands of a half are fetched just before its MFMAs
-  // instead of per block -- 128 accumulator registers leave no room for the whole block's operands
+  // DEEP (tune builds, ABL = 10, NI = 2): the Gram MFMA runs one full step ahead of the generation that consumes it -- the
+  // distances of step s + 2 are issued at the start of step s, the generation during step s reads those issued during s - 1
+  constexpr bool DEEP = (ABL == 10) && NI == 2;
+  // LEAN (NI * CT > 4: tune builds with four row tiles per wave and two column tiles): operands of a half are fetched just before
+  // its MFMAs instead of per block -- 128 accumulator registers leave no room for the whole block's operands
   constexpr bool LEAN = NI * CT > 4;
+  f32x16 kk_pend;
   {
     f16x8 aq0[KH];
     load_aq(0, 0, aq0);
     const f32x16 kk = gram(aq0, 0);
     finish_half(kk, 0, 0, 0, 0, bh[0], bl[0]);
     finish_half(kk, 1, 0, 0, 0, bh[1], bl[1]);
+    if constexpr (DEEP) kk_pend = gram(aq0, 1);   // distances of step (0, 1), consumed during step (0, 0)
   }
 
-  // V planes of one tile: global -> registers (-> LDS between the barriers)
+  // V planes of one tile: global -> registers (-> LDS between the barriers).  VPF: the loads of tile k + 1 are issued right
+  // after the barrier that opens tile k, so their latency hides under a whole tile of compute.
   u32x4 pvh[VQ], pvl[VQ];
   auto load_v = [&](int j0) {
     const int64_t jc = min((int64_t)j0, ka.ldh - BN);   // past the chunk end: any in-bounds tile (never consumed)
@@ -271,13 +244,20 @@ void kv_gramh_kernel(KvhArgs ka) {
       pvl[rr] = *reinterpret_cast<const u32x4*>(ka.Vl + off);
     }
   };
+  if constexpr (VPF) {
+    load_v(jbeg);
+    load_x(jbeg + BN);
+  }
+
   int buf = 0;
   for (int j0 = jbeg; j0 < jend; j0 += BN, buf ^= 1) {
-    __syncthreads();   // every wave is done with the V planes of the previous tile and with Xh[buf ^ 1]
-    {
-      load_v(j0);
-      load_x(j0 + BN);   // past the end of the chunk: zero rows and a zero extra column (the last step's look-ahead generation
-                         // must stay finite and add nothing to the extra column)
+    if (ABL != 4) __syncthreads();   // every wave is done with the V planes of the previous tile and with Xh[buf ^ 1]
+    if ((ABL != 3 && ABL != 4) || j0 == jbeg) {
+      if constexpr (!VPF) {
+        load_v(j0);
+        load_x(j0 + BN);   // past the end of the chunk: zero rows and a zero extra column (the last step's look-ahead generation
+                           // must stay finite and add nothing to the extra column)
+      }
       store_x(buf ^ 1);
 #pragma unroll
       for (int rr = 0; rr < VQ; ++rr) {
@@ -287,7 +267,11 @@ void kv_gramh_kernel(KvhArgs ka) {
         *reinterpret_cast<u32x4*>(&Vls[c * LDH + 8 * q]) = pvl[rr];
       }
     }
-    __syncthreads();
+    if (ABL != 4 || j0 == jbeg) __syncthreads();
+    if constexpr (VPF) {   // next tile's global loads fly during this tile's compute
+      load_v(j0 + BN);
+      load_x(j0 + 2 * BN);
+    }
 
     // A operands of a block (V planes): 16 contiguous bytes per (16-row half, column tile, plane).  Block jb + 32's are
     // fetched during block jb (LDS latency off the critical path); only the first block of a tile waits for them.
@@ -296,7 +280,7 @@ void kv_gramh_kernel(KvhArgs ka) {
       for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          const int o = (ct * 32 + l31) * LDH + jb + 16 * mf + 8 * h;
+          const int o = (ct * 32 + l31) * LDH + (ABL == 5 ? 0 : jb) + 16 * mf + 8 * h;
           ah[mf][ct] = *reinterpret_cast<const f16x8*>(&Vhs[o]);
           al[mf][ct] = *reinterpret_cast<const f16x8*>(&Vls[o]);
         }
@@ -324,9 +308,15 @@ void kv_gramh_kernel(KvhArgs ka) {
           load_ev(bufn, jbn, 0, ev[0]);
           load_ev(bufn, jbn, 1, ev[1]);
         }
-        const f32x16 kkn = gram(wrap ? aqn : aqc, nin);
+        f32x16 kkn, kk_new;
+        if constexpr (DEEP) {
+          kk_new = gram(aqn, ni);   // step s + 2 = (jb + 32, ni): x rows of the next block
+          kkn = kk_pend;
+        } else {
+          kkn = gram(wrap ? aqn : aqc, nin);
+        }
         u32x4 bhn[2], bln[2];
-        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 8) __builtin_amdgcn_sched_barrier(0);
         // contraction of this step, each MFMA followed by its share of the next step's generation; sched_barrier(0) pins the
         // source order (left alone the scheduler groups the MFMAs, and the wave stalls 32 cycles on each with the VALU idle).
         // Eight half-chunks (gen_a / gen_b of four pairs) over the 3 CT MFMAs of a half:
@@ -349,19 +339,20 @@ void kv_gramh_kernel(KvhArgs ka) {
           for (int q = 0; q < 3 * CT; ++q) {
             // the two small terms first, then the leading one; consecutive instructions alternate accumulators
             const int ct = q % CT, term = q / CT;
-            acc[ni][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al[mf][ct] : ah[mf][ct], term == 1 ? blv : bhv, acc[ni][ct], 0, 0, 0);
+            if (ABL != 2) acc[ni][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al[mf][ct] : ah[mf][ct], term == 1 ? blv : bhv, acc[ni][ct], 0, 0, 0);
             // half-chunk u = 2 p + (0: gen_a, 1: gen_b); this MFMA's share: [u0, u1)
             constexpr int U6[7] = {0, 1, 3, 4, 5, 7, 8}, U3[4] = {0, 3, 6, 8};
             const int u0 = CT == 1 ? U3[q] : U6[q], u1 = CT == 1 ? U3[q + 1] : U6[q + 1];
 #pragma unroll
-            for (int u = u0; u < u1; ++u) {
+            for (int u = (ABL == 1 ? u1 : u0); u < u1; ++u) {
               if ((u & 1) == 0) gen_a(kkn, mf, u >> 1, ev[mf], nin, kv[u >> 1], bhn[mf]);
               else gen_b(kv[u >> 1], u >> 1, bhn[mf][u >> 1], bln[mf]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (ABL != 8) __builtin_amdgcn_sched_barrier(0);
           }
         }
-        bh[0] = bhn[0]; bh[1] = bhn[1]; bl[0] = bln[0]; bl[1] = bln[1];
+        if (ABL != 1) { bh[0] = bhn[0]; bh[1] = bhn[1]; bl[0] = bln[0]; bl[1] = bln[1]; }
+        if constexpr (DEEP) kk_pend = kk_new;
       }
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) aqc[kh] = aqn[kh];
