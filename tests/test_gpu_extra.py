@@ -601,8 +601,17 @@ def test_sqrt_inv_matmul_backward_against_dense_autograd(dev):
     X64 = X.clone().requires_grad_(True)
     b64 = b.clone().requires_grad_(True)
     Kh = p[1] * OK.rbf(X64, X64, p[0], x1_eq_x2=False, direct=True) + p[2] * torch.eye(n, dtype=torch.float64)
-    ev, U = torch.linalg.eigh(Kh)
-    ref = (U @ torch.diag(ev.rsqrt()) @ U.t()) @ b64
+    # float64 reference: autograd through eigh is unstable here (kernel matrices have near-degenerate eigenvalues: 1 / (l_i - l_j) terms), so
+    # the square root is taken through the SAME contour-integral identity with a converged rule (40 nodes, exact spectral bounds, dense
+    # float64 solves) -- K^{-1/2} = sum_q w_q (K + s_q I)^-1 holds to 1e-12 for any interval containing the spectrum
+    from gpytorch_amd.ciq import ciq_weights_shifts
+
+    ev = torch.linalg.eigvalsh(Kh.detach())
+    wq, sq = ciq_weights_shifts(float(ev[0]) * 0.9, float(ev[-1]) * 1.1, 40)
+    eye = torch.eye(n, dtype=torch.float64)
+    ref = sum(w_ * torch.linalg.solve(Kh + s_ * eye, b64) for w_, s_ in zip(wq.tolist(), sq.tolist()))
+    U_, = (torch.linalg.eigh(Kh.detach())[1],)
+    assert rel_err(ref, (U_ @ torch.diag(ev.rsqrt()) @ U_.t()) @ b) < 1e-9      # the identity itself, against the eigendecomposition (values only)
     assert rel_err(out, ref) < 2e-3
     gref = torch.autograd.grad((ref * gvec).sum(), p + [b64, X64])
     sp = lambda v: 1.0 - math.exp(-v)  # noqa: E731
