@@ -50,6 +50,8 @@ SIGNATURES = {
     "gpamd_cg_update_xr_f32": (_i, [_p, _i, _p]),
     "gpamd_cg_update_d_f32": (_i, [_p, _i, _p]),
     "gpamd_cg_stop_f32": (_i, [_p, _i, _i, _i, _f, _p]),
+    "gpamd_cg_stop_comm_f32": (_i, [_p, _i, _i, _i, _f, _p, _p]),
+    "gpamd_allreduce_sum_f32": (_i, [_p, _i64, _p, _p]),
     "gpamd_cg_finish_f32": (_i, [_p, _p]),
     "gpamd_pivoted_cholesky_f32": (_i, [_i, _f, _p, _i, _i, _p, _i, _f, _p, _i64, _p, _p, _p, _p]),
     "gpamd_lanczos_num_partials": (_i, [_i]),

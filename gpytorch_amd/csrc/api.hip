@@ -2,6 +2,7 @@
 // interfaces each one replaces).  gfx950 only; no torch types, no CPU fallbacks.
 #include "../../include/gpamd.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -665,6 +666,41 @@ int gpamd_pivoted_cholesky_f32(int kind, float kparam, const float* Xp, int n, i
                                          scale));
   }
   return check_launch("pivoted_cholesky");
+}
+
+// ----------------------------------------------------------------------------- RCCL-communicator variants (multi-GPU hosts without torch)
+// librccl is resolved lazily (dlopen / dlsym) so that the library keeps loading on single-GPU hosts without it.
+namespace {
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+nccl_allreduce_fn rccl_allreduce() {
+  static nccl_allreduce_fn fn = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void* hdl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!hdl) hdl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (hdl) fn = reinterpret_cast<nccl_allreduce_fn>(dlsym(hdl, "ncclAllReduce"));
+  }
+  return fn;
+}
+}  // namespace
+
+int gpamd_allreduce_sum_f32(float* buf, int64_t count, void* rccl_comm, void* stream) {
+  if (!buf || count <= 0 || !rccl_comm) return fail(GPAMD_EINVAL, "allreduce_sum: bad arguments");
+  nccl_allreduce_fn fn = rccl_allreduce();
+  if (!fn) return fail(GPAMD_EUNSUPPORTED, "allreduce_sum: librccl.so (ncclAllReduce) not found");
+  const int rc = fn(buf, buf, (size_t)count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, rccl_comm, (hipStream_t)stream);
+  if (rc != 0) return fail(GPAMD_EINVAL, "allreduce_sum: ncclAllReduce failed");
+  return 0;
+}
+
+int gpamd_cg_stop_comm_f32(gpamd_cg_t* h, int k, int min_iter, int tridiag_floor, float tol, void* rccl_comm, void* stream) {
+  if (!h) return fail(GPAMD_EINVAL, "cg_stop_comm: null handle");
+  if (rccl_comm) {
+    const int rc = gpamd_allreduce_sum_f32(h->st.stats, 2, rccl_comm, stream);
+    if (rc) return rc;
+  }
+  return gpamd_cg_stop_f32(h, k, min_iter, tridiag_floor, tol, stream);
 }
 
 }  // extern "C"

@@ -155,6 +155,17 @@ int gpamd_cg_update_xr_f32(gpamd_cg_t* h, int k, void* stream);
 int gpamd_cg_update_d_f32(gpamd_cg_t* h, int k, void* stream);
 /* stopping rule on stats (all-reduce stats[0:2] across ranks first when probe columns are sharded) */
 int gpamd_cg_stop_f32(gpamd_cg_t* h, int k, int min_iter, int tridiag_floor, float tol, void* stream);
+/* ---- RCCL-communicator variants ("RCCL communicator handle passed in for the multi-GPU variants"; they replace the peer
+ * copies of gpytorch/kernels/multi_device_kernel.py:49-92).  rccl_comm: an ncclComm_t of the caller (one rank per GPU); stream-ordered on
+ * `stream`, no host round trip.  librccl.so is resolved on first use (dlopen), so single-GPU hosts need not have it.
+ *   gpamd_cg_stop_comm_f32: the stopping rule of a PROBE-SHARDED solve -- all-reduces the solver's two residual statistics (sum of column
+ *     residual norms, column count) over the communicator, then applies the rule: the ONLY per-iteration collective of the design.
+ *   gpamd_allreduce_sum_f32: in-place sum of `count` device floats (SLQ partial sums, packed hyper-parameter gradients, the k x t
+ *     preconditioner coefficients of a row-sharded apply).
+ * The Python host of this repository drives the same collectives through torch.distributed (backend "nccl" = RCCL), which owns its
+ * communicators; these entry points serve hosts that hold an ncclComm_t themselves. ---- */
+int gpamd_cg_stop_comm_f32(gpamd_cg_t* h, int k, int min_iter, int tridiag_floor, float tol, void* rccl_comm, void* stream);
+int gpamd_allreduce_sum_f32(float* buf, int64_t count, void* rccl_comm, void* stream);
 /* X *= |B| */
 int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream);
 

@@ -150,3 +150,37 @@ def test_settings_skip_flags(dev):
     # train-mode input check (exact_gp.py:276-280)
     with pytest.raises(RuntimeError, match="train on the training inputs"):
         m(Xs.float().to(dev))
+
+
+def test_rccl_communicator_entry_points_on_a_single_rank_communicator(dev):
+    """The RCCL-communicator variants of the C ABI (include/gpamd.h: gpamd_allreduce_sum_f32, gpamd_cg_stop_comm_f32) with a REAL ncclComm_t:
+    a one-rank communicator created through librccl (ncclGetUniqueId / ncclCommInitRank) -- the all-reduce is then the identity, which checks
+    the handle passing, the datatype / op constants and the stream ordering; multi-rank behaviour is RCCL's."""
+    import ctypes as C
+
+    from gpytorch_amd import backend as B
+    from gpytorch_amd._lib import check, lib
+
+    try:
+        rccl = C.CDLL("librccl.so")
+    except OSError:
+        pytest.skip("librccl.so not present")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        buf = torch.arange(1, 9, device=dev, dtype=torch.float32)
+        want = buf.clone()
+        check(lib().gpamd_allreduce_sum_f32(B._ptr(buf), buf.numel(), comm, B._stream(dev)), "allreduce")
+        torch.cuda.synchronize(dev)
+        assert torch.equal(buf, want)
+        assert lib().gpamd_allreduce_sum_f32(None, 4, comm, B._stream(dev)) == -1
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
