@@ -617,6 +617,7 @@ def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.
 
 
 FORCE_GRAD_DIRECT = False  # tests: keep the bilinear derivative on the direct-difference kernel (kv_grad.hpp)
+GRAD_SPLIT_MIN_COLS = 24   # backward: columns from which W = L^T R runs on hi/lo-split f16 operands (kv_grad2 below)
 
 
 def grad_gram_ok(x1: PreparedPoints, x2: PreparedPoints) -> bool:
@@ -651,9 +652,12 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
         lt = lt[:, : x1.n].index_select(1, x1.sorted_view().perm).contiguous()
         if lt.shape[1] % 4:
             lt = torch.nn.functional.pad(lt, (0, 4 - lt.shape[1] % 4))
-    # W = L^T R on the f16 matrix pipe at f32 accuracy (kv_grad2.hpp WSPLIT; the same switch as the K*V contraction).  The per-dimension
-    # mode keeps 40 more registers live and spills from d = 8 on: those shapes stay on the fp32-MFMA contraction
-    split = _split_on() and (x1.d <= 6 or (iso and not want_gz1))
+    # W = L^T R on the f16 matrix pipe at f32 accuracy (kv_grad2.hpp WSPLIT; the same switch as the K*V contraction) from 24 columns on: a
+    # 32 x 32 tile costs 15 f16 MFMAs (480 cycles) whatever t, the fp32 form t / 2 MFMAs of 64 cycles -- cheaper below 15 columns, and exact
+    # to 1e-10 of sum |W dK| where the f16 accumulation leaves a 1.5e-8 floor (measured: profiles/r03_s15_grad_split_error_floor.txt; it only
+    # shows where the sum cancels by > 1e4, e.g. the gradient of a few-column solve).  The per-dimension mode keeps 40 more registers live and
+    # spills from d = 8 on: those shapes stay on the fp32-MFMA contraction too
+    split = _split_on() and t >= GRAD_SPLIT_MIN_COLS and (x1.d <= 6 or (iso and not want_gz1))
     sws, ns = None, 0
     if split:
         ns = int(L.gpamd_kv_grad2_split_workspace_floats(x1.n, x2.n))
