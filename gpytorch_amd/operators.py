@@ -24,6 +24,10 @@ from . import settings
 from .functions import CholeskyInvQuadLogdetFn, InvQuadLogdetFn, KernelDenseFn, KernelMatmulFn, KernelSpec, SolveFn
 
 
+class NotPSDError(RuntimeError):
+    """Same role as ``linear_operator.utils.errors.NotPSDError``."""
+
+
 class LinearOperator:
     """Minimal protocol base (2-D, no batch dimensions: the fused kernels are non-batched)."""
 
@@ -184,6 +188,9 @@ class LinearOperator:
                 Lc, info = torch.linalg.cholesky_ex(K + (jitter * 10**k if k else 0.0) * eye)
                 if not bool(info.any()):
                     break
+            else:
+                # the reference's psd_safe_cholesky raises NotPSDError after its last jitter level; never hand back a failed factor
+                raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter * 10**3:.1e}.")
             return RootLinearOperator(Lc.to(self.dtype))
         from .lanczos import lanczos_tridiag, tridiag_to_diag
 
@@ -207,8 +214,8 @@ class LinearOperator:
             eps = torch.randn(self.shape[-1], num_samples, device=self.device, dtype=self.dtype)
             return sqrt_matmul(self, eps).t()
         root = self.root_decomposition().root
-        eps = torch.randn(root.shape[-1], num_samples, device=root.device, dtype=root.dtype)
-        return (root @ eps).t()
+        eps = torch.randn(*root.shape[:-2], root.shape[-1], num_samples, device=root.device, dtype=root.dtype)
+        return torch.movedim(root @ eps, -1, 0)   # [num_samples, ..., n]: batch operators keep their leading dimensions
 
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
         Lc = self.cholesky()

@@ -47,3 +47,25 @@ def test_batch_noise_and_scale():
     assert het.shape == (3, 2, 5, 5)
     scaled = op.mul(torch.tensor([2.0, 3.0], dtype=torch.float64).view(2, 1, 1))
     assert torch.allclose(scaled.to_dense(), K * torch.tensor([2.0, 3.0], dtype=torch.float64).view(1, 2, 1, 1))
+
+
+def test_root_decomposition_raises_on_non_psd_and_batch_samples_keep_their_shape():
+    """``root_decomposition(method="cholesky")`` on a matrix no jitter level rescues raises (the reference's psd_safe_cholesky raises
+    NotPSDError) instead of returning the failed factor; ``zero_mean_mvn_samples`` keeps batch dimensions ([num, *batch, n])."""
+    import pytest
+
+    from gpytorch_amd.operators import BatchLinearOperator, DenseLinearOperator, NotPSDError
+
+    bad = DenseLinearOperator(-torch.eye(5))
+    with pytest.raises(NotPSDError):
+        bad.root_decomposition(method="cholesky")
+    g = torch.Generator().manual_seed(0)
+    mats = []
+    for _ in range(3):
+        a = torch.randn(6, 6, generator=g)
+        mats.append(a @ a.t() + 0.5 * torch.eye(6))
+    bop = BatchLinearOperator([DenseLinearOperator(m) for m in mats], torch.Size([3]))
+    smp = bop.zero_mean_mvn_samples(7)
+    assert smp.shape == (7, 3, 6)
+    one = DenseLinearOperator(mats[0]).zero_mean_mvn_samples(4)
+    assert one.shape == (4, 6)
