@@ -96,6 +96,20 @@ template <int KIND> __device__ __forceinline__ double cov_any(double s) { return
 template <int KIND> __device__ __forceinline__ float dcov_any(float s) { return dcov_dsq<KIND>(s); }
 template <int KIND> __device__ __forceinline__ double dcov_any(double s) { return dcov_dsq_f64<KIND>(s); }
 
+// Fence between a group of MFMAs whose results land in VGPRs (translation units built with -mllvm -amdgpu-mfma-vgpr-form=1: kvs_*, kvm_*)
+// and the first VALU instruction that reads them.  An MFMA -> VALU read-after-write is NOT interlocked by the hardware; the compiler
+// inserts the wait states of its hazard table (s_nop 11 for v_mfma_f32_32x32x16_f16), which is NOT enough on gfx950 when the consumer
+// follows immediately: kv_gramv_kernel<Matern, D = 3, T = 1> -- v_med3_f32 on the result right after the s_nop -- returned stale values
+// in the lanes of the last passes (output rows 16..31 of a tile; 4 % errors on a quarter of the rows, different from run to run;
+// profiles/r03_s6_gramv_mfma_vgpr_hazard.txt: wrong with the flag, right with the default AGPR destination -- whose v_accvgpr_read IS
+// interlocked -- and right, and 7 % faster, with this fence).  RBF instantiations happened to have enough independent instructions in
+// between.  The fence pins the MFMA group (sched_barrier) and idles 32 further wait states once per 32-row j block.
+__device__ __forceinline__ void mfma_result_fence() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -40,19 +40,7 @@ __device__ __forceinline__ void f16_split(float v, _Float16& hi, _Float16& lo) {
   lo = (_Float16)(v - hf);
 }
 
-// Fence between a group of MFMAs whose results land in VGPRs (translation units built with -mllvm -amdgpu-mfma-vgpr-form=1: kvs_*, kvm_*)
-// and the first VALU instruction that reads them.  An MFMA -> VALU read-after-write is NOT interlocked by the hardware; the compiler
-// inserts the wait states of its hazard table (s_nop 11 for v_mfma_f32_32x32x16_f16), which is NOT enough on gfx950 when the consumer
-// follows immediately: kv_gramv_kernel<Matern, D = 3, T = 1> -- v_med3_f32 on the result right after the s_nop -- returned stale values
-// in the lanes of the last passes (output rows 16..31 of a tile; 4 % errors on a quarter of the rows, different from run to run;
-// profiles/r03_s6_gramv_mfma_vgpr_hazard.txt: wrong with the flag, right with the default AGPR destination -- whose v_accvgpr_read IS
-// interlocked -- and right, and 7 % faster, with this fence).  RBF instantiations happened to have enough independent instructions in
-// between.  The fence pins the MFMA group (sched_barrier) and idles 32 further wait states once per 32-row j block.
-__device__ __forceinline__ void mfma_result_fence() {
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_nop 15\n\ts_nop 15");
-  __builtin_amdgcn_sched_barrier(0);
-}
+// (mfma_result_fence(): common.hpp)
 
 // Block-centred expansion (GPAMD "recentre" mode).  The cancellation error of the quadratic expansion is ~2^-22 (|z_i| + |z_j|)^2: with
 // the cloud centred as a whole it grows with the CLOUD radius (host limit max |z|^2 <= 32).  Squared distances are translation

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void kv_f64_kernel(KvArgs64 a) {
       }
     }
   }
+  mfma_result_fence();   // the accumulators of the last contraction MFMAs are read next (common.hpp; once per workgroup)
   double* Pout = a.P + (int64_t)s * a.pstride;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {

@@ -204,6 +204,7 @@ void kv_gram_kernel(KvArgs a) {
     }
   }
 
+  mfma_result_fence();   // the accumulators of the last contraction MFMAs are read next (common.hpp; once per workgroup)
   float* Pout = a.P + (int64_t)s * a.pstride;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {

@@ -54,11 +54,9 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
     sub_center<DP>(z, cz);
     gram_pack_b<D>(z, h, bq[ni]);
   }
-  float acc1[NI];        // T == 1
   f32x2 acc2[NI][TP];    // T >= 2: column pairs on packed math
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    acc1[ni] = 0.f;
 #pragma unroll
     for (int c = 0; c < TP; ++c) acc2[ni][c] = (f32x2)(0.f);
   }
@@ -99,15 +97,23 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
       for (int g = 0; g < 4; ++g) {
         const int jl = jb + 8 * g + 4 * h;  // this half-wave's 4 consecutive j rows of group g (LDS broadcast reads)
         if constexpr (T == 1) {
+          // one column: two j rows per packed multiply-add (v_pk_fma_f32: the loop is bound by VALU issue -- one v_exp_f32 per pair plus
+          // the multiply-add; pairing halves the latter); the two partial sums are added in the epilogue
           const f32x4 v4 = *reinterpret_cast<const f32x4*>(&Vs[jl]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; e += 2) {
+            const f32x2 vv = {v4[e], v4[e + 1]};
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              float sv = kk[ni][4 * g + e];
-              if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-              acc1[ni] = __builtin_fmaf(cov_from_sq<KIND>(sv, a.kparam), v4[e], acc1[ni]);
+              float s0 = kk[ni][4 * g + e], s1 = kk[ni][4 * g + e + 1];
+              if constexpr (KIND != KIND_RBF) {
+                s0 = __builtin_amdgcn_fmed3f(s0, 0.f, 3.0e38f);
+                s1 = __builtin_amdgcn_fmed3f(s1, 0.f, 3.0e38f);
+              }
+              const f32x2 kv = {cov_from_sq<KIND>(s0, a.kparam), cov_from_sq<KIND>(s1, a.kparam)};
+              acc2[ni][0] = __builtin_elementwise_fma(kv, vv, acc2[ni][0]);
             }
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
     const int i = ibase + ni * 32 + l31;
 #pragma unroll
     for (int c = 0; c < T; ++c) {
-      const float part = T == 1 ? acc1[ni] : acc2[ni][c / 2][c & 1];
+      const float part = T == 1 ? acc2[ni][0][0] + acc2[ni][0][1] : acc2[ni][c / 2][c & 1];
       const float tot = part + __shfl_xor(part, 32, 64);
       if (h == 0 && i < a.n && c < a.t) Pout[(int64_t)c * a.ldo + i] = tot;
     }

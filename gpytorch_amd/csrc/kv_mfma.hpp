@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void kv_mfma_kernel(KvArgs a) {
   }
 
   // epilogue: D[c][i] -> P[s][c][i]
+  mfma_result_fence();   // the accumulators of the last contraction MFMAs are read next (common.hpp; once per workgroup)
   float* Pout = a.P + (int64_t)s * a.pstride;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
