@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 2 ||
 void kv_gram_kernel(KvArgs a) {
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;    // 32x32x16 f16 MFMAs per 32x32 block of squared distances
+  static_assert(NI >= 2, "the MFMA -> VALU ordering below relies on at least two row tiles per wave");
   constexpr int BN = KV_BN, LDT = KV_LDT, TC = 32 * CT;
   __shared__ __attribute__((aligned(16))) float smem[TC * LDT + BN + KH * BN * 8];
   float* Vs = smem;
@@ -163,9 +164,14 @@ void kv_gram_kernel(KvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) kk[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq[ni][kh], kk[ni], 0, 0, 0);
       }
-      mfma_result_fence();   // with the register cap above the distance block lives in VGPRs and the VALU reads it next (gram_f16.hpp)
+      // With the register cap above the distance blocks live in VGPRs and the VALU reads them next: an MFMA -> VALU read-after-write is not
+      // interlocked (common.hpp, mfma_result_fence).  Here no idle fence is needed -- the ORDER is pinned instead: all NI (>= 2) Gram MFMAs
+      // first, then the tiles are converted one after the other.  A second MFMA cannot issue while the first occupies the matrix pipe, so
+      // tile 0 is complete when the last MFMA has issued, and tile ni is read only after the >= 16 transcendental instructions of every
+      // earlier tile (>= 128 cycles against the 32 + pipeline cycles of an 8-pass MFMA).
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+      for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           // RBF: a slightly negative S (cancellation) only makes k = 2^-S exceed 1 by <= 1e-5 -- no clamp needed;
@@ -174,6 +180,8 @@ void kv_gram_kernel(KvArgs a) {
           if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
           kk[ni][r] = cov_from_sq<KIND>(sv, a.kparam);
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 
       // ---- contraction: 16 steps (4 groups of 4), step r pairs rows (r&3)+8(r>>2) and +4 ----
 #pragma unroll
