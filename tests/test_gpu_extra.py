@@ -50,7 +50,7 @@ def test_fixed_heteroskedastic_noise(dev):
     # solve through the operator
     op = lik(m.train().__call__(m.train_inputs[0])).lazy_covariance_matrix
     assert type(op).__name__ == "FusedKernelAddedDiagLinearOperator" and op.noise_vec is not None
-    with torch.no_grad(), S.max_cholesky_size(0), S.cg_tolerance(1e-4):
+    with torch.no_grad(), S.max_cholesky_size(0), S.cg_tolerance(3e-5):   # (at 1e-4 the solve error sits AT the 1e-3 bound: 0.97e-3 .. 1.02e-3 depending on the summation order of the one-column kernel)
         sol = op.solve(y.float().to(dev).unsqueeze(-1))
     assert rel_err(sol, torch.linalg.solve(Kh, y.unsqueeze(-1))) < 1e-3
     assert rel_err(op.diagonal(), Kh.diagonal()) < 1e-5
