@@ -222,3 +222,118 @@ def test_row_sharded_cg_matches_single_process():
         assert iters == info["iters"]
         # (unlike probe sharding, the reduction ORDER changes: rounding differences grow along the CG recurrence)
         assert torch.allclose(sol_loc, sol[r0:r1], rtol=0, atol=1e-6 * float(sol.abs().max()))
+
+
+def _kron_problem():
+    from oracle import kernels as OK
+    from oracle import multitask as OM
+
+    g = torch.Generator().manual_seed(11)
+    n, T = 70, 3
+    X = torch.rand(n, 2, generator=g, dtype=torch.float64)
+    Bf = 0.6 * torch.randn(T, 1, generator=g, dtype=torch.float64)
+    v = 0.2 + 0.3 * torch.rand(T, generator=g, dtype=torch.float64)
+    task_noise = 0.05 + 0.1 * torch.rand(T, generator=g, dtype=torch.float64)
+    K = torch.kron(OK.kernel_matrix("rbf", X, X, 0.3, 1.2, x1_eq_x2=True), OM.task_covar(Bf, v))   # noise-free part, interleaved layout
+    dvec = task_noise.repeat(n)
+    y = torch.randn(n * T, generator=g, dtype=torch.float64)
+    return K, dvec, y
+
+
+def _kron_solve(K, dvec, y, probes, t_total, owns_rhs, mean_fn=None):
+    """The structured-operator MLL ingredients with the product's host pieces (row-callback pivoted Cholesky, vector-diagonal
+    preconditioner) around the oracle's CG: what KroneckerInvQuadLogdetFn runs per rank, the device product replaced by a dense one."""
+    from gpytorch_amd.bbmm import build_preconditioner_rows
+    from oracle import linear_cg as OCG
+    from oracle import slq as OS
+
+    N = K.shape[0]
+    pre = build_preconditioner_rows(lambda p: K[p], K.diagonal().clone(), dvec, True, rank=12, tol=1e-8, min_size=0)
+    ld = pre.q1t.shape[1]
+
+    def papply(R):                                       # oracle layout (n, c) <-> the product's probe-major [c, ld]
+        Rt = torch.zeros(R.shape[1], ld, dtype=R.dtype)
+        Rt[:, :N] = R.t()
+        return pre.apply_(Rt, torch.zeros_like(Rt))[:, :N].t().contiguous()
+
+    t = probes.shape[1]
+    Z = probes / probes.norm(dim=-2, keepdim=True)
+    rhs = torch.cat([Z, y.unsqueeze(-1)], dim=-1) if owns_rhs else Z
+    Khat = K + torch.diag(dvec)
+    sol, Tm, info = OCG.linear_cg(lambda V: Khat @ V, rhs, n_tridiag=t, tolerance=1e-4, max_tridiag_iter=40, return_info=True,
+                                  preconditioner=papply, mean_residual_fn=mean_fn)
+    ld_part = OS.slq_logdet(Tm, N) * (t / t_total)
+    return sol, ld_part, pre, info
+
+
+def _kron_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from gpytorch_amd import distributed as D
+    from gpytorch_amd import settings as S
+    from gpytorch_amd.bbmm import deterministic_probe_matrix, structured_opts
+
+    group = D.init_from_env("gloo")
+    K, dvec, y = _kron_problem()
+    N, t_total = K.shape[0], 6
+    with S.sharding(probe_group=group), S.num_trace_samples(t_total), S.deterministic_probes(True):
+        opts = structured_opts({}, torch.device("cpu"))          # the completion every structured autograd function performs
+        assert opts["group"] is group and opts["t_total"] == t_total
+        a, b = D.probe_shard(t_total, world, rank)
+        assert opts["num_probes"] == b - a
+        torch.manual_seed(99)                                     # identically seeded ranks draw the SAME t_total-column matrix ...
+        probes = deterministic_probe_matrix(N, b - a, torch.device("cpu"), torch.float64, shard=(t_total, a, b))   # ... and keep their columns
+        assert probes.shape == (N, b - a)
+
+        def mean_fn(rnorm):
+            return D.allreduce_residual_stats(rnorm.sum(), torch.tensor(float(rnorm.numel())), group)
+
+        sol, ld_part, pre, info = _kron_solve(K, dvec, y, probes, t_total, rank == 0, mean_fn)
+        D.allreduce_sum_(ld_part, group)
+        ysol = sol[:, -1].clone() if rank == 0 else torch.zeros(N, dtype=sol.dtype)
+        D.broadcast_(ysol, 0, group)
+    q.put((rank, info["iters"], float(ld_part + pre.logdet), float(ysol @ y), probes.numpy(), (a, b)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_probe_sharded_kronecker_mll_matches_single_process():
+    """SURVEY.md 8e for the STRUCTURED operators: the Kronecker multitask system with its per-task (vector) noise, preconditioned
+    by the row-callback pivoted Cholesky, probe-sharded over two ranks == the single-process evaluation with the same six probes
+    (same iteration count, inverse quadratic form and log-determinant), and both agree with dense Cholesky."""
+    sys.path.insert(0, ROOT)
+    from gpytorch_amd import settings as S
+    from gpytorch_amd.bbmm import deterministic_probe_matrix
+
+    world, port = 2, free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_kron_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    K, dvec, y = _kron_problem()
+    N, t_total = K.shape[0], 6
+    with S.deterministic_probes(True):
+        S.deterministic_probes.probe_vectors = None
+        S.deterministic_probes._drawn.clear()
+        torch.manual_seed(99)
+        Z = deterministic_probe_matrix(N, t_total, torch.device("cpu"), torch.float64)
+        sol, ld, pre, info = _kron_solve(K, dvec, y, Z, t_total, True)
+        S.deterministic_probes.probe_vectors = None
+        S.deterministic_probes._drawn.clear()
+    logdet = float(ld + pre.logdet)
+    inv_quad = float(sol[:, -1] @ y)
+    for rank, iters, ldr, iqr, pr, (a, b) in results:
+        assert torch.equal(torch.from_numpy(pr), Z[:, a:b])       # t_total DISTINCT probes over the ranks, the single-process ones
+        assert iters == info["iters"]
+        assert abs(ldr - logdet) < 1e-9 * abs(logdet)
+        assert abs(iqr - inv_quad) < 1e-9 * abs(inv_quad)
+    Khat = K + torch.diag(dvec)
+    assert abs(inv_quad - float(y @ torch.linalg.solve(Khat, y))) < 1e-5 * abs(inv_quad)
+    assert abs(logdet - float(torch.logdet(Khat))) < 0.1 * abs(float(torch.logdet(Khat)))       # six probes: a stochastic estimate
