@@ -67,13 +67,15 @@ SIGNATURES = {
     "gpamd_precond_apply_f32f64": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _p, _p, _p, _i64, _p]),
     "gpamd_kv_grad_workspace_doubles": (_i64, [_i, _i, _i, _i]),
     # ---- float64 section
-    "gpamd_prep_points_f64": (_i, [_i, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
-    "gpamd_kernel_rows_f64": (_i, [_i, _p, _p, _i64, _i, _p, _i, _i, _p, _p, _i64, _p]),
-    "gpamd_kernel_diag_f64": (_i, [_i, _p, _p, _i, _i, _p, _p, _p]),
+    "gpamd_kernel_dense_batched_f32": (_i, [_i, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i64, _p]),
+    "gpamd_kernel_grad_batched_f32": (_i, [_i, _p, _p, _i, _p, _i, _i, _i, _p, _i64, _p, _p]),
+    "gpamd_prep_points_f64": (_i, [_i, C.c_double, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
+    "gpamd_kernel_rows_f64": (_i, [_i, C.c_double, _p, _p, _i64, _i, _p, _i, _i, _p, _p, _i64, _p]),
+    "gpamd_kernel_diag_f64": (_i, [_i, C.c_double, _p, _p, _i, _i, _p, _p, _p]),
     "gpamd_kv_plan_f64": (_i, [_i, _i, _i, _i, _i64, _p, _p, _p]),
-    "gpamd_kv_partials_f64": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _i64, _i, _i, _p, _p]),
-    "gpamd_kernel_grad_block_f32": (_i, [_i, _p, _i64, _i, _p, _i, _i, _p, _i64, _p, _p]),
-    "gpamd_kernel_grad_block_f64": (_i, [_i, _p, _i64, _i, _p, _i, _i, _p, _i64, _p, _p]),
+    "gpamd_kv_partials_f64": (_i, [_i, C.c_double, _p, _i, _p, _i, _i, _p, _i64, _i, _p, _i64, _i, _i, _p, _p]),
+    "gpamd_kernel_grad_block_f32": (_i, [_i, C.c_double, _p, _i64, _i, _p, _i, _i, _p, _i64, _p, _p]),
+    "gpamd_kernel_grad_block_f64": (_i, [_i, C.c_double, _p, _i64, _i, _p, _i, _i, _p, _i64, _p, _p]),
     "gpamd_coldot_f64": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
     "gpamd_kv_reduce_f64": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "gpamd_cg64_fscratch_elems": (_i64, [_i, _i]),
@@ -112,7 +114,7 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if h.gpamd_abi_version() != 2:
+        if h.gpamd_abi_version() != 3:
             raise GpamdError("libgpamd.so ABI version mismatch")
         _lib = h
     return _lib

@@ -274,8 +274,6 @@ def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: to
         if param is None:
             raise ValueError("the rational-quadratic family needs its shape parameter alpha")
         param = float(param)
-        if work_dtype(x) != torch.float32 or x.shape[-1] > MAX_INPUT_DIM:
-            raise NotImplementedError("RQKernel runs on the fused float32 kernels only (float32 inputs, d <= 16)")
         if not param > 0.0:
             raise ValueError("the rational-quadratic shape parameter alpha must be positive")
     else:
@@ -290,7 +288,7 @@ def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: to
     sh = None if shift is None else shift.detach().to(device=x.device, dtype=wd).reshape(-1).contiguous()
     xp = torch.empty(n, dp, device=x.device, dtype=wd)
     fn = lib().gpamd_prep_points_f64 if wd == torch.float64 else lib().gpamd_prep_points_f32
-    lead = (KIND_IDS[kind],) if wd == torch.float64 else (KIND_IDS[kind], param if param is not None else 0.0)
+    lead = (KIND_IDS[kind], param if param is not None else 0.0)
     check(fn(*lead, _ptr(x), n, d, x.stride(0), _ptr(ls), ls.numel(), _ptr(sh), _ptr(xp), dp, _stream(x.device)), "prep_points")
     return PreparedPoints(xp, n, d, dp, kind, param)
 
@@ -421,7 +419,7 @@ def kernel_row_block(x1: PreparedPoints, r0: int, nrows: int, x2: PreparedPoints
     st = _stream(out.device)
     if x1.dtype == torch.float64:
         sc = None if scale is None else scale.to(torch.float64)
-        check(lib().gpamd_kernel_rows_f64(kind_id(x1), _ptr(x1.xp), None, r0, nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(sc),
+        check(lib().gpamd_kernel_rows_f64(*kind_args(x1), _ptr(x1.xp), None, r0, nrows, _ptr(x2.xp), x2.n, x1.dp, _ptr(sc),
                                           _ptr(out), out.stride(0), st), "kernel_rows_f64")
     else:
         blk = x1.xp[r0 : r0 + nrows]
@@ -451,7 +449,7 @@ def kv_partials_f64(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, do
     if buf is None or buf.numel() < ws.value:
         buf = torch.empty(max(ws.value, 1 << 18), device=vt.device, dtype=torch.float64)
         _ws_cache[key] = buf
-    check(lib().gpamd_kv_partials_f64(kind_id(x1), _ptr(x1.xp), n, _ptr(x2.xp), m, x1.dp, _ptr(vt), vt.stride(0), t, _ptr(buf),
+    check(lib().gpamd_kv_partials_f64(*kind_args(x1), _ptr(x1.xp), n, _ptr(x2.xp), m, x1.dp, _ptr(vt), vt.stride(0), t, _ptr(buf),
                                       ldo, S.value, jc.value, done_ptr, _stream(vt.device)), "kv_partials_f64")
     return buf, S.value, ldo
 
@@ -520,7 +518,7 @@ def kernel_rows(x1: PreparedPoints, rows: torch.Tensor, x2: PreparedPoints, scal
     if x1.dtype == torch.float64:
         out = torch.empty(rows.numel(), x2.n, device=x1.xp.device, dtype=torch.float64)
         sc = None if scale is None else scale.to(torch.float64)
-        check(lib().gpamd_kernel_rows_f64(kind_id(x1), _ptr(x1.xp), _ptr(rows), 0, rows.numel(), _ptr(x2.xp), x2.n, x1.dp,
+        check(lib().gpamd_kernel_rows_f64(*kind_args(x1), _ptr(x1.xp), _ptr(rows), 0, rows.numel(), _ptr(x2.xp), x2.n, x1.dp,
                                           _ptr(sc), _ptr(out), out.stride(0), _stream(out.device)), "kernel_rows_f64")
         return out
     out = torch.empty(rows.numel(), x2.n, device=x1.xp.device, dtype=torch.float32)
@@ -539,7 +537,7 @@ def kernel_diag(x1: PreparedPoints, x2: PreparedPoints, scale=None) -> torch.Ten
     if x1.dtype == torch.float64:
         out = torch.empty(x1.n, device=x1.xp.device, dtype=torch.float64)
         sc = None if scale is None else scale.to(torch.float64)
-        check(lib().gpamd_kernel_diag_f64(kind_id(x1), _ptr(x1.xp), _ptr(x2.xp), x1.n, x1.dp, _ptr(sc), _ptr(out),
+        check(lib().gpamd_kernel_diag_f64(*kind_args(x1), _ptr(x1.xp), _ptr(x2.xp), x1.n, x1.dp, _ptr(sc), _ptr(out),
                                           _stream(out.device)), "kernel_diag_f64")
         return out
     out = torch.empty(x1.n, device=x1.xp.device, dtype=torch.float32)
@@ -691,7 +689,8 @@ def prep_coef_of(xp: PreparedPoints) -> float:
 
 
 def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor) -> torch.Tensor:
-    """Generic-path (float64, or d > 16) twin of :func:`kv_grad`; same return convention, float64 [1 + dp].
+    """Generic-path (float64, or d > 16) twin of :func:`kv_grad`; same return convention, float64 [2 + dp] (the last element is the
+    shape-parameter sum  sum W dk/dp|_s  of a parametrised family -- RQ's alpha --, zero otherwise: as :func:`kv_grad2`).
 
     Per row block: W = left^T right (library GEMM) -> HIP ``gpamd_kernel_grad_block`` turns it into A = W * dk/ds and
     accumulates sum W*k -> the per-dimension sums  sum_ij A_ij (z_iq - z_jq)^2  expand into row sums, column sums and
@@ -701,7 +700,7 @@ def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt
     n, m, dp, dt = x1.n, x2.n, x1.dp, x1.dtype
     dev = lt.device
     fn = lib().gpamd_kernel_grad_block_f64 if dt == torch.float64 else lib().gpamd_kernel_grad_block_f32
-    acc = torch.zeros(1, device=dev, dtype=torch.float64)
+    acc = torch.zeros(2, device=dev, dtype=torch.float64)
     gq = torch.zeros(dp, device=dev, dtype=torch.float64)
     cs = torch.zeros(m, device=dev, dtype=torch.float64)
     z1, z2 = x1.xp.to(torch.float64), x2.xp.to(torch.float64)
@@ -711,13 +710,13 @@ def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt
     for r0 in range(0, n, rows):
         nr = min(rows, n - r0)
         w = (lt[:, r0 : r0 + nr].to(dt).t() @ r_all).contiguous()
-        check(fn(kind_id(x1), _ptr(x1.xp), r0, nr, _ptr(x2.xp), m, dp, _ptr(w), w.stride(0), _ptr(acc), st), "kernel_grad_block")
+        check(fn(*kind_args(x1), _ptr(x1.xp), r0, nr, _ptr(x2.xp), m, dp, _ptr(w), w.stride(0), _ptr(acc), st), "kernel_grad_block")
         a = w.to(torch.float64)
         zb = z1[r0 : r0 + nr]
         gq += (zb.pow(2) * a.sum(1, keepdim=True)).sum(0) - 2.0 * (zb * (a @ z2)).sum(0)
         cs += a.sum(0)
     gq += (z2.pow(2) * cs.unsqueeze(-1)).sum(0)
-    return torch.cat([acc, gq])
+    return torch.cat([acc[:1], gq, acc[1:]])
 
 
 # d s / d l factors: s = sum_q z_q^2-differences with z = coef * x / l  =>  ds_q/dl_q = -2 s_q / l_q

@@ -91,10 +91,10 @@ __device__ __forceinline__ double dcov_dsq_f64(double s, double p = 0.0) {
 }
 
 // scalar-type dispatch for the kernels templated on T (generic path)
-template <int KIND> __device__ __forceinline__ float cov_any(float s) { return cov_from_sq<KIND>(s); }
-template <int KIND> __device__ __forceinline__ double cov_any(double s) { return cov_from_sq_f64<KIND>(s); }
-template <int KIND> __device__ __forceinline__ float dcov_any(float s) { return dcov_dsq<KIND>(s); }
-template <int KIND> __device__ __forceinline__ double dcov_any(double s) { return dcov_dsq_f64<KIND>(s); }
+template <int KIND> __device__ __forceinline__ float cov_any(float s, float p = 0.f) { return cov_from_sq<KIND>(s, p); }
+template <int KIND> __device__ __forceinline__ double cov_any(double s, double p = 0.0) { return cov_from_sq_f64<KIND>(s, p); }
+template <int KIND> __device__ __forceinline__ float dcov_any(float s, float p = 0.f) { return dcov_dsq<KIND>(s, p); }
+template <int KIND> __device__ __forceinline__ double dcov_any(double s, double p = 0.0) { return dcov_dsq_f64<KIND>(s, p); }
 
 // Fence between a group of MFMAs whose results land in VGPRs (translation units built with -mllvm -amdgpu-mfma-vgpr-form=1: kvs_*, kvm_*)
 // and the first VALU instruction that reads them.  An MFMA -> VALU read-after-write is NOT interlocked by the hardware; the compiler

@@ -35,8 +35,9 @@ int launch_ok(const char* what) {
   }
   return 0;
 }
-double prep_coef64(int kind) {
+double prep_coef64(int kind, double kparam) {
   switch (kind) {
+    case GPAMD_RQ: return 1.0 / sqrt(2.0 * kparam);   // (1 + |x - x'|^2 / (2 alpha l^2))^-alpha = (1 + |z - z'|^2)^-alpha
     case GPAMD_RBF: return sqrt(0.5 * 1.4426950408889634);
     case GPAMD_MATERN12: return 1.0;
     case GPAMD_MATERN32: return sqrt(3.0);
@@ -62,46 +63,47 @@ __global__ void prep_points_f64_kernel(const double* __restrict__ X, int n, int 
 }
 
 template <int KIND>
-__device__ __forceinline__ double cov_pair64(const double* __restrict__ a, const double* __restrict__ b, int DP) {
+__device__ __forceinline__ double cov_pair64(const double* __restrict__ a, const double* __restrict__ b, int DP, double p) {
   double sq = 0.0;
   for (int k = 0; k < DP; ++k) {
     double df = a[k] - b[k];
     sq = fma(df, df, sq);
   }
-  return cov_from_sq_f64<KIND>(sq);
+  return cov_from_sq_f64<KIND>(sq, p);
 }
 
 // out[r][j] = scale * k(X1p[row(r)], X2p[j]);  rows == nullptr: row(r) = r0 + r  (dense row block)
 template <int KIND>
 __global__ void kernel_rows_f64_kernel(const double* __restrict__ X1p, const int64_t* __restrict__ rows, int64_t r0,
                                        const double* __restrict__ X2p, int m, int DP, const double* __restrict__ scale,
-                                       double* __restrict__ out, int64_t ldo) {
+                                       double* __restrict__ out, int64_t ldo, double p) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int r = blockIdx.y;
   if (j >= m) return;
   const int64_t i = rows ? rows[r] : r0 + r;
-  out[(int64_t)r * ldo + j] = (scale ? *scale : 1.0) * cov_pair64<KIND>(X1p + i * DP, X2p + (int64_t)j * DP, DP);
+  out[(int64_t)r * ldo + j] = (scale ? *scale : 1.0) * cov_pair64<KIND>(X1p + i * DP, X2p + (int64_t)j * DP, DP, p);
 }
 
 template <int KIND>
 __global__ void kernel_diag_f64_kernel(const double* __restrict__ X1p, const double* __restrict__ X2p, int n, int DP,
-                                       const double* __restrict__ scale, double* __restrict__ out) {
+                                       const double* __restrict__ scale, double* __restrict__ out, double p) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  out[i] = (scale ? *scale : 1.0) * cov_pair64<KIND>(X1p + (int64_t)i * DP, X2p + (int64_t)i * DP, DP);
+  out[i] = (scale ? *scale : 1.0) * cov_pair64<KIND>(X1p + (int64_t)i * DP, X2p + (int64_t)i * DP, DP, p);
 }
 
 // Generic-path bilinear derivative, one row block:  W[r][j] (r < nb, j < m) holds left^T right on entry and
-// W * dk/ds on exit (s = squared prepared distance);  acc[0] += sum_rj W[r][j] * k(x1[r0 + r], x2[j]).
+// W * dk/ds on exit (s = squared prepared distance);  acc[0] += sum_rj W[r][j] * k(x1[r0 + r], x2[j]) and, for a family with a
+// shape parameter p (RQ: alpha), acc[1] += sum_rj W[r][j] * dk/dp at fixed s.
 // The per-dimension sums  sum_rj (W dk/ds)_rj (z_rq - z_jq)^2  are then three GEMM-shaped reductions on the host side
 // (backend.py::kv_grad_generic) -- no per-dimension register arrays, so any input dimension works.
 template <int KIND, typename T>
 __global__ __launch_bounds__(256) void grad_block_kernel(const T* __restrict__ X1p, int64_t r0, const T* __restrict__ X2p, int m,
-                                                         int DP, T* __restrict__ W, int64_t ldw, double* __restrict__ acc) {
+                                                         int DP, T* __restrict__ W, int64_t ldw, double* __restrict__ acc, T p) {
   __shared__ double red[4];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
-  double part = 0.0;
+  double part = 0.0, ppart = 0.0;
   if (j < m) {
     const T* a = X1p + (r0 + r) * DP;
     const T* b = X2p + (int64_t)j * DP;
@@ -111,22 +113,29 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const T* __restrict__ X
       sq += df * df;
     }
     const T w = W[(int64_t)r * ldw + j];
-    part = (double)w * (double)cov_any<KIND>(sq);
-    W[(int64_t)r * ldw + j] = w * dcov_any<KIND>(sq);
+    const T kv = cov_any<KIND>(sq, p);
+    part = (double)w * (double)kv;
+    if constexpr (KIND == KIND_RQ) ppart = -(double)w * (double)kv * log1p((double)sq);   // k = (1 + s)^-p  ->  dk/dp = -k ln(1 + s)
+    W[(int64_t)r * ldw + j] = w * dcov_any<KIND>(sq, p);
   }
   part = block_sum_256(part, red);
   if (threadIdx.x == 0 && part != 0.0) atomicAdd(acc, part);
+  if constexpr (KIND == KIND_RQ) {
+    __syncthreads();
+    ppart = block_sum_256(ppart, red);
+    if (threadIdx.x == 0 && ppart != 0.0) atomicAdd(acc + 1, ppart);
+  }
 }
 
 template <typename T>
-int grad_block_launch(int kind, const T* X1p, int64_t row0, int nrows, const T* X2p, int m, int dp, T* W, int64_t ldw,
+int grad_block_launch(int kind, double kparam, const T* X1p, int64_t row0, int nrows, const T* X2p, int m, int dp, T* W, int64_t ldw,
                       double* acc, void* stream) {
   if (nrows <= 0 || m <= 0 || nrows > 65535 || dp <= 0 || ldw < m) return fail64(GPAMD_EINVAL, "kernel_grad_block: bad shape (1 <= nrows <= 65535)");
   dim3 grid((m + 255) / 256, nrows);
   switch (kind) {
 #define GB(KE, KK) \
-  case KE: hipLaunchKernelGGL((grad_block_kernel<KK, T>), grid, dim3(256), 0, (hipStream_t)stream, X1p, row0, X2p, m, dp, W, ldw, acc); break;
-    GB(GPAMD_RBF, KIND_RBF) GB(GPAMD_MATERN12, KIND_MATERN12) GB(GPAMD_MATERN32, KIND_MATERN32) GB(GPAMD_MATERN52, KIND_MATERN52)
+  case KE: hipLaunchKernelGGL((grad_block_kernel<KK, T>), grid, dim3(256), 0, (hipStream_t)stream, X1p, row0, X2p, m, dp, W, ldw, acc, (T)kparam); break;
+    GB(GPAMD_RBF, KIND_RBF) GB(GPAMD_MATERN12, KIND_MATERN12) GB(GPAMD_MATERN32, KIND_MATERN32) GB(GPAMD_MATERN52, KIND_MATERN52) GB(GPAMD_RQ, KIND_RQ)
 #undef GB
     default: return fail64(GPAMD_EINVAL, "unknown kind");
   }
@@ -139,6 +148,7 @@ int grad_block_launch(int kind, const T* X1p, int64_t row0, int nrows, const T* 
     case GPAMD_MATERN12: { constexpr int KK = KIND_MATERN12; CALL; } break;    \
     case GPAMD_MATERN32: { constexpr int KK = KIND_MATERN32; CALL; } break;    \
     case GPAMD_MATERN52: { constexpr int KK = KIND_MATERN52; CALL; } break;    \
+    case GPAMD_RQ: { constexpr int KK = KIND_RQ; CALL; } break;                \
     default: return fail64(GPAMD_EINVAL, "unknown kind");                      \
   }
 
@@ -170,6 +180,7 @@ const void* kv64_ptr(int kind, int dp, int ct) {
     case GPAMD_MATERN12: return kv64_ptr_dp<KIND_MATERN12>(dp, ct);
     case GPAMD_MATERN32: return kv64_ptr_dp<KIND_MATERN32>(dp, ct);
     case GPAMD_MATERN52: return kv64_ptr_dp<KIND_MATERN52>(dp, ct);
+    case GPAMD_RQ: return kv64_ptr_dp<KIND_RQ>(dp, ct);
   }
   return nullptr;
 }
@@ -182,39 +193,40 @@ struct gpamd_cg64 {
 
 extern "C" {
 
-int gpamd_prep_points_f64(int kind, const double* X, int n, int d, int64_t ldx, const double* ls, int nls,
+int gpamd_prep_points_f64(int kind, double kparam, const double* X, int n, int d, int64_t ldx, const double* ls, int nls,
                           const double* shift, double* Xp, int dp, void* stream) {
-  if (kind < 0 || kind > 3 || n <= 0 || d <= 0 || dp < d || (nls != 1 && nls != d)) return fail64(GPAMD_EINVAL, "prep_points_f64: bad shape");
+  if (kind < 0 || kind > GPAMD_RQ || n <= 0 || d <= 0 || dp < d || (nls != 1 && nls != d)) return fail64(GPAMD_EINVAL, "prep_points_f64: bad shape");
+  if (kind == GPAMD_RQ && !(kparam > 0.0)) return fail64(GPAMD_EINVAL, "prep_points_f64: the rational-quadratic shape parameter alpha must be positive");
   long total = (long)n * dp;
   hipLaunchKernelGGL(prep_points_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, n, d,
-                     ldx, ls, nls, shift, prep_coef64(kind), Xp, dp);
+                     ldx, ls, nls, shift, prep_coef64(kind, kparam), Xp, dp);
   return launch_ok("prep_points_f64");
 }
 
-int gpamd_kernel_rows_f64(int kind, const double* X1p, const int64_t* rows, int64_t row0, int nrows, const double* X2p, int m,
+int gpamd_kernel_rows_f64(int kind, double kparam, const double* X1p, const int64_t* rows, int64_t row0, int nrows, const double* X2p, int m,
                           int dp, const double* scale, double* out, int64_t ldo, void* stream) {
   if (nrows <= 0 || m <= 0 || nrows > 65535) return fail64(GPAMD_EINVAL, "kernel_rows_f64: bad shape (1 <= nrows <= 65535)");
   dim3 grid((m + 255) / 256, nrows);
   KIND_SWITCH64(kind, hipLaunchKernelGGL((kernel_rows_f64_kernel<KK>), grid, dim3(256), 0, (hipStream_t)stream, X1p, rows, row0,
-                                         X2p, m, dp, scale, out, ldo));
+                                         X2p, m, dp, scale, out, ldo, kparam));
   return launch_ok("kernel_rows_f64");
 }
 
-int gpamd_kernel_diag_f64(int kind, const double* X1p, const double* X2p, int n, int dp, const double* scale, double* out,
+int gpamd_kernel_diag_f64(int kind, double kparam, const double* X1p, const double* X2p, int n, int dp, const double* scale, double* out,
                           void* stream) {
   if (n <= 0) return fail64(GPAMD_EINVAL, "kernel_diag_f64: bad shape");
   KIND_SWITCH64(kind, hipLaunchKernelGGL((kernel_diag_f64_kernel<KK>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                                         X1p, X2p, n, dp, scale, out));
+                                         X1p, X2p, n, dp, scale, out, kparam));
   return launch_ok("kernel_diag_f64");
 }
 
-int gpamd_kernel_grad_block_f32(int kind, const float* X1p, int64_t row0, int nrows, const float* X2p, int m, int dp, float* W,
+int gpamd_kernel_grad_block_f32(int kind, double kparam, const float* X1p, int64_t row0, int nrows, const float* X2p, int m, int dp, float* W,
                                 int64_t ldw, double* acc, void* stream) {
-  return grad_block_launch<float>(kind, X1p, row0, nrows, X2p, m, dp, W, ldw, acc, stream);
+  return grad_block_launch<float>(kind, kparam, X1p, row0, nrows, X2p, m, dp, W, ldw, acc, stream);
 }
-int gpamd_kernel_grad_block_f64(int kind, const double* X1p, int64_t row0, int nrows, const double* X2p, int m, int dp, double* W,
+int gpamd_kernel_grad_block_f64(int kind, double kparam, const double* X1p, int64_t row0, int nrows, const double* X2p, int m, int dp, double* W,
                                 int64_t ldw, double* acc, void* stream) {
-  return grad_block_launch<double>(kind, X1p, row0, nrows, X2p, m, dp, W, ldw, acc, stream);
+  return grad_block_launch<double>(kind, kparam, X1p, row0, nrows, X2p, m, dp, W, ldw, acc, stream);
 }
 
 int gpamd_kv_plan_f64(int n, int m, int dp, int t, int64_t ldo, int* S, int* jchunk, int64_t* workspace_doubles) {
@@ -233,9 +245,9 @@ int gpamd_kv_plan_f64(int n, int m, int dp, int t, int64_t ldo, int* S, int* jch
   return 0;
 }
 
-int gpamd_kv_partials_f64(int kind, const double* X1p, int n, const double* X2p, int m, int dp, const double* Vt, int64_t ldv,
+int gpamd_kv_partials_f64(int kind, double kparam, const double* X1p, int n, const double* X2p, int m, int dp, const double* Vt, int64_t ldv,
                           int t, double* P, int64_t ldo, int S, int jchunk, const int* done, void* stream) {
-  if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || S <= 0 || jchunk <= 0 || jchunk % KV64_BN || ldv < m || ldo < n)
+  if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || S <= 0 || jchunk <= 0 || jchunk % KV64_BN || ldv < m || ldo < n)
     return fail64(GPAMD_EINVAL, "kv_partials_f64: bad shape");
   if (dp != 4 && dp != 8) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: fused float64 kernel needs d <= 8 (generic path otherwise)");
   for (int g0 = 0; g0 < t;) {
@@ -250,6 +262,7 @@ int gpamd_kv_partials_f64(int kind, const double* X1p, int n, const double* X2p,
     a.S = S; a.jchunk = jchunk;
     a.nrb = (n + kv64_bm(ct) - 1) / kv64_bm(ct);
     a.done = done;
+    a.kparam = kparam;
     const void* fn = kv64_ptr(kind, dp, ct);
     if (!fn) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: no kernel variant");
     void* kargs[] = {(void*)&a};

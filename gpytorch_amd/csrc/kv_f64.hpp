@@ -23,6 +23,7 @@ struct KvArgs64 {
   int n, m, t;
   int S, jchunk, nrb;
   const int* done;
+  double kparam;     // shape parameter of the family (RQ: alpha)
 };
 
 typedef double f64x4v __attribute__((ext_vector_type(4)));
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void kv_f64_kernel(KvArgs64 a) {
           const double df = zi[ni][k] - zj[k];
           sq = fma(df, df, sq);
         }
-        const double kv = cov_from_sq_f64<KIND>(sq);
+        const double kv = cov_from_sq_f64<KIND>(sq, a.kparam);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[ni][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct], kv, acc[ni][ct], 0, 0, 0);
       }

@@ -59,9 +59,9 @@ def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t, want_x1=Fal
                 "gradients with respect to the inputs need the Gram-form derivative kernel (float32, d <= 16, RBF / Matern "
                 "3/2 / 5/2, max |x / lengthscale|^2 within the accuracy policy); this operator is outside it"
             )
-        if xp1.fused and xp2.fused:
+        if xp1.fused and xp2.fused and xp1.kind != "rq":
             g = B.kv_grad(xp1, xp2, left_t, right_t, iso=iso)
-        else:
+        else:  # float64, d > 16, or a parametrised family outside the Gram-form accuracy policy
             g = B.kv_grad_generic(xp1, xp2, left_t, right_t).to(wd)
     d = xp1.d
     theta = 1.0 if outputscale is None else outputscale.detach().reshape(()).to(wd)

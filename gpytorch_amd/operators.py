@@ -1061,6 +1061,16 @@ class BatchLinearOperator(LinearOperator):
     def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
         rs = [None] * len(self.ops) if inv_quad_rhs is None else self._split(inv_quad_rhs if inv_quad_rhs.dim() > len(self._batch_shape) + 1
                                                                               else inv_quad_rhs.unsqueeze(-1), 2)
+        from .batched import batched_inv_quad_logdet, members_stackable
+
+        if members_stackable(self.ops):
+            # small members (Cholesky branch): all of them in a batch-size-independent number of launches (batched.py)
+            n = self.ops[0].shape[-1]
+            rr = [torch.zeros(n, 1, device=self.device, dtype=self.dtype) if r is None else r for r in rs]   # (log-det alone: a dummy column)
+            iq, ld = batched_inv_quad_logdet(self.ops, rr)
+            iq = iq.sum(-1) if reduce_inv_quad else iq
+            iq = None if inv_quad_rhs is None else iq.reshape(*self._batch_shape, *iq.shape[1:])
+            return iq, (ld.reshape(self._batch_shape) if logdet else None)
         res = [o.inv_quad_logdet(r, logdet, reduce_inv_quad) for o, r in zip(self.ops, rs)]
         iq = None if inv_quad_rhs is None else self._stack(r[0] for r in res)
         ld = self._stack(r[1] for r in res) if logdet else None

@@ -256,6 +256,15 @@ class cg_graph(_feature_flag):
     max_work = 1.0e10
 
 
+class batched_small_members(_feature_flag):
+    """(no counterpart in the reference, whose dense batch mode is batched by construction.)  A batch of independent exact GPs whose
+    members are factorised (``n <= max_cholesky_size``) evaluates its marginal log likelihood with a launch count that does not depend
+    on the batch size: ONE launch generates every member's dense covariance matrix, the factorisation / solves are torch's batched
+    Cholesky, ONE launch reduces every member's kernel derivative (``gpytorch_amd/batched.py``, ``csrc/extra_batch.hip``).
+    ``batched_small_members(False)`` keeps the launch plan over members (one Cholesky branch per member)."""
+    _default = True
+
+
 class split_contraction(_feature_flag):
     """(no counterpart in the reference.)  With five or more right-hand sides the fused ``K @ V`` contraction runs on the f16
     matrix pipe at float32 accuracy: both operands are split exactly into f16 hi + lo parts (21-22 significant bits, per-column

@@ -24,15 +24,16 @@
 extern "C" {
 #endif
 
-#define GPAMD_ABI_VERSION 2
+#define GPAMD_ABI_VERSION 3
 
 /* covariance families: gpytorch/kernels/rbf_kernel.py:68-85, matern_kernel.py:85-110 (nu = 1/2, 3/2, 5/2) */
 enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3,
        GPAMD_RQ = 4 /* rational quadratic (gpytorch/kernels/rq_kernel.py:60-74): k = (1 + |z - z'|^2)^-alpha on points prepared as
-                       x / (l sqrt(2 alpha)); float32 fused path only */ };
+                       x / (l sqrt(2 alpha)); float32 and float64, any input dimension */ };
 /* `kparam`: shape parameter of the parametrised covariance families (RQ: alpha > 0; ignored by the others), an EXPLICIT argument of
  * every entry point that evaluates the covariance or prepares points for it (ABI version 2: the library holds no per-thread kernel
- * state, so operators with different alpha may interleave freely on one thread -- AdditiveKernel(RQ, RQ)). */
+ * state, so operators with different alpha may interleave freely on one thread -- AdditiveKernel(RQ, RQ)).  ABI version 3: the
+ * float64 / generic entry points take it too (`double kparam`), so the family runs on every path. */
 
 enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 
@@ -245,15 +246,30 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
                        int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, int flags, float* sworkspace,
                        int64_t sworkspace_floats, void* stream);
 
+/* ---- batches of SMALL independent GPs (gpytorch/kernels/kernel.py:163-208 batch_shape; test/examples/test_batch_gp_regression.py).
+ * Members below settings.max_cholesky_size are factorised, not iterated: what the member loop costs there is launches.  These two
+ * entry points make the launch count independent of the batch size (blockIdx.z = member).  b members of n (resp. m) prepared points
+ * each, stored back to back: X1p [b][n][dp], X2p [b][m][dp] (gpamd_prep_points_f32 per member, or the same arithmetic by the
+ * caller); kparam [b] (RQ; NULL otherwise), scale [b] or NULL, dadd [b] or NULL (added on the diagonal i == j: K_hat in one pass).
+ * out [b][n][ldo]:  out[g][i][j] = scale[g] k(x1_gi, x2_gj) + [i == j] dadd[g]   -- replaces the batched `Kernel.forward` +
+ * `to_dense()` + `add_diagonal` of a batch-mode ExactGP (kernels/kernel.py:318-330, likelihoods/gaussian_likelihood.py:117-121). */
+int gpamd_kernel_dense_batched_f32(int kind, const float* kparam, const float* X1p, int n, const float* X2p, int m, int dp, int b,
+                                   const float* scale, const float* dadd, float* out, int64_t ldo, void* stream);
+/* Batched bilinear derivative (the kernel backward of every member in one launch; functions/rbf_covariance.py:26-29,
+ * matern_covariance.py:53-56): W [b][n][ldw] = d loss / d K_g;  G [b][2 + dp] (device doubles, zeroed here):
+ * G[g][0] = sum W k,  G[g][1 + q] = sum W dk/ds (z_iq - z_jq)^2,  G[g][1 + dp] = sum W dk/dkparam at fixed s (RQ; 0 otherwise). */
+int gpamd_kernel_grad_batched_f32(int kind, const float* kparam, const float* X1p, int n, const float* X2p, int m, int dp, int b,
+                                  const float* W, int64_t ldw, double* G, void* stream);
+
 /* ---- float64 (the reference honours float64 inputs).  Same conventions with double buffers.  The fused MFMA K*V
  * kernels are float32-only; in float64 K @ V is formed from dense row blocks of K generated by
  * gpamd_kernel_rows_f64 (rows == NULL: the block [row0, row0 + nrows)) times V with a library DGEMM by the caller,
  * then fed to the same device-resident mBCG through gpamd_cg64_reduce_q (S = 1). ---- */
-int gpamd_prep_points_f64(int kind, const double* X, int n, int d, int64_t ldx, const double* ls, int nls,
+int gpamd_prep_points_f64(int kind, double kparam, const double* X, int n, int d, int64_t ldx, const double* ls, int nls,
                           const double* shift, double* Xp, int dp, void* stream);
-int gpamd_kernel_rows_f64(int kind, const double* X1p, const int64_t* rows, int64_t row0, int nrows, const double* X2p, int m,
+int gpamd_kernel_rows_f64(int kind, double kparam, const double* X1p, const int64_t* rows, int64_t row0, int nrows, const double* X2p, int m,
                           int dp, const double* scale, double* out, int64_t ldo, void* stream);
-int gpamd_kernel_diag_f64(int kind, const double* X1p, const double* X2p, int n, int dp, const double* scale, double* out,
+int gpamd_kernel_diag_f64(int kind, double kparam, const double* X1p, const double* X2p, int n, int dp, const double* scale, double* out,
                           void* stream);
 /* Fused float64 K*V (kv_f64.hpp: float64 generation on the VALU, contraction on v_mfma_f64_16x16x4_f64; d <= 8, else
  * GPAMD_EUNSUPPORTED and the caller uses the row-block path).  Same partial-slab convention as gpamd_kv_partials_f32:
@@ -261,15 +277,16 @@ int gpamd_kernel_diag_f64(int kind, const double* X1p, const double* X2p, int n,
  * KernelLinearOperator._matmul / LazyEvaluatedKernelTensor._matmul (lazy_evaluated_kernel_tensor.py:245-275) for
  * float64 models. */
 int gpamd_kv_plan_f64(int n, int m, int dp, int t, int64_t ldo, int* S, int* jchunk, int64_t* workspace_doubles);
-int gpamd_kv_partials_f64(int kind, const double* X1p, int n, const double* X2p, int m, int dp, const double* Vt, int64_t ldv,
+int gpamd_kv_partials_f64(int kind, double kparam, const double* X1p, int n, const double* X2p, int m, int dp, const double* Vt, int64_t ldv,
                           int t, double* P, int64_t ldo, int S, int jchunk, const int* done, void* stream);
 /* Generic-path bilinear derivative, one row block (any dp; replaces, for float64 / d > 16, what gpamd_kv_grad_f32 does
  * fused; reference: the kernel backward, gpytorch/functions/rbf_covariance.py:26-29, matern_covariance.py:53-56).
  * W [nrows, ldw]: left^T right on entry, W * dk/ds on exit (s = squared prepared distance);
- * acc[0] += sum W * k  (acc: one device double, zeroed by the caller). */
-int gpamd_kernel_grad_block_f32(int kind, const float* X1p, int64_t row0, int nrows, const float* X2p, int m, int dp, float* W,
+ * acc[0] += sum W * k and, for a family with a shape parameter (RQ), acc[1] += sum W * dk/dkparam at fixed s
+ * (acc: TWO device doubles, zeroed by the caller). */
+int gpamd_kernel_grad_block_f32(int kind, double kparam, const float* X1p, int64_t row0, int nrows, const float* X2p, int m, int dp, float* W,
                                 int64_t ldw, double* acc, void* stream);
-int gpamd_kernel_grad_block_f64(int kind, const double* X1p, int64_t row0, int nrows, const double* X2p, int m, int dp, double* W,
+int gpamd_kernel_grad_block_f64(int kind, double kparam, const double* X1p, int64_t row0, int nrows, const double* X2p, int m, int dp, double* W,
                                 int64_t ldw, double* acc, void* stream);
 int gpamd_coldot_f64(const double* A, const double* B, int64_t ld, int n, int t, double* out, double* scratch, void* stream);
 int gpamd_kv_reduce_f64(const double* P, int S, int64_t ldp, int t, int n, const double* scale, const double* dscale,

@@ -163,3 +163,95 @@ def test_train_on_batch_test_on_batch(dev):
             test_x_param = torch.nn.Parameter(tx.clone())
             likelihood(gp_model(test_x_param)).mean.sum().backward()
             assert test_x_param.grad is not None and float(test_x_param.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("kind,ard", [("rbf", False), ("matern52", True), ("matern12", False), ("rq", False)])
+def test_small_members_are_evaluated_stacked(kind, ard, dev):
+    """Members below ``max_cholesky_size``: the whole batch goes through ``batched.BatchedCholeskyInvQuadLogdetFn`` (one dense-generation
+    launch + batched Cholesky + one derivative launch, ``csrc/extra_batch.hip``).  Value and EVERY hyper-parameter gradient
+    (lengthscale(s), outputscale, noise, constant mean, RQ alpha) == the launch plan over members (``batched_small_members(False)``)
+    == dense float64 autograd per member."""
+    import gpytorch_amd as g
+    from gpytorch_amd import batched
+
+    b, n, d = 5, 140, 3
+    gen = torch.Generator().manual_seed(3)
+    X = torch.rand(b, n, d, generator=gen)
+    Y = torch.sin(3 * X.sum(-1)) + 0.1 * torch.randn(b, n, generator=gen)
+    bs = torch.Size([b])
+
+    def base():
+        if kind == "rbf":
+            return g.kernels.RBFKernel(batch_shape=bs, ard_num_dims=d if ard else None)
+        if kind == "rq":
+            return g.kernels.RQKernel(batch_shape=bs, ard_num_dims=d if ard else None)
+        return g.kernels.MaternKernel(nu=OK.KINDS[kind], batch_shape=bs, ard_num_dims=d if ard else None)
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, y, lik):
+            super().__init__(x, y, lik)
+            self.mean_module = g.means.ConstantMean(batch_shape=bs)
+            self.covar_module = g.kernels.ScaleKernel(base(), batch_shape=bs)
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    nls = d if ard else 1
+    ls = 0.3 + 0.5 * torch.rand(b, 1, nls, generator=gen)
+    os_ = 0.7 + torch.rand(b, generator=gen)
+    nz = 0.05 + 0.2 * torch.rand(b, 1, generator=gen)
+    al = 0.8 + 2.0 * torch.rand(b, 1, generator=gen)
+    mu = 0.3 * torch.randn(b, generator=gen)
+
+    def evaluate(stacked):
+        lik = g.likelihoods.GaussianLikelihood(batch_shape=bs).to(dev)
+        m = M(X.to(dev), Y.to(dev), lik).to(dev)
+        m.covar_module.base_kernel.lengthscale = ls
+        m.covar_module.outputscale = os_
+        lik.noise = nz
+        m.mean_module.constant = mu
+        if kind == "rq":
+            m.covar_module.base_kernel.alpha = al
+        mll = g.ExactMarginalLogLikelihood(lik, m)
+        m.train()
+        lik.train()
+        calls = []
+        orig = batched.BatchedCholeskyInvQuadLogdetFn.apply
+        batched.BatchedCholeskyInvQuadLogdetFn.apply = lambda *a: (calls.append(1), orig(*a))[1]
+        try:
+            with g.settings.batched_small_members(stacked):
+                val = mll(m(m.train_inputs[0]), m.train_targets)
+                val.sum().backward()
+        finally:
+            batched.BatchedCholeskyInvQuadLogdetFn.apply = orig
+        assert len(calls) == (1 if stacked else 0)
+        k = m.covar_module.base_kernel
+        grads = [k.raw_lengthscale.grad, m.covar_module.raw_outputscale.grad, lik.noise_covar.raw_noise.grad, m.mean_module.raw_constant.grad]
+        if kind == "rq":
+            grads.append(k.raw_alpha.grad)
+        return val.detach().double().cpu(), [x.detach().double().cpu().reshape(b, -1) for x in grads]
+
+    v1, g1 = evaluate(True)
+    v0, g0 = evaluate(False)
+    assert v1.shape == torch.Size([b])
+    assert torch.allclose(v1, v0, rtol=2e-5, atol=2e-5)
+    for a, c in zip(g1, g0):
+        assert torch.allclose(a, c, rtol=3e-3, atol=3e-3 * float(c.abs().max())), (kind, a, c)
+    # dense float64 autograd per member (softplus chain rule on the raw parameters: d softplus(raw) = 1 - exp(-value))
+    for i in range(b):
+        p = [ls[i].double().clone().requires_grad_(True), os_[i].double().clone().requires_grad_(True), nz[i].double().reshape(()).clone().requires_grad_(True),
+             mu[i].double().clone().requires_grad_(True), al[i].double().reshape(()).clone().requires_grad_(True)]
+        Xi, Yi = X[i].double(), Y[i].double()
+        if kind == "rq":
+            Kd = OK.rq(Xi, Xi, p[0], p[4], x1_eq_x2=True, direct=True)
+        else:
+            Kd = OK.kernel_matrix(kind, Xi - Xi.mean(0), Xi - Xi.mean(0), p[0], 1.0, x1_eq_x2=True, direct=True)
+        Kh = p[1] * Kd + p[2] * torch.eye(n, dtype=torch.float64)
+        ref = OG.dense_log_prob(Kh, Yi - p[3]) / n
+        gr = torch.autograd.grad(ref, p[:5] if kind == "rq" else p[:4], allow_unused=True)
+        assert abs(float(v1[i]) - float(ref)) < 2e-4 * max(1.0, abs(float(ref))), (kind, i, float(v1[i]), float(ref))
+        chain = [1.0 - torch.exp(-ls[i].double()).reshape(-1), 1.0 - math.exp(-float(os_[i])), 1.0 - math.exp(-(float(nz[i]) - 1e-4)), 1.0,
+                 1.0 - math.exp(-float(al[i]))]
+        for q, (gg, rr) in enumerate(zip(g1, gr)):
+            want = (rr.reshape(-1) * chain[q]).reshape(-1)
+            assert torch.allclose(gg[i].reshape(-1), want, rtol=5e-3, atol=5e-3 * float(want.abs().max()) + 1e-7), (kind, i, q, gg[i], want)

@@ -260,3 +260,101 @@ def test_fused_float64_kernel(kind, d, n, m, t, dev):
     finally:
         B.FORCE_CHUNKED = False
     assert rel_err(out, ref) < 1e-12
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.float64, 3), (torch.float64, 10), (torch.float32, 20)])
+def test_rq_on_the_generic_path_entries_products_and_gradients(dtype, d, dev):
+    """The rational-quadratic family (rq_kernel.py:61-74; oracle pinned to the reference's own forward by tests/test_oracle_golden.py)
+    OUTSIDE the fused float32 kernels: float64 (fused float64 product for d <= 8, row blocks x GEMM above) and float32 with d > 16.
+    Dense entries / rows / diagonal / K @ V against the float64 oracle, and the bilinear derivative with respect to the ARD
+    lengthscales, the outputscale and alpha against float64 autograd."""
+    from gpytorch_amd import backend as B
+    from gpytorch_amd.functions import hyper_grads
+
+    n, m, t, alpha = 420, 333, 9, 1.7
+    g0 = torch.Generator().manual_seed(6)
+    X1 = torch.rand(n, d, generator=g0, dtype=torch.float64)
+    X2 = torch.rand(m, d, generator=g0, dtype=torch.float64)
+    V = torch.randn(m, t, generator=g0, dtype=torch.float64)
+    Lm = torch.randn(n, t, generator=g0, dtype=torch.float64)
+    ls = ((0.9 if d > 8 else 0.3) + 0.4 * torch.rand(1, d, generator=g0, dtype=torch.float64)).requires_grad_(True)
+    os_ = torch.tensor(1.7, dtype=torch.float64, requires_grad=True)
+    a64 = torch.tensor(alpha, dtype=torch.float64, requires_grad=True)
+    K = os_ * OK.rq(X1, X2, ls, a64, x1_eq_x2=False, direct=True)
+    gl, go, ga = torch.autograd.grad((Lm * (K @ V)).sum(), [ls, os_, a64])
+    K = K.detach()
+    tol = 1e-11 if dtype == torch.float64 else 2e-5
+    shift = X1.mean(0).to(dev, dtype)
+    lsd = ls.detach().to(dev, dtype)
+    p1 = B.prep_points("rq", X1.to(dev, dtype), lsd, shift, alpha)
+    p2 = B.prep_points("rq", X2.to(dev, dtype), lsd, shift, alpha)
+    assert p1.dtype == dtype and not p1.fused and p1.param == alpha
+    sc = torch.tensor([1.7], dtype=dtype, device=dev)
+    assert rel_err(B.kernel_dense(p1, p2, sc), K) < tol
+    rows = torch.tensor([0, 5, n - 1, 17])
+    assert rel_err(B.kernel_rows(p1, rows, p2, sc), K[rows]) < tol
+    assert rel_err(B.kernel_diag(p1, p1, sc), torch.full((n,), 1.7, dtype=torch.float64)) < tol
+    out = B.from_probe_major(B.kv(p1, p2, B.to_probe_major(V.to(dev), dtype), scale=sc), n)
+    assert out.dtype == dtype and rel_err(out, K @ V) < tol
+    kp = torch.tensor([alpha], dtype=dtype, device=dev)
+    d_ls, d_os, d_al = hyper_grads(p1, p2, lsd, sc, B.to_probe_major(Lm.to(dev), dtype), B.to_probe_major(V.to(dev), dtype), kparam=kp)
+    gtol = 1e-9 if dtype == torch.float64 else 1e-3
+    assert rel_err(d_ls, gl) < gtol
+    assert abs(float(d_os) - float(go)) < gtol * abs(float(go))
+    assert abs(float(d_al) - float(ga)) < gtol * abs(float(ga)), (float(d_al), float(ga))
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.float64, 2), (torch.float32, 18)])
+def test_rq_gp_mll_on_the_generic_path(dtype, d, dev):
+    """ScaleKernel(RQKernel) ExactGP in float64 / with 18 input dimensions: the MLL and its gradients (lengthscale, alpha, outputscale,
+    noise) on the Cholesky branch and on the BBMM branch with a COMPLETE probe basis (exact trace terms), against dense float64 autograd."""
+    import gpytorch_amd as g
+
+    n = 260
+    X, y = make_data(n, d)
+    ls0 = 0.3 if d <= 8 else 0.9
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ZeroMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RQKernel())
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    p = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (ls0, 2.2, 1.3, 0.1)]   # ls, alpha, outputscale, noise
+    Kh = p[2] * OK.rq(X, X, p[0], p[1], x1_eq_x2=True, direct=True) + p[3] * torch.eye(n, dtype=torch.float64)
+    ref = OG.dense_log_prob(Kh, y) / n
+    gref = torch.autograd.grad(ref, p)
+    want = torch.tensor([float(gr) * c for gr, c in zip(gref, _chain(ls0, 2.2, 1.3, 0.1 - 1e-4))], dtype=torch.float64)
+    for bbmm in (False, True):
+        lik = g.likelihoods.GaussianLikelihood()
+        m = M(X.to(dev, dtype), y.to(dev, dtype), lik).to(dev).to(dtype)
+        m.covar_module.base_kernel.lengthscale = ls0
+        m.covar_module.base_kernel.alpha = 2.2
+        m.covar_module.outputscale = 1.3
+        lik.noise = 0.1
+        mll = g.ExactMarginalLogLikelihood(lik, m)
+        m.train()
+        lik.train()
+        if bbmm:
+            Z = math.sqrt(n) * torch.eye(n, dtype=torch.float64)
+            with g.settings.max_cholesky_size(0), g.settings.deterministic_probes(True), g.settings.cg_tolerance(1e-5), \
+                    g.settings.max_preconditioner_size(0), g.settings.max_lanczos_quadrature_iterations(n):
+                g.settings.deterministic_probes.probe_vectors = Z.to(dev)
+                try:
+                    val = mll(m(m.train_inputs[0]), m.train_targets)
+                    val.backward()
+                finally:
+                    g.settings.deterministic_probes.probe_vectors = None
+        else:
+            val = mll(m(m.train_inputs[0]), m.train_targets)
+            val.backward()
+        assert val.dtype == dtype
+        tol = 2e-3 if bbmm else 1e-3
+        assert abs(float(val) - float(ref)) < tol * max(1.0, abs(float(ref))), (bbmm, float(val), float(ref))
+        k = m.covar_module.base_kernel
+        got = torch.tensor([float(k.raw_lengthscale.grad.sum()), float(k.raw_alpha.grad.sum()), float(m.covar_module.raw_outputscale.grad),
+                            float(lik.noise_covar.raw_noise.grad.sum())], dtype=torch.float64)
+        assert float((got - want).norm() / want.norm()) < 5 * tol, (bbmm, got, want)

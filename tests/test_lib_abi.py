@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
     for name in declared:
         assert hasattr(h, name), f"{name} declared in gpamd.h but not exported"
     assert sorted(SIGNATURES) == declared, "ctypes table and gpamd.h disagree"
-    assert h.gpamd_abi_version() == 2
+    assert h.gpamd_abi_version() == 3
 
 
 def test_library_exports_nothing_beyond_the_header():
@@ -81,6 +81,12 @@ def test_argument_validation_without_gpu():
     # split-operand contraction: the j chunk must be the plan's (a multiple of the 128-row LDS tile) -- refused before any launch
     rc = h.gpamd_kv_partials_f32(0, 0.0, None, 1000, None, 1000, 3, None, None, 1000, 11, None, 1000, 1, 1004, 1 | 8, None, None)
     assert rc == -1 and b"jchunk % 128" in h.gpamd_last_error()
+    # batched small-member entry points: shapes and the RQ shape-parameter array are checked before any launch
+    assert h.gpamd_kernel_dense_batched_f32(0, None, None, 0, None, 5, 4, 2, None, None, None, 8, None) == -1
+    assert h.gpamd_kernel_dense_batched_f32(4, None, None, 5, None, 5, 4, 2, None, None, None, 8, None) == -1 and b"kparam" in h.gpamd_last_error()
+    assert h.gpamd_kernel_grad_batched_f32(0, None, None, 5, None, 5, 20, 2, None, 8, None, None) == -1 and b"dp <= 16" in h.gpamd_last_error()
+    # float64 / generic entry points take the shape parameter too (ABI version 3): RQ needs alpha > 0
+    assert h.gpamd_prep_points_f64(4, 0.0, None, 5, 2, 2, None, 1, None, None, 4, None) == -1 and b"alpha must be positive" in h.gpamd_last_error()
 
 
 def test_build_tridiag_matches_oracle():
