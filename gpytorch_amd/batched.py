@@ -8,8 +8,8 @@ a time, so :class:`~gpytorch_amd.operators.BatchLinearOperator` is a launch plan
 launches is left of that plan (~50 per member and evaluation).  Here the members are stacked instead:
 
 * forward: prepared points of all members ``[b, n, dp]`` (three elementwise torch ops), ``gpamd_kernel_dense_batched_f32`` (one launch,
-  ``blockIdx.z`` = member), float64 batched Cholesky / triangular solves through torch (rocSOLVER);
-* backward: ``W_g = g_ld K_g^-1 - sum_c g_iq[c] a_gc a_gc^T`` for every member in float64 (batched ``cholesky_inverse`` + one ``baddbmm``),
+  ``blockIdx.z`` = member), float64 batched Cholesky + ONE batched triangular solve (L^-1) through torch (rocSOLVER / rocBLAS);
+* backward: ``W_g = g_ld K_g^-1 - sum_c g_iq[c] a_gc a_gc^T`` for every member in float64 (K^-1 = L^-T L^-1 from the forward's triangular solve + one ``baddbmm``),
   then ``gpamd_kernel_grad_batched_f32`` (one launch) reduces ``sum W dK/dtheta`` of every member to the 2 + dp numbers the
   hyper-parameter chain rule needs (the same convention as ``backend.kv_grad2``).
 
@@ -75,23 +75,26 @@ class BatchedCholeskyInvQuadLogdetFn(torch.autograd.Function):
         K.diagonal(dim1=-2, dim2=-1).add_(noise.detach().to(torch.float64).reshape(-1, 1))
         Lc = torch.linalg.cholesky(K)
         r64 = rhs.detach().to(torch.float64)
-        sol = torch.cholesky_solve(r64, Lc)
+        # L^-1 once (one batched triangular solve, rocBLAS; reused by the backward for K^-1): the batched potrs behind torch.cholesky_solve
+        # returned hipErrorLaunchFailure for [2, 600, 600] float64 on this stack (profiles/r03_s23_*), the triangular solve has no size limit
+        Linv = torch.linalg.solve_triangular(Lc, torch.eye(K.shape[-1], device=K.device, dtype=torch.float64).expand_as(K), upper=False)
+        sol = Linv.transpose(-1, -2) @ (Linv @ r64)
         inv_quad = (sol * r64).sum(-2)
         logdet = 2.0 * Lc.diagonal(dim1=-2, dim2=-1).log().sum(-1)
         ctx.kind, ctx.zp, ctx.d = kind, zp, x.shape[-1]
         ctx.has_os, ctx.has_par = outputscale is not None, kparam is not None
         empty = torch.empty(0, device=x.device)
-        ctx.save_for_backward(lengthscale, outputscale if ctx.has_os else empty, kparam if ctx.has_par else empty, Lc, sol)
+        ctx.save_for_backward(lengthscale, outputscale if ctx.has_os else empty, kparam if ctx.has_par else empty, Linv, sol)
         return inv_quad.to(rhs.dtype), logdet.to(rhs.dtype)
 
     @staticmethod
     def backward(ctx, g_iq, g_ld):
-        lengthscale, outputscale, kparam, Lc, sol = ctx.saved_tensors
+        lengthscale, outputscale, kparam, Linv, sol = ctx.saved_tensors
         zp, d = ctx.zp, ctx.d
         b, n, dp = zp.shape
         g_iq = g_iq.to(torch.float64)
         # d logdet = tr(K^-1 dK);  d inv_quad[c] = -a_c^T dK a_c
-        w = torch.cholesky_inverse(Lc) * g_ld.to(torch.float64).reshape(b, 1, 1)
+        w = (Linv.transpose(-1, -2) @ Linv) * g_ld.to(torch.float64).reshape(b, 1, 1)
         w = torch.baddbmm(w, sol * g_iq.reshape(b, 1, -1), sol.transpose(-1, -2), alpha=-1.0)
         d_noise = w.diagonal(dim1=-2, dim2=-1).sum(-1)
         G = kernel_grad_batched(ctx.kind, zp, w, kparam if ctx.has_par else None)
