@@ -236,8 +236,8 @@ class MaternKernel(_StationaryFused):
 
 class RQKernel(_StationaryFused):
     r"""k(x, x') = (1 + (x - x')^T Theta^-2 (x - x') / (2 alpha))^-alpha   (``gpytorch/kernels/rq_kernel.py:14-86``).  A native
-    covariance family of the fused float32 kernels (``KIND_RQ``: one ``v_log_f32`` + one ``v_exp_f32`` per pair); alpha is a learnable
-    shape parameter whose gradient comes out of the same fused derivative pass as the lengthscales'."""
+    covariance family of the fused float32 kernels (``KIND_RQ``: one ``v_log_f32`` + one ``v_exp_f32`` per pair) and of the float64 / d > 16
+    generic path; alpha is a learnable shape parameter whose gradient comes out of the same derivative pass as the lengthscales'."""
 
     kind = "rq"
 
