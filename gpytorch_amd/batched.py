@@ -13,7 +13,7 @@ launches is left of that plan (~50 per member and evaluation).  Here the members
   then ``gpamd_kernel_grad_batched_f32`` (one launch) reduces ``sum W dK/dtheta`` of every member to the 2 + dp numbers the
   hyper-parameter chain rule needs (the same convention as ``backend.kv_grad2``).
 
-Used when every member is a single stationary kernel + homoskedastic noise on the fused float32 path with the same family and shape
+Used when every member is a single stationary kernel + homoskedastic noise (optionally + a FIXED heteroskedastic noise vector) on the fused float32 path with the same family and shape
 (``members_stackable``); everything else keeps the member loop."""
 from __future__ import annotations
 
@@ -68,11 +68,13 @@ class BatchedCholeskyInvQuadLogdetFn(torch.autograd.Function):
     the batched twin of ``functions.CholeskyInvQuadLogdetFn`` (same arithmetic: float32 generation, float64 factorisation)."""
 
     @staticmethod
-    def forward(ctx, x, lengthscale, outputscale, noise, rhs, kind, shift, kparam):
+    def forward(ctx, x, lengthscale, outputscale, noise, rhs, kind, shift, kparam, noise_vec=None):
         B._require_gpu(x, "x")
         zp = stack_prepared(kind, x, lengthscale, shift, kparam)
         K = kernel_dense_batched(kind, zp, outputscale, kparam).to(torch.float64)
         K.diagonal(dim1=-2, dim2=-1).add_(noise.detach().to(torch.float64).reshape(-1, 1))
+        if noise_vec is not None:   # fixed heteroskedastic noise (FixedNoiseGaussianLikelihood): [b, n], not learnable
+            K.diagonal(dim1=-2, dim2=-1).add_(noise_vec.detach().to(torch.float64))
         Lc = torch.linalg.cholesky(K)
         r64 = rhs.detach().to(torch.float64)
         # L^-1 once (one batched triangular solve, rocBLAS; reused by the backward for K^-1): the batched potrs behind torch.cholesky_solve
@@ -111,13 +113,13 @@ class BatchedCholeskyInvQuadLogdetFn(torch.autograd.Function):
             # RQ: s = |dx|^2 / (2 alpha l^2) -> dK/dalpha = dk/dalpha|_s - dk/ds s / alpha (functions.hyper_grads)
             d_par = (theta * (G[:, 1 + dp] - gq.sum(-1) / kparam.detach().to(torch.float64).reshape(b))).reshape(kparam.shape).to(kparam.dtype)
         d_rhs = (2.0 * sol * g_iq.reshape(b, 1, -1)).to(g_ld.dtype) if ctx.needs_input_grad[4] else None
-        return None, d_ls.reshape(lengthscale.shape).to(lengthscale.dtype), d_os, d_noise.reshape(-1).to(g_ld.dtype), d_rhs, None, None, d_par
+        return None, d_ls.reshape(lengthscale.shape).to(lengthscale.dtype), d_os, d_noise.reshape(-1).to(g_ld.dtype), d_rhs, None, None, d_par, None
 
 
 def members_stackable(ops) -> bool:
     """Every member is ``outputscale * k(x, x) + noise I`` with ONE stationary kernel of the same family on the fused float32 path
-    (d <= 16), the same number of points, lengthscales and optional parts, no fixed noise vector and no gradient with respect to the
-    inputs -- and small enough for the Cholesky branch."""
+    (d <= 16), the same number of points, lengthscales and optional parts (output scale, centring shift, shape parameter, fixed
+    heteroskedastic noise vector), no gradient with respect to the inputs -- and small enough for the Cholesky branch."""
     from .operators import FusedKernelAddedDiagLinearOperator
 
     if len(ops) < 2 or settings.batched_small_members.off():
@@ -129,7 +131,9 @@ def members_stackable(ops) -> bool:
     if B.work_dtype(k0.x1) != torch.float32 or k0.x1.shape[-1] > B.MAX_INPUT_DIM or not k0.x1.is_cuda:
         return False
     for o in ops:
-        if type(o) is not FusedKernelAddedDiagLinearOperator or o.noise_vec is not None:
+        if type(o) is not FusedKernelAddedDiagLinearOperator or (o.noise_vec is None) != (o0.noise_vec is None):
+            return False
+        if o.noise_vec is not None and (o.noise_vec.requires_grad or o.noise_vec.numel() != o0.shape[-1]):
             return False
         k = o.kernel_op
         if (k.spec.kind != k0.spec.kind or k.x1.shape != k0.x1.shape or k.x1.dtype != k0.x1.dtype or not k.square_same_inputs
@@ -161,4 +165,5 @@ def batched_inv_quad_logdet(ops, rhs_members):
     par = None if k0.spec.param is None else _stack([k.spec.param.reshape(()) for k in ks])
     rhs = _stack(list(rhs_members))
     assert rhs.shape[0] == b
-    return BatchedCholeskyInvQuadLogdetFn.apply(x, ls, os_, noise, rhs, k0.spec.kind, shift, par)
+    nvec = None if ops[0].noise_vec is None else _stack([o.noise_vec.reshape(-1) for o in ops])
+    return BatchedCholeskyInvQuadLogdetFn.apply(x, ls, os_, noise, rhs, k0.spec.kind, shift, par, nvec)

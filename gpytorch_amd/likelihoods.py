@@ -158,8 +158,9 @@ def _add_diags(a, b):
     if isinstance(a, ConstantDiagLinearOperator) and isinstance(b, ConstantDiagLinearOperator):
         return ConstantDiagLinearOperator(a.diag_values.reshape(-1)[:1] + b.diag_values.reshape(-1)[:1], a.diag_shape)
     # fixed vector + learned scalar: kept apart so that the scalar stays on the autograd path of the fused operators
-    if isinstance(b, ConstantDiagLinearOperator) and not b.batch_shape and a._diag.dim() == 1:
+    # (batch mode: fixed [*batch, n] + a scalar that is shared ([1]) or per member ([*batch, 1]); BatchLinearOperator.__add__ splits both per member)
+    if isinstance(b, ConstantDiagLinearOperator) and not isinstance(a, ConstantDiagLinearOperator):
         return FixedPlusConstantDiagLinearOperator(a._diag, b.diag_values)
-    if isinstance(a, ConstantDiagLinearOperator) and not a.batch_shape and b._diag.dim() == 1:
+    if isinstance(a, ConstantDiagLinearOperator) and not isinstance(b, ConstantDiagLinearOperator):
         return FixedPlusConstantDiagLinearOperator(b._diag, a.diag_values)
     return DiagLinearOperator(a._diag + b._diag)

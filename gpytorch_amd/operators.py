@@ -344,8 +344,8 @@ class FixedPlusConstantDiagLinearOperator(DiagLinearOperator):
     (the fused operators carry the vector as a non-learnable epilogue diagonal and differentiate the scalar)."""
 
     def __init__(self, fixed: torch.Tensor, const: torch.Tensor):
-        self.fixed = fixed
-        self.const = const.reshape(-1)[:1]
+        self.fixed = fixed                                                   # [*batch, n]
+        self.const = const.reshape(-1)[:1] if const.numel() == 1 else const                                               # [1], or [*batch, 1] in batch mode
 
     @property
     def _diag(self):
@@ -1018,6 +1018,12 @@ class BatchLinearOperator(LinearOperator):
             me = self.expand_batch(bs)
             vals = other.diag_values.expand(*bs, 1).reshape(-1, 1).unbind(0) if bs else [other.diag_values]
             return BatchLinearOperator([o + ConstantDiagLinearOperator(v, other.diag_shape) for o, v in zip(me.ops, vals)], bs)
+        if isinstance(other, FixedPlusConstantDiagLinearOperator):
+            # fixed per-point noise + learned scalar, per member: the two parts stay apart (the scalar keeps its gradient)
+            bs = torch.broadcast_shapes(other.batch_shape, self._batch_shape)
+            me = self.expand_batch(bs)
+            consts = me._split(other.const, 1)
+            return BatchLinearOperator([o + FixedPlusConstantDiagLinearOperator(f, c) for o, f, c in zip(me.ops, me._split(other.fixed, 1), consts)], bs)
         if isinstance(other, DiagLinearOperator):
             bs = torch.broadcast_shapes(other.batch_shape, self._batch_shape)
             me = self.expand_batch(bs)

@@ -69,3 +69,37 @@ def test_root_decomposition_raises_on_non_psd_and_batch_samples_keep_their_shape
     assert smp.shape == (7, 3, 6)
     one = DenseLinearOperator(mats[0]).zero_mean_mvn_samples(4)
     assert one.shape == (4, 6)
+
+
+def test_batch_fixed_noise_keeps_the_learned_scalar_apart():
+    """FixedNoiseGaussianLikelihood(noise [b, n], learn_additional_noise=True) on a batch model: every member operator carries the fixed
+    vector as its (non-learnable) epilogue diagonal and the learned second noise as its differentiable scalar -- folding them into one
+    vector (as a plain DiagLinearOperator sum would) cuts the autograd path to the scalar.  Host logic only: nothing is evaluated."""
+    import gpytorch_amd as g
+
+    b, n, d = 3, 30, 2
+    bs = torch.Size([b])
+    X, Y = torch.rand(b, n, d), torch.randn(b, n)
+    fixed = 0.05 + 0.1 * torch.rand(b, n)
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, y, lik):
+            super().__init__(x, y, lik)
+            self.mean_module = g.means.ConstantMean(batch_shape=bs)
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel(batch_shape=bs), batch_shape=bs)
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    for learn in (True, False):
+        lik = g.likelihoods.FixedNoiseGaussianLikelihood(fixed, learn_additional_noise=learn)
+        m = M(X, Y, lik)
+        m.train()
+        lik.train()
+        ops = lik(m(X)).lazy_covariance_matrix.ops
+        assert len(ops) == b
+        for i, o in enumerate(ops):
+            assert type(o).__name__ == "FusedKernelAddedDiagLinearOperator"
+            assert torch.equal(o.noise_vec, fixed[i])
+            assert o.noise.requires_grad == learn
+            assert abs(float(o.noise.detach()) - (float(lik.second_noise.detach()) if learn else 0.0)) < 1e-7

@@ -126,3 +126,30 @@ def test_members_stackable_policy():
     assert not batched.members_stackable([mk()])                  # a single member gains nothing
     with settings.batched_small_members(False):
         assert not batched.members_stackable([mk(), mk()])
+
+
+def test_stacked_members_with_fixed_heteroskedastic_noise(monkeypatch):
+    """FixedNoiseGaussianLikelihood members (a fixed per-point noise vector on top of the learnable scalar): the vector rides on the
+    diagonal of every member's K_hat, the scalar keeps its gradient (= trace of W)."""
+    monkeypatch.setattr(batched, "kernel_dense_batched", _fake_dense)
+    monkeypatch.setattr(batched, "kernel_grad_batched", _fake_grad)
+    monkeypatch.setattr(B, "_require_gpu", lambda t, name: None)
+    b, n, d = 3, 40, 2
+    gen = torch.Generator().manual_seed(5)
+    X = torch.rand(b, n, d, generator=gen)
+    Y = torch.randn(b, n, 1, generator=gen)
+    ls = (0.4 + 0.3 * torch.rand(b, 1, 1, generator=gen)).requires_grad_(True)
+    nz = (0.05 + 0.1 * torch.rand(b, 1, generator=gen)).requires_grad_(True)
+    fixed = 0.02 + 0.2 * torch.rand(b, n, generator=gen)
+    ops = [FusedKernelAddedDiagLinearOperator(FusedKernelLinearOperator(X[i], X[i], KernelSpec("rbf"), ls[i]), nz[i], noise_vec=fixed[i]) for i in range(b)]
+    iq, ld = batched.batched_inv_quad_logdet(ops, [Y[i] for i in range(b)])
+    got = torch.autograd.grad(iq.sum() + ld.sum(), [ls, nz])
+    for i in range(b):
+        p = [ls[i].detach().double().requires_grad_(True), nz[i].detach().double().reshape(()).requires_grad_(True)]
+        Xi, Yi = X[i].double(), Y[i].double()
+        Kh = OK.kernel_matrix("rbf", Xi, Xi, p[0], 1.0, x1_eq_x2=True, direct=True) + torch.diag(p[1] + fixed[i].double())
+        ref = (Yi * torch.linalg.solve(Kh, Yi)).sum() + torch.logdet(Kh)
+        want = torch.autograd.grad(ref, p)
+        assert abs(float(iq[i].sum().detach() + ld[i].detach()) - float(ref)) < 2e-4 * abs(float(ref)) + 1e-3
+        for q in range(2):
+            assert abs(float(got[q][i].sum()) - float(want[q].sum())) < 3e-3 * abs(float(want[q].sum())) + 1e-5, (i, q)

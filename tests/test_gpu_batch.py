@@ -255,3 +255,55 @@ def test_small_members_are_evaluated_stacked(kind, ard, dev):
         for q, (gg, rr) in enumerate(zip(g1, gr)):
             want = (rr.reshape(-1) * chain[q]).reshape(-1)
             assert torch.allclose(gg[i].reshape(-1), want, rtol=5e-3, atol=5e-3 * float(want.abs().max()) + 1e-7), (kind, i, q, gg[i], want)
+
+
+def test_batch_fixed_noise_with_learned_second_noise_stacked(dev):
+    """A batch of FixedNoiseGaussianLikelihood GPs (``gaussian_likelihood.py:245-362``; fixed noise [b, n] + ``learn_additional_noise``): the
+    fixed vector rides on every member's diagonal, the learned scalar keeps its gradient -- stacked evaluation == launch plan over members
+    == dense float64 per member."""
+    import gpytorch_amd as g
+
+    b, n, d = 3, 120, 2
+    gen = torch.Generator().manual_seed(9)
+    X = torch.rand(b, n, d, generator=gen)
+    Y = torch.sin(4 * X[..., 0]) + 0.1 * torch.randn(b, n, generator=gen)
+    fixed = 0.02 + 0.1 * torch.rand(b, n, generator=gen)
+    bs = torch.Size([b])
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, y, lik):
+            super().__init__(x, y, lik)
+            self.mean_module = g.means.ZeroMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel(batch_shape=bs), batch_shape=bs)
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    ls = torch.tensor([0.3, 0.45, 0.6]).view(b, 1, 1)
+    os_ = torch.tensor([1.1, 0.8, 1.4])
+
+    def evaluate(stacked):
+        lik = g.likelihoods.FixedNoiseGaussianLikelihood(fixed.to(dev), learn_additional_noise=True).to(dev)
+        m = M(X.to(dev), Y.to(dev), lik).to(dev)
+        m.covar_module.base_kernel.lengthscale = ls
+        m.covar_module.outputscale = os_
+        lik.second_noise = 0.07
+        mll = g.ExactMarginalLogLikelihood(lik, m)
+        m.train()
+        lik.train()
+        with g.settings.batched_small_members(stacked):
+            val = mll(m(m.train_inputs[0]), m.train_targets)
+            val.sum().backward()
+        return (val.detach().double().cpu(), m.covar_module.base_kernel.raw_lengthscale.grad.double().cpu().reshape(-1),
+                lik.second_noise_covar.raw_noise.grad.double().cpu().reshape(-1))
+
+    v1, gl1, gn1 = evaluate(True)
+    v0, gl0, gn0 = evaluate(False)
+    assert torch.allclose(v1, v0, rtol=2e-5, atol=2e-5)
+    assert torch.allclose(gl1, gl0, rtol=3e-3, atol=1e-6)
+    assert float(gn1.abs().sum()) > 0 and torch.allclose(gn1, gn0, rtol=3e-3, atol=1e-6)
+    for i in range(b):
+        Kh = float(os_[i]) * OK.kernel_matrix("rbf", X[i].double(), X[i].double(), float(ls[i]), 1.0, x1_eq_x2=True, direct=True) \
+            + torch.diag(fixed[i].double() + 0.07)
+        ref = OG.dense_log_prob(Kh, Y[i].double()) / n
+        assert abs(float(v1[i]) - float(ref)) < 2e-4 * max(1.0, abs(float(ref))), (i, float(v1[i]), float(ref))
