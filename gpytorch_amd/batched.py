@@ -17,7 +17,6 @@ Used when every member is a single stationary kernel + homoskedastic noise (opti
 (``members_stackable``); everything else keeps the member loop."""
 from __future__ import annotations
 
-import math
 
 import torch
 

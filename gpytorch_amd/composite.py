@@ -15,7 +15,6 @@ from .bbmm import allreduce_grads_, backward_vectors, build_preconditioner_rows,
 from .functions import _prep, hyper_grads
 from .linear_cg import linear_cg
 from .operators import (
-    ConstantDiagLinearOperator,
     DiagLinearOperator,
     FusedKernelLinearOperator,
     LinearOperator,

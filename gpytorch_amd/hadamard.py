@@ -21,7 +21,7 @@ from .bbmm import allreduce_grads_, backward_vectors, build_preconditioner_rows,
 from .functions import KernelSpec, _prep, hyper_grads
 from .lanczos import root_inv_decomposition
 from .linear_cg import linear_cg
-from .operators import ConstantDiagLinearOperator, DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, split_diag
+from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, split_diag
 
 
 class IndexedTaskCovar(LinearOperator):
