@@ -224,6 +224,48 @@ def api_level_extras(Xd, yd, ls, t, dev, n_test=10_000):
     return res
 
 
+def batch_small_extras(dev, b=64, n=200, d=3, reps=3):
+    """A batch of SMALL exact GPs (members below max_cholesky_size): one MLL evaluation + backward through the stacked path
+    (gpytorch_amd/batched.py: one dense-generation launch, batched Cholesky, one derivative launch) and through the launch plan over
+    members.  Same measurement as scripts/batch_small_timing.py."""
+    import gpytorch_amd as g
+
+    bs = torch.Size([b])
+    gen = torch.Generator().manual_seed(0)
+    X = torch.rand(b, n, d, generator=gen).to(dev)
+    Y = (torch.sin(3 * X.sum(-1).cpu()) + 0.1 * torch.randn(b, n, generator=gen)).to(dev)
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, y, lik):
+            super().__init__(x, y, lik)
+            self.mean_module = g.means.ConstantMean(batch_shape=bs)
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel(batch_shape=bs), batch_shape=bs)
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood(batch_shape=bs).to(dev)
+    m = M(X, Y, lik).to(dev)
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    m.train(); lik.train()
+    res = {"members": b, "points_per_member": n, "d": d}
+    for stacked in (True, False):
+        with g.settings.batched_small_members(stacked):
+            best = None
+            for _ in range(reps):
+                m.zero_grad()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                val = mll(m(X), Y).sum()
+                val.backward()
+                torch.cuda.synchronize(dev)
+                dt = (time.perf_counter() - t0) * 1e3
+                best = dt if best is None else min(best, dt)
+            res["stacked_ms" if stacked else "member_loop_ms"] = best
+            res["mll_sum_stacked" if stacked else "mll_sum_member_loop"] = float(val.detach())
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -449,6 +491,10 @@ def main():
         gsettings.split_contraction._set_state(None)   # API-level timings on the library defaults (split contraction on)
         extras = api_level_extras(Xd, yd, ls, t, dev)
         extras["kv_contraction"] = "library default: split" if gsettings.split_contraction.on() else "f32"
+        try:
+            extras["batch_of_small_gps"] = batch_small_extras(dev)
+        except Exception as e:  # (reported, never fatal for the headline line)
+            extras["batch_of_small_gps"] = {"error": repr(e)[:200]}
 
     if args.contraction == "f32":
         roofline = {
