@@ -153,3 +153,34 @@ def test_stacked_members_with_fixed_heteroskedastic_noise(monkeypatch):
         assert abs(float(iq[i].sum().detach() + ld[i].detach()) - float(ref)) < 2e-4 * abs(float(ref)) + 1e-3
         for q in range(2):
             assert abs(float(got[q][i].sum()) - float(want[q].sum())) < 3e-3 * abs(float(want[q].sum())) + 1e-5, (i, q)
+
+
+@pytest.mark.parametrize("reduce_inv_quad", [True, False])
+def test_batch_operator_routes_a_two_dimensional_batch_through_the_stack(reduce_inv_quad, monkeypatch):
+    """``BatchLinearOperator.inv_quad_logdet`` with batch_shape [3, 2] (the reference's multi-batch mode, gpytorch/test/model_test_case.py):
+    members are stacked row-major, results come back in the batch shape; log-det alone works through a dummy column."""
+    from gpytorch_amd.operators import BatchLinearOperator
+
+    monkeypatch.setattr(batched, "kernel_dense_batched", _fake_dense)
+    monkeypatch.setattr(batched, "kernel_grad_batched", _fake_grad)
+    monkeypatch.setattr(batched, "members_stackable", lambda ops: True)
+    monkeypatch.setattr(B, "_require_gpu", lambda t, name: None)
+    bs, n, d, c = (3, 2), 30, 2, 2
+    gen = torch.Generator().manual_seed(2)
+    X = torch.rand(*bs, n, d, generator=gen)
+    Y = torch.randn(*bs, n, c, generator=gen)
+    ls = 0.3 + 0.5 * torch.rand(*bs, 1, 1, generator=gen)
+    nz = 0.05 + 0.2 * torch.rand(*bs, 1, generator=gen)
+    ops = [FusedKernelAddedDiagLinearOperator(FusedKernelLinearOperator(X[i, j], X[i, j], KernelSpec("rbf"), ls[i, j]), nz[i, j]) for i in range(3) for j in range(2)]
+    op = BatchLinearOperator(ops, torch.Size(bs))
+    iq, ld = op.inv_quad_logdet(Y, logdet=True, reduce_inv_quad=reduce_inv_quad)
+    assert ld.shape == bs and iq.shape == (bs if reduce_inv_quad else (*bs, c))
+    for i in range(3):
+        for j in range(2):
+            Kh = OK.kernel_matrix("rbf", X[i, j].double(), X[i, j].double(), ls[i, j].double(), 1.0, x1_eq_x2=True, direct=True) + float(nz[i, j]) * torch.eye(n, dtype=torch.float64)
+            riq = (Y[i, j].double() * torch.linalg.solve(Kh, Y[i, j].double())).sum(0)
+            want = riq.sum() if reduce_inv_quad else riq
+            assert torch.allclose(iq[i, j].double(), want, rtol=2e-4)
+            assert abs(float(ld[i, j]) - float(torch.logdet(Kh))) < 2e-4 * abs(float(torch.logdet(Kh))) + 1e-3
+    iq0, ld0 = op.inv_quad_logdet(None, logdet=True)
+    assert iq0 is None and torch.allclose(ld0, ld)
