@@ -23,6 +23,7 @@ import torch
 from . import backend as B
 from . import settings
 from ._lib import check, lib
+from .operators import psd_safe_cholesky
 
 
 def stack_prepared(kind: str, x: torch.Tensor, ls: torch.Tensor, shift, param) -> torch.Tensor:
@@ -74,7 +75,7 @@ class BatchedCholeskyInvQuadLogdetFn(torch.autograd.Function):
         K.diagonal(dim1=-2, dim2=-1).add_(noise.detach().to(torch.float64).reshape(-1, 1))
         if noise_vec is not None:   # fixed heteroskedastic noise (FixedNoiseGaussianLikelihood): [b, n], not learnable
             K.diagonal(dim1=-2, dim2=-1).add_(noise_vec.detach().to(torch.float64))
-        Lc = torch.linalg.cholesky(K)
+        Lc = psd_safe_cholesky(K, model_dtype=rhs.dtype)   # jitter only for the members whose plain factorisation fails
         r64 = rhs.detach().to(torch.float64)
         # L^-1 once (one batched triangular solve, rocBLAS; reused by the backward for K^-1): the batched potrs behind torch.cholesky_solve
         # returned hipErrorLaunchFailure for [2, 600, 600] float64 on this stack (profiles/r03_s23_*), the triangular solve has no size limit

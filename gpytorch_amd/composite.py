@@ -20,6 +20,7 @@ from .operators import (
     LinearOperator,
     RootLinearOperator,
     ZeroLinearOperator,
+    psd_safe_cholesky,
     split_diag,
 )
 
@@ -166,7 +167,7 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
         if self._use_cholesky(settings.fast_computations.log_prob):
             # small problems: K_hat is formed from the members' differentiable dense kernels; torch differentiates the rest
             Kh = self.to_dense().to(torch.float64)
-            Lc = torch.linalg.cholesky(Kh)
+            Lc = psd_safe_cholesky(Kh, model_dtype=self.dtype)
             sol = torch.cholesky_solve(rhs.to(torch.float64), Lc)
             iq = (sol * rhs.to(torch.float64)).sum(-2).to(rhs.dtype)
             ld = (2.0 * Lc.diagonal().log().sum()).to(rhs.dtype)
@@ -209,7 +210,7 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
         squeeze = rhs.dim() == 1
         r = rhs.unsqueeze(-1) if squeeze else rhs
         if self._use_cholesky(settings.fast_computations.solves):
-            sol = torch.cholesky_solve(r.detach().to(torch.float64), torch.linalg.cholesky(self.to_dense().detach().to(torch.float64))).to(rhs.dtype)
+            sol = torch.cholesky_solve(r.detach().to(torch.float64), psd_safe_cholesky(self.to_dense().detach().to(torch.float64), model_dtype=self.dtype)).to(rhs.dtype)
         else:
             partials, wd = self._partials()
             nz = self.noise.detach().reshape(-1)[:1].to(wd).contiguous()

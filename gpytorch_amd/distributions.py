@@ -10,7 +10,7 @@ import torch
 
 from . import settings
 from .linear_cg import NumericalWarning
-from .operators import LinearOperator, to_dense, to_linear_operator
+from .operators import LinearOperator, psd_safe_cholesky, to_dense, to_linear_operator
 
 
 class MultivariateNormal:
@@ -46,7 +46,7 @@ class MultivariateNormal:
         mean, covar = self.loc, self.lazy_covariance_matrix
         diff = value - mean
         if settings.fast_computations.log_prob.off() and not hasattr(covar, "kernel_op") and not hasattr(covar, "ops"):
-            Lc = torch.linalg.cholesky(covar.to_dense())
+            Lc = psd_safe_cholesky(covar.to_dense())
             sol = torch.cholesky_solve(diff.unsqueeze(-1), Lc).squeeze(-1)
             return -0.5 * ((diff * sol).sum(-1) + 2 * Lc.diagonal(dim1=-2, dim2=-1).log().sum(-1) + diff.size(-1) * math.log(2 * math.pi))
         covar = covar.evaluate_kernel()

@@ -176,7 +176,9 @@ class CholeskyInvQuadLogdetFn(torch.autograd.Function):
         K.diagonal().add_(noise.detach().reshape(()).to(torch.float64))
         if spec.dvec is not None:
             K.diagonal().add_(spec.dvec[:n].to(torch.float64))
-        Lc = torch.linalg.cholesky(K)
+        from .operators import psd_safe_cholesky   # (operators imports this module)
+
+        Lc = psd_safe_cholesky(K, model_dtype=rhs.dtype)
         sol = torch.cholesky_solve(rhs.detach().to(torch.float64), Lc)
         inv_quad = (sol * rhs.detach().to(torch.float64)).sum(-2)
         logdet = 2.0 * Lc.diagonal().log().sum()

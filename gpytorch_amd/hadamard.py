@@ -21,7 +21,7 @@ from .bbmm import allreduce_grads_, backward_vectors, build_preconditioner_rows,
 from .functions import KernelSpec, _prep, hyper_grads
 from .lanczos import root_inv_decomposition
 from .linear_cg import linear_cg
-from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, split_diag
+from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, psd_safe_cholesky, split_diag
 
 
 class IndexedTaskCovar(LinearOperator):
@@ -203,7 +203,7 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
             inv_quad_rhs = torch.zeros(n, 0, device=self.device, dtype=self.dtype)
         rhs = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
         if self._use_cholesky(settings.fast_computations.log_prob):
-            Lc = torch.linalg.cholesky(self.to_dense().to(torch.float64))   # members' dense kernels are autograd-visible
+            Lc = psd_safe_cholesky(self.to_dense().to(torch.float64), model_dtype=self.dtype)   # members' dense kernels are autograd-visible
             sol = torch.cholesky_solve(rhs.to(torch.float64), Lc)
             iq = (sol * rhs.to(torch.float64)).sum(-2).to(rhs.dtype)
             ld = (2.0 * Lc.diagonal().log().sum()).to(rhs.dtype)
@@ -226,7 +226,7 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
         squeeze = rhs.dim() == 1
         r = rhs.unsqueeze(-1) if squeeze else rhs
         if self._use_cholesky(settings.fast_computations.solves):
-            sol = torch.cholesky_solve(r.detach().to(torch.float64), torch.linalg.cholesky(self.to_dense().detach().to(torch.float64))).to(rhs.dtype)
+            sol = torch.cholesky_solve(r.detach().to(torch.float64), psd_safe_cholesky(self.to_dense().detach().to(torch.float64), model_dtype=self.dtype)).to(rhs.dtype)
         else:
             partials, wd = self._partials()
             dv = self._dvec(wd)

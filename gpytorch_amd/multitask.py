@@ -27,7 +27,7 @@ from .likelihoods import _GaussianLikelihoodBase
 from .linear_cg import linear_cg
 from .means import Mean
 from .module import GreaterThan, Module, Positive
-from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator
+from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, psd_safe_cholesky
 
 
 # ------------------------------------------------------------------------------------------------ layout helpers
@@ -188,7 +188,7 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
         squeeze = rhs.dim() == 1
         r = rhs.unsqueeze(-1) if squeeze else rhs
         if self._use_cholesky(settings.fast_computations.solves):
-            sol = torch.cholesky_solve(r.detach().double(), torch.linalg.cholesky(self.to_dense().detach().double())).to(rhs.dtype)
+            sol = torch.cholesky_solve(r.detach().double(), psd_safe_cholesky(self.to_dense().detach().double(), model_dtype=self.dtype)).to(rhs.dtype)
         else:
             sol_t, info = self._cg(B.to_probe_major(r.detach(), B.work_dtype(self.kron.kx.x1)), tolerance=settings.cg_tolerance.value())
             self._cache["last_cg_info"] = info
@@ -203,7 +203,7 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
         rhs = inv_quad_rhs.unsqueeze(-1) if inv_quad_rhs.dim() == 1 else inv_quad_rhs
         if self._use_cholesky(settings.fast_computations.log_prob):
             K = self.to_dense_differentiable()
-            Lc = torch.linalg.cholesky(K.double())
+            Lc = psd_safe_cholesky(K.double(), model_dtype=K.dtype)
             sol = torch.cholesky_solve(rhs.double(), Lc)
             iq = (sol * rhs.double()).sum(-2).to(rhs.dtype)
             ld = (2.0 * Lc.diagonal().log().sum()).to(rhs.dtype)

@@ -28,6 +28,41 @@ class NotPSDError(RuntimeError):
     """Same role as ``linear_operator.utils.errors.NotPSDError``."""
 
 
+class NanError(RuntimeError):
+    """Same role as ``linear_operator.utils.errors.NanError``."""
+
+
+def psd_safe_cholesky(A: torch.Tensor, jitter=None, max_tries: int = 3, model_dtype=None) -> torch.Tensor:
+    """``linear_operator.utils.cholesky.psd_safe_cholesky`` (third-party, restated): the lower Cholesky factor of ``A`` ([..., n, n]);
+    when the plain factorisation fails, jitter ``settings.cholesky_jitter`` x 10^i (i = 0 .. max_tries - 1) is added to the diagonal of
+    the FAILED batch members only, with a ``NumericalWarning`` per level; NaN input raises ``NanError``, exhaustion ``NotPSDError``
+    (every small-n branch of the reference reaches its factor through it: ``LinearOperator.cholesky`` under ``inv_quad_logdet`` /
+    ``solve`` / ``root_decomposition``).  The successful first attempt -- the normal case -- is exactly ``torch.linalg.cholesky``.
+    ``model_dtype``: dtype whose jitter default applies when ``A`` was promoted for the factorisation (float32 models factorise in float64)."""
+    L, info = torch.linalg.cholesky_ex(A)
+    if not bool(info.any()):
+        return L
+    if bool(torch.isnan(A).any()):
+        raise NanError(f"cholesky: {int(torch.isnan(A).sum())} of {A.numel()} elements of the {tuple(A.shape)} tensor are NaN.")
+    import warnings
+
+    from .linear_cg import NumericalWarning
+
+    if jitter is None:
+        jitter = settings.cholesky_jitter.value(model_dtype if model_dtype is not None else A.dtype)
+    prev, new, Ap = 0.0, 0.0, A
+    for i in range(max_tries):
+        new = jitter * (10**i)
+        add = (info > 0).to(A.dtype) * (new - prev)
+        Ap = Ap + torch.diag_embed(add.reshape(*A.shape[:-2], 1).expand(*A.shape[:-1]))
+        prev = new
+        warnings.warn(f"A not p.d., added jitter of {new:.1e} to the diagonal", NumericalWarning)
+        L, info = torch.linalg.cholesky_ex(Ap)
+        if not bool(info.any()):
+            return L
+    raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {new:.1e}.")
+
+
 class LinearOperator:
     """Minimal protocol base (2-D, no batch dimensions: the fused kernels are non-batched)."""
 
@@ -144,7 +179,7 @@ class LinearOperator:
 
     # ---- solves / determinants: dense Cholesky defaults (small operators only) ----
     def cholesky(self):
-        return torch.linalg.cholesky(self.to_dense().to(torch.float64))
+        return psd_safe_cholesky(self.to_dense().to(torch.float64), model_dtype=self.dtype)
 
     def solve(self, rhs: torch.Tensor, lhs=None) -> torch.Tensor:
         squeeze = rhs.dim() == 1
@@ -181,16 +216,8 @@ class LinearOperator:
             big = n > settings.max_cholesky_size.value() or settings.fast_pred_samples.on()
             method = "lanczos" if (big and self.device is not None and torch.device(self.device).type == "cuda") else "cholesky"
         if method == "cholesky":
-            K = self.to_dense().to(torch.float64)
-            jitter = settings.cholesky_jitter.value(self.dtype)
-            eye = torch.eye(n, device=K.device, dtype=K.dtype)
-            for k in range(4):  # psd_safe_cholesky: growing jitter
-                Lc, info = torch.linalg.cholesky_ex(K + (jitter * 10**k if k else 0.0) * eye)
-                if not bool(info.any()):
-                    break
-            else:
-                # the reference's psd_safe_cholesky raises NotPSDError after its last jitter level; never hand back a failed factor
-                raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter * 10**3:.1e}.")
+            # (psd_safe_cholesky raises NotPSDError after its last jitter level: a failed factor is never handed back)
+            Lc = psd_safe_cholesky(self.to_dense().to(torch.float64), model_dtype=self.dtype)
             return RootLinearOperator(Lc.to(self.dtype))
         from .lanczos import lanczos_tridiag, tridiag_to_diag
 
@@ -729,7 +756,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         squeeze = rhs.dim() == 1
         r = rhs.unsqueeze(-1) if squeeze else rhs
         if self._use_cholesky(settings.fast_computations.solves):
-            sol = torch.cholesky_solve(r.detach().to(torch.float64), torch.linalg.cholesky(self.to_dense().detach().to(torch.float64))).to(rhs.dtype)
+            sol = torch.cholesky_solve(r.detach().to(torch.float64), psd_safe_cholesky(self.to_dense().detach().to(torch.float64), model_dtype=self.dtype)).to(rhs.dtype)
         elif self._row_shard() is not None:
             sol = self._solve_row_sharded(r).to(rhs.dtype)
         elif torch.is_grad_enabled() and (self.requires_grad or r.requires_grad) and self.kernel_op.prepared()[0].fused:

@@ -103,3 +103,41 @@ def test_batch_fixed_noise_keeps_the_learned_scalar_apart():
             assert torch.equal(o.noise_vec, fixed[i])
             assert o.noise.requires_grad == learn
             assert abs(float(o.noise.detach()) - (float(lik.second_noise.detach()) if learn else 0.0)) < 1e-7
+
+
+def test_psd_safe_cholesky_restates_the_reference_rule():
+    """``linear_operator.utils.cholesky.psd_safe_cholesky`` (third-party; every small-n branch of the reference factorises through it):
+    plain Cholesky when it succeeds; otherwise jitter settings.cholesky_jitter x 10^i on the FAILED batch members only, one
+    NumericalWarning per level; NaN -> NanError; still not p.d. after the last level -> NotPSDError."""
+    import warnings
+
+    import pytest
+
+    from gpytorch_amd.linear_cg import NumericalWarning
+    from gpytorch_amd.operators import NanError, NotPSDError, psd_safe_cholesky
+
+    g0 = torch.Generator().manual_seed(0)
+    A = torch.randn(6, 6, generator=g0, dtype=torch.float64)
+    good = A @ A.t() + 0.5 * torch.eye(6, dtype=torch.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert torch.equal(psd_safe_cholesky(good), torch.linalg.cholesky(good))
+    v = torch.randn(6, 1, generator=g0, dtype=torch.float64)
+    singular = v @ v.t() - 1e-9 * torch.eye(6, dtype=torch.float64)          # rank one, slightly indefinite: needs jitter 1e-8 x 10
+    both = torch.stack([good, singular])
+    with pytest.warns(NumericalWarning, match="added jitter of"):
+        L = psd_safe_cholesky(both)
+    assert torch.equal(L[0], torch.linalg.cholesky(good))                    # the member that was fine is untouched
+    rec = L[1] @ L[1].t()
+    assert torch.allclose(rec - singular, (rec - singular).diagonal().mean() * torch.eye(6, dtype=torch.float64), atol=1e-12)
+    assert 0 < float((rec - singular).diagonal().mean()) <= 1.2e-6
+    # float32 model factorised in float64: the jitter ladder of the MODEL dtype (1e-6, 1e-5, 1e-4)
+    with pytest.warns(NumericalWarning, match="1.0e-06"):
+        psd_safe_cholesky(v @ v.t() - 1e-8 * torch.eye(6, dtype=torch.float64), model_dtype=torch.float32)
+    with pytest.raises(NotPSDError, match="adding jitter up to 1.0e-06"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        psd_safe_cholesky(-torch.eye(4, dtype=torch.float64))
+    bad = good.clone()
+    bad[3, 2] = float("nan")          # (the factorisation reads the lower triangle)
+    with pytest.raises(NanError, match="are NaN"):
+        psd_safe_cholesky(bad)
