@@ -32,9 +32,9 @@ class NanError(RuntimeError):
     """Same role as ``linear_operator.utils.errors.NanError``."""
 
 
-def psd_safe_cholesky(A: torch.Tensor, jitter=None, max_tries: int = 3, model_dtype=None) -> torch.Tensor:
+def psd_safe_cholesky(A: torch.Tensor, jitter=None, max_tries=None, model_dtype=None) -> torch.Tensor:
     """``linear_operator.utils.cholesky.psd_safe_cholesky`` (third-party, restated): the lower Cholesky factor of ``A`` ([..., n, n]);
-    when the plain factorisation fails, jitter ``settings.cholesky_jitter`` x 10^i (i = 0 .. max_tries - 1) is added to the diagonal of
+    when the plain factorisation fails, jitter ``settings.cholesky_jitter`` x 10^i (i = 0 .. ``settings.cholesky_max_tries`` - 1) is added to the diagonal of
     the FAILED batch members only, with a ``NumericalWarning`` per level; NaN input raises ``NanError``, exhaustion ``NotPSDError``
     (every small-n branch of the reference reaches its factor through it: ``LinearOperator.cholesky`` under ``inv_quad_logdet`` /
     ``solve`` / ``root_decomposition``).  The successful first attempt -- the normal case -- is exactly ``torch.linalg.cholesky``.
@@ -50,6 +50,8 @@ def psd_safe_cholesky(A: torch.Tensor, jitter=None, max_tries: int = 3, model_dt
 
     if jitter is None:
         jitter = settings.cholesky_jitter.value(model_dtype if model_dtype is not None else A.dtype)
+    if max_tries is None:
+        max_tries = settings.cholesky_max_tries.value()
     prev, new, Ap = 0.0, 0.0, A
     for i in range(max_tries):
         new = jitter * (10**i)

@@ -237,6 +237,12 @@ class cholesky_jitter(_dtype_value_context):
     _global_half_value = 1e-4
 
 
+class cholesky_max_tries(_value_context):
+    """Jitter levels ``psd_safe_cholesky`` tries before giving up (``linear_operator.settings.cholesky_max_tries``, re-exported at
+    ``gpytorch/settings.py:11``): jitter x 10^i, i = 0 .. max_tries - 1."""
+    _global_value = 3
+
+
 class deterministic_probes(_feature_flag):
     """Re-use one fixed set of probe vectors (``linear_operator.settings.deterministic_probes``).
     ``deterministic_probes.probe_vectors`` may be pre-set to an (n, t) tensor to inject Z."""
