@@ -35,13 +35,17 @@ def ciq_weights_shifts(lmin: float, lmax: float, num_quad: int = 15):
     return weights, shifts
 
 
-def msminres(matvec, rhs_t: torch.Tensor, shifts: torch.Tensor, n: int, tol: float = 1e-4, max_iter: int = 400):
+def msminres(matvec, rhs_t: torch.Tensor, shifts: torch.Tensor, n: int, tol: float | None = None, max_iter: int = 400):
     """Solve (A + shifts[q] I) x = b for all shifts and all rows b of ``rhs_t`` ([t, ld] probe-major) with one Lanczos recurrence.
 
     ``matvec(v [t, ld]) -> [t, ld]``.  Returns (X [Q, t, ld], iterations).  MINRES recurrences per (shift, column):
     Givens rotations applied to the shifted tridiagonal column [beta_k; alpha_k + s; beta_{k+1}], search directions
     d_k = (v_k - delta_k d_{k-1} - eps_k d_{k-2}) / gamma_k, x += tau_k d_k, residual norm |phibar_k|; stops when the largest
     relative residual over shifts and columns falls below ``tol``."""
+    if tol is None:
+        from . import settings
+
+        tol = settings.minres_tolerance.value()
     dev, dt = rhs_t.device, rhs_t.dtype
     Q, t = shifts.numel(), rhs_t.shape[0]
     native = rhs_t.is_cuda and dt == torch.float32 and rhs_t.stride(1) == 1 and rhs_t.stride(0) % 4 == 0 and rhs_t.shape[1] == rhs_t.stride(0)
@@ -128,7 +132,7 @@ def lanczos_eig_bounds(matvec, n: int, device, dtype, iters: int = 20, generator
     return float(ev[0].clamp_min(1e-12)), float(ev[-1])
 
 
-def contour_integral_quad(matvec, rhs_t, n, inverse=True, num_quad=None, lmin=None, lmax=None, tol=1e-4, max_iter=400, generator=None):
+def contour_integral_quad(matvec, rhs_t, n, inverse=True, num_quad=None, lmin=None, lmax=None, tol=None, max_iter=400, generator=None):
     """K^{-1/2} rhs (``inverse``) or K^{1/2} rhs = K (K^{-1/2} rhs), rows of ``rhs_t`` probe-major.  Returns (result_t, info)."""
     from . import settings
 

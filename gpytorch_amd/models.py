@@ -182,8 +182,8 @@ class ExactGP(GP):
                 if not all(torch.equal(ti, inp) for ti, inp in zip(train_inputs, inputs)):
                     raise RuntimeError("You must train on the training inputs!")
             return Module.__call__(self, *inputs, **kwargs)
-        if self.train_inputs is None or self.train_targets is None:
-            return Module.__call__(self, *inputs, **kwargs)  # prior mode
+        if settings.prior_mode.on() or self.train_inputs is None or self.train_targets is None:
+            return Module.__call__(self, *inputs, **kwargs)  # prior mode (exact_gp.py:285)
         if settings.debug.on():
             if all(torch.equal(ti, inp) for ti, inp in zip(train_inputs, inputs)):
                 warnings.warn("The input matches the stored training data. Did you forget to call model.train()?", GPInputWarning)

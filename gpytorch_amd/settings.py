@@ -237,6 +237,17 @@ class cholesky_jitter(_dtype_value_context):
     _global_half_value = 1e-4
 
 
+class prior_mode(_feature_flag):
+    """``gpytorch/settings.py:336-344``: evaluate an ExactGP in prior mode even if it has training data (``models/exact_gp.py:285``)."""
+    _default = False
+
+
+class minres_tolerance(_value_context):
+    """Relative-residual tolerance of msMINRES under contour-integral quadrature (``linear_operator.settings.minres_tolerance``,
+    re-exported by ``gpytorch/settings.py``; consumer ``gpytorch/__init__.py:252-278`` ``sqrt_inv_matmul``)."""
+    _global_value = 1e-4
+
+
 class cholesky_max_tries(_value_context):
     """Jitter levels ``psd_safe_cholesky`` tries before giving up (``linear_operator.settings.cholesky_max_tries``, re-exported at
     ``gpytorch/settings.py:11``): jitter x 10^i, i = 0 .. max_tries - 1."""

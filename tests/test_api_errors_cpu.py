@@ -94,3 +94,20 @@ def test_split_contraction_setting_scopes_and_env(monkeypatch):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**__import__("os").environ, "GPAMD_KV_SPLIT": "0"})
     assert out.stdout.strip() == "0", out.stderr
     assert B.KV_SPLIT == 8 and B.KV_GRAM == 1
+
+
+def test_prior_mode_setting():
+    """``settings.prior_mode`` (gpytorch/settings.py:336-344; models/exact_gp.py:285): an ExactGP WITH training data evaluates the prior
+    at the given inputs -- no prediction strategy is built, the mean is the prior mean, the covariance the lazy prior kernel operator."""
+    lik = g.likelihoods.GaussianLikelihood()
+    x, y = torch.rand(7, 2), torch.randn(7)
+    m = _GP(x, y, lik)
+    m.mean_module.constant = 0.3
+    m.eval()
+    xs = torch.rand(4, 2)
+    with g.settings.prior_mode(True):
+        out = m(xs)
+    assert m.prediction_strategy is None
+    assert out.mean.shape == (4,) and torch.allclose(out.mean, torch.full((4,), 0.3))
+    assert tuple(out.lazy_covariance_matrix.shape) == (4, 4)
+    assert g.settings.prior_mode.off()

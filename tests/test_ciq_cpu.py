@@ -67,3 +67,21 @@ def test_msminres_iterates_are_scipy_minres_iterates():
             ref, _ = spla.minres(K.numpy(), b[0].numpy(), shift=-s, rtol=0.0, maxiter=k, x0=np.zeros(n))
             ref = torch.from_numpy(ref)
             assert float((X[q, 0] - ref).norm() / ref.norm()) < 1e-8, (k, s)
+
+
+def test_minres_tolerance_setting_is_the_default_stopping_tolerance():
+    """``settings.minres_tolerance`` (linear_operator's knob, 1e-4): msMINRES stops at it unless a tolerance is passed explicitly."""
+    from gpytorch_amd import settings
+
+    n = 200
+    K = _spd(n, 3)
+    b = torch.randn(2, n, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    shifts = torch.tensor([0.0, 0.5], dtype=torch.float64)
+    assert settings.minres_tolerance.value() == 1e-4
+    _, it_default = msminres(lambda v: v @ K, b, shifts, n)
+    _, it_explicit = msminres(lambda v: v @ K, b, shifts, n, tol=1e-4)
+    with settings.minres_tolerance(1e-9):
+        X, it_tight = msminres(lambda v: v @ K, b, shifts, n)
+    assert it_default == it_explicit < it_tight
+    ref = torch.linalg.solve(K + 0.5 * torch.eye(n, dtype=torch.float64), b.t()).t()
+    assert float((X[1] - ref).norm() / ref.norm()) < 1e-7
