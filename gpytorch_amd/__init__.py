@@ -69,6 +69,22 @@ def solve(input, rhs, lhs=None):
     return to_linear_operator(input).solve(rhs, lhs)
 
 
+def matmul(mat, rhs):
+    """Deprecated alias kept by the reference (``gpytorch/functions/__init__.py:31-33``)."""
+    import warnings
+
+    warnings.warn("gpytorch.matmul is deprecated. Use torch.matmul instead.", DeprecationWarning)
+    return mat @ rhs
+
+
+def inv_matmul(mat, right_tensor, left_tensor=None):
+    """Deprecated alias kept by the reference (``gpytorch/functions/__init__.py:36-38``): ``solve`` under its old name."""
+    import warnings
+
+    warnings.warn("gpytorch.inv_matmul is deprecated. Use gpytorch.solve instead.", DeprecationWarning)
+    return solve(mat, right_tensor, left_tensor)
+
+
 def sqrt_inv_matmul(input, rhs, lhs=None):
     """gpytorch/__init__.py:252-278: K^{-1/2} rhs by contour-integral quadrature + msMINRES (:mod:`gpytorch_amd.ciq`)."""
     from .ciq import sqrt_inv_matmul as _f
@@ -77,7 +93,7 @@ def sqrt_inv_matmul(input, rhs, lhs=None):
 
 
 __all__ = [
-    "ExactMarginalLogLikelihood", "Module", "add_diagonal", "add_jitter", "distributed", "distributions", "inv_quad", "inv_quad_logdet",
-    "kernels", "likelihoods", "logdet", "means", "mlls", "models", "operators", "pivoted_cholesky", "priors", "root_decomposition",
+    "ExactMarginalLogLikelihood", "Module", "add_diagonal", "add_jitter", "distributed", "distributions", "inv_matmul", "inv_quad", "inv_quad_logdet",
+    "kernels", "likelihoods", "logdet", "matmul", "means", "mlls", "models", "operators", "pivoted_cholesky", "priors", "root_decomposition",
     "root_inv_decomposition", "settings", "solve", "sqrt_inv_matmul", "to_dense",
 ]

@@ -111,3 +111,24 @@ def test_prior_mode_setting():
     assert out.mean.shape == (4,) and torch.allclose(out.mean, torch.full((4,), 0.3))
     assert tuple(out.lazy_covariance_matrix.shape) == (4, 4)
     assert g.settings.prior_mode.off()
+
+
+def test_functional_aliases_on_dense_operands():
+    """The functional surface of ``gpytorch/__init__.py:34-278`` on plain tensors (wrapped as dense operators, as the reference's
+    ``to_linear_operator`` does): solve / inv_quad / logdet / inv_quad_logdet against torch.linalg, and the two deprecated aliases the
+    reference still exports (``matmul``, ``inv_matmul``) with their DeprecationWarning."""
+    gen = torch.Generator().manual_seed(0)
+    A = torch.randn(9, 9, generator=gen, dtype=torch.float64)
+    A = A @ A.t() + torch.eye(9, dtype=torch.float64)
+    R = torch.randn(9, 3, generator=gen, dtype=torch.float64)
+    Lm = torch.randn(2, 9, generator=gen, dtype=torch.float64)
+    assert torch.allclose(g.solve(A, R), torch.linalg.solve(A, R))
+    assert torch.allclose(g.solve(A, R, Lm), Lm @ torch.linalg.solve(A, R))
+    assert torch.allclose(g.inv_quad(A, R), (R * torch.linalg.solve(A, R)).sum())
+    assert torch.allclose(g.logdet(A), torch.logdet(A))
+    iq, ld = g.inv_quad_logdet(A, R, logdet=True, reduce_inv_quad=False)
+    assert torch.allclose(iq, (R * torch.linalg.solve(A, R)).sum(0)) and torch.allclose(ld, torch.logdet(A))
+    with pytest.warns(DeprecationWarning, match="Use torch.matmul"):
+        assert torch.allclose(g.matmul(A, R), A @ R)
+    with pytest.warns(DeprecationWarning, match="Use gpytorch.solve"):
+        assert torch.allclose(g.inv_matmul(A, R), torch.linalg.solve(A, R))
