@@ -307,6 +307,61 @@ class ScaleKernel(Kernel):
         return self.base_kernel.prediction_strategy
 
 
+class MultiDeviceKernel(Kernel):
+    r"""Constructor-compatible stand-in for ``gpytorch.kernels.MultiDeviceKernel`` (``kernels/multi_device_kernel.py:14-92``).
+
+    The reference scatters row chunks of x1 over ``device_ids`` inside ONE process (``DataParallel``: module replicas re-created on
+    every forward, peer copies of V on every product) and concatenates dense chunks.  Here multi-GPU means one process per GPU
+    (``torchrun``; RCCL): the wrapped kernel returns the same fused operator as without the wrapper, and the operator shards its
+    work at solve time -- probe columns of the MLL over ``settings.sharding.probe_group``, the few-column posterior solves by rows
+    over ``settings.sharding.row_group`` (``distributed.py``).  Constructing this kernel in a process group of more than one rank
+    installs the WORLD group for both (unless groups are already set), which is the closest equivalent of "allocate the covariance
+    on these devices"; in a single process with several ``device_ids`` it warns once and runs on the inputs' device.
+    The wrapped kernel is registered as ``module`` (the name ``DataParallel`` uses), so state-dict keys match the reference's."""
+
+    def __init__(self, base_kernel, device_ids, output_device=None, create_cuda_context=True, **kwargs):
+        super().__init__(**kwargs)
+        self.module = base_kernel
+        self.device_ids = list(device_ids)
+        self.output_device = output_device if output_device is not None else (self.device_ids[0] if self.device_ids else None)
+        import torch.distributed as dist
+
+        from . import settings
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if settings.sharding._probe_group is None:
+                settings.sharding._probe_group = dist.group.WORLD
+            if settings.sharding._row_group is None:
+                settings.sharding._row_group = dist.group.WORLD
+        elif len(self.device_ids) > 1:
+            import warnings
+
+            warnings.warn("gpytorch_amd.kernels.MultiDeviceKernel: multi-GPU runs are one process per GPU (torchrun + settings.sharding); "
+                          "this single process evaluates the kernel on the device of its inputs.", RuntimeWarning)
+
+    @property
+    def base_kernel(self):
+        return self.module
+
+    @property
+    def is_stationary(self):
+        return self.module.is_stationary
+
+    def __call__(self, x1, x2=None, diag=False, **params):
+        return self.forward(x1, x2, diag=diag, **params)     # (the wrapped kernel applies its own active_dims)
+
+    def forward(self, x1, x2, diag=False, **params):
+        return self.module(x1, x2, diag=diag, **params)
+
+    def num_outputs_per_input(self, x1, x2):
+        f = getattr(self.module, "num_outputs_per_input", None)
+        return 1 if f is None else f(x1, x2)
+
+    @property
+    def prediction_strategy(self):
+        return self.module.prediction_strategy
+
+
 class AdditiveKernel(Kernel):
     """K = sum_i K_i (``kernels/kernel.py:592-632``): the members stay matrix-free; their sum is a
     :class:`~gpytorch_amd.operators.SumFusedLinearOperator` whose products, solves and log-determinants add the members'

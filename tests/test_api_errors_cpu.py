@@ -132,3 +132,20 @@ def test_functional_aliases_on_dense_operands():
         assert torch.allclose(g.matmul(A, R), A @ R)
     with pytest.warns(DeprecationWarning, match="Use gpytorch.solve"):
         assert torch.allclose(g.inv_matmul(A, R), torch.linalg.solve(A, R))
+
+
+def test_multi_device_kernel_constructor_compatibility():
+    """``gpytorch.kernels.MultiDeviceKernel(base_kernel, device_ids, output_device)`` (multi_device_kernel.py:14-47) constructs and
+    delegates: same lazy operator as the wrapped kernel, ``base_kernel`` property, ``module.``-prefixed state dict, a warning when one
+    process is handed several devices (multi-GPU here is one process per GPU + settings.sharding)."""
+    base = g.kernels.ScaleKernel(g.kernels.RBFKernel(ard_num_dims=2))
+    with pytest.warns(RuntimeWarning, match="one process per GPU"):
+        k = g.kernels.MultiDeviceKernel(base, device_ids=[torch.device("cpu"), torch.device("cpu")], output_device=torch.device("cpu"))
+    assert k.base_kernel is base and k.output_device == torch.device("cpu")
+    keys = sorted(k.state_dict())
+    assert all(key.startswith("module.") for key in keys) and {"module.base_kernel.raw_lengthscale", "module.raw_outputscale"} <= set(keys)
+    x = torch.rand(6, 2)
+    op, ref = k(x), base(x)
+    assert type(op) is type(ref) and tuple(op.shape) == (6, 6)
+    assert torch.equal(k(x, diag=True), base(x, diag=True))
+    assert g.settings.sharding.probe_group() is None          # no process group: nothing installed

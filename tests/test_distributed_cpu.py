@@ -27,6 +27,14 @@ def _worker(rank, world, port, q):
     from tests.util import make_data
 
     group = D.init_from_env("gloo")
+    # the constructor-compatible MultiDeviceKernel: in a process group of more than one rank it installs WORLD as the probe / row group
+    import gpytorch_amd as g
+    from gpytorch_amd import settings as S0
+
+    assert S0.sharding.probe_group() is None and S0.sharding.row_group() is None
+    mdk = g.kernels.MultiDeviceKernel(g.kernels.RBFKernel(), device_ids=[torch.device("cpu")] * world)
+    assert S0.sharding.probe_group() is dist.group.WORLD and S0.sharding.row_group() is dist.group.WORLD and mdk.base_kernel.has_lengthscale
+    S0.sharding._probe_group = S0.sharding._row_group = None
     n, t_total = 300, 6
     X, y = make_data(n, 3)
     Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
