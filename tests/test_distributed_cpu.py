@@ -345,3 +345,92 @@ def test_probe_sharded_kronecker_mll_matches_single_process():
     Khat = K + torch.diag(dvec)
     assert abs(inv_quad - float(y @ torch.linalg.solve(Khat, y))) < 1e-5 * abs(inv_quad)
     assert abs(logdet - float(torch.logdet(Khat))) < 0.1 * abs(float(torch.logdet(Khat)))       # six probes: a stochastic estimate
+
+
+def _grid_worker(rank, world, port, q):
+    """2-D split: rank = p * 2 + r -- probe group p owns a share of the probe columns, row half r a block of rows."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from gpytorch_amd import backend as B
+    from gpytorch_amd import distributed as D
+    from oracle import kernels as OK
+    from oracle import linear_cg as OCG
+    from oracle import slq as OS
+    from tests.util import make_data
+
+    D.init_from_env("gloo")
+    G_r = 2
+    p, r = divmod(rank, G_r)
+    # every rank creates every subgroup, in the same order (torch.distributed contract)
+    row_groups = [dist.new_group([pp * G_r + rr for rr in range(G_r)]) for pp in range(world // G_r)]
+    probe_groups = [dist.new_group([pp * G_r + rr for pp in range(world // G_r)]) for rr in range(G_r)]
+    row_group, probe_group = row_groups[p], probe_groups[r]
+    n, t_total = 302, 6
+    X, y = make_data(n, 3)
+    Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
+    Z = Z / Z.norm(dim=-2, keepdim=True)
+    a, b = D.probe_shard(t_total, world // G_r, p)
+    t = b - a
+    rs = D.RowShard(B.PreparedPoints(X.clone(), n, 3, 3, "rbf"), row_group)
+    assert rs.rank == r and rs.world == G_r
+    K_rows = OK.kernel_matrix("rbf", X[rs.r0 : rs.r1], X, 0.25, 1.0, x1_eq_x2=False)
+    cols = torch.cat([Z[:, a:b], y.unsqueeze(-1)], dim=-1) if p == 0 else Z[:, a:b]       # the y column rides with probe group 0
+    rhs_loc = cols[rs.r0 : rs.r1]
+
+    def mm_local(D_loc):      # this rank's rows of K_hat @ D: directions all-gathered over the ROW group only
+        full = rs.gather(D_loc.t().contiguous())[:, :n].t()
+        return K_rows @ full + 0.1 * D_loc
+
+    def rowsum(v):            # inner products / norms: summed over the row group
+        return D.allreduce_sum_(v.clone(), row_group)
+
+    def mean_fn(rnorm):       # stopping rule: global mean over ALL columns -- summed over the probe group (one rank per probe share)
+        return D.allreduce_residual_stats(rnorm.sum(), torch.tensor(float(rnorm.numel())), probe_group)
+
+    sol_loc, T, info = OCG.linear_cg(mm_local, rhs_loc, n_tridiag=t, tolerance=1e-5, max_iter=300, max_tridiag_iter=30, return_info=True,
+                                     rowsum_fn=rowsum, mean_residual_fn=mean_fn)
+    ld = OS.slq_logdet(T, n) * (t / t_total)
+    D.allreduce_sum_(ld, probe_group)
+    q.put((rank, p, r, (a, b), (rs.r0, rs.r1), info["iters"], sol_loc.numpy(), float(ld)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_dimensional_split_probe_groups_times_row_halves_matches_single_process():
+    """The 2-D split of DESIGN.md section 6 (probe groups x row halves; 4 ranks = 2 x 2 over gloo, float64): row-group collectives carry the
+    products and inner products, the probe-group collectives the stopping rule and the SLQ sums -- two ORTHOGONAL subgroups per rank.
+    Same iteration count, the same solves (rows x columns of every rank) and the same log-det as the single-process evaluation."""
+    sys.path.insert(0, ROOT)
+    from oracle import exact_gp as OG
+    from oracle import linear_cg as OCG
+    from oracle import slq as OS
+    from tests.util import make_data
+
+    world, port = 4, free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grid_worker, args=(rk, world, port, q)) for rk in range(world)]
+    for pr in procs:
+        pr.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    n, t_total = 302, 6
+    X, y = make_data(n, 3)
+    Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
+    Z = Z / Z.norm(dim=-2, keepdim=True)
+    rhs = torch.cat([Z, y.unsqueeze(-1)], dim=-1)
+    sol, T, info = OCG.linear_cg(OG.make_matmul("rbf", X, 0.25, 1.0, 0.1), rhs, n_tridiag=t_total, tolerance=1e-5, max_iter=300, max_tridiag_iter=30,
+                                 return_info=True)
+    ld = float(OS.slq_logdet(T, n))
+    scale = float(sol.abs().max())
+    for rank, p, r, (a, b), (r0, r1), iters, s_loc, ldr in results:
+        s_loc = torch.from_numpy(s_loc)
+        assert iters == info["iters"], (rank, iters, info["iters"])
+        # (row sharding changes the reduction ORDER: rounding differences grow along the recurrence up to the level of the CG tolerance, 1e-5)
+        assert torch.allclose(s_loc[:, : b - a], sol[r0:r1, a:b], rtol=0, atol=3e-5 * scale)
+        if p == 0:
+            assert torch.allclose(s_loc[:, -1], sol[r0:r1, t_total], rtol=0, atol=3e-5 * scale)
+        assert abs(ldr - ld) < 1e-6 * abs(ld), (rank, ldr, ld)
