@@ -104,10 +104,46 @@ template <int KIND> __device__ __forceinline__ double dcov_any(double s, double 
 // profiles/r03_s6_gramv_mfma_vgpr_hazard.txt: wrong with the flag, right with the default AGPR destination -- whose v_accvgpr_read IS
 // interlocked -- and right, and 7 % faster, with this fence).  RBF instantiations happened to have enough independent instructions in
 // between.  The fence pins the MFMA group (sched_barrier) and idles 32 further wait states once per 32-row j block.
+//
+// Round 4: the fence must carry DATA dependencies.  `sched_barrier` only binds the machine scheduler; the MFMA builtins are pure
+// functions of their operands, so the IR-level passes that run before it (code sinking, instruction combining) are free to move an MFMA
+// BELOW a fence that merely sits between it and its reader in the source -- and did: in kv_grad2_kernel<RBF, 3, 0, WSPLIT> the last W MFMA
+// and the second Gram MFMA of every j step were emitted AFTER the wait states, back on the compiler's (insufficient) hazard table, which
+// is where the 1e-3 .. 4e-3 deviations of the split backward at n = 500 000 came from (a full chip, three waves per SIMD sharing the
+// matrix pipe; invisible at n <= 2048).  `mfma_result_fence(regs...)` therefore ties every result register to the wait states: an empty
+// volatile asm with a "+v" operand BEFORE the s_nops (the producing MFMA must precede it), the same AFTER them (every reader must follow it);
+// volatile asms keep their program order among themselves.  The zero-argument form remains for the epilogues of the AGPR-destination
+// kernels (kv_gram, kv_gramh, kv_mfma, kv_f64), whose v_accvgpr_read IS interlocked.
+template <typename T>
+__device__ __forceinline__ void mfma_tie(T& r) { asm volatile("" : "+v"(r)); }
+template <typename T, int N>
+__device__ __forceinline__ void mfma_tie(T (&r)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(r[k]));
+}
+template <typename T, int N, int M>
+__device__ __forceinline__ void mfma_tie(T (&r)[N][M]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int q = 0; q < M; ++q) asm volatile("" : "+v"(r[k][q]));
+}
 __device__ __forceinline__ void mfma_result_fence() {
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 15\n\ts_nop 15");
   __builtin_amdgcn_sched_barrier(0);
+}
+template <typename... R>
+__device__ __forceinline__ void mfma_result_fence(R&... regs) {
+#ifdef GPAMD_FENCE_NO_TIES   // A/B builds only (scripts/grad_at_size_diag.py): the round-3 fence without the data dependencies
+  mfma_result_fence();
+#else
+  __builtin_amdgcn_sched_barrier(0);
+  (mfma_tie(regs), ...);
+  asm volatile("s_nop 15\n\ts_nop 15");
+  (mfma_tie(regs), ...);
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[kh], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[kh], s1, 0, 0, 0);
     }
-    mfma_result_fence();   // VGPR-destination MFMA results (w0, w1, s0, s1) are read by the VALU next (gram_f16.hpp)
+    mfma_result_fence(w0, w1, s0, s1);   // VGPR-destination MFMA results are read by the VALU next: data-dependent fence (common.hpp)
     // ---- consume: k, dk/ds, A = W dk/ds
     float f0 = 0.f, f1 = 0.f, f2 = 0.f;
     f32x4 zacc[GZ];
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
       }
     }
-    if constexpr (MODE == 1) mfma_result_fence();   // zacc (4x4x1 MFMA results in VGPRs) is read next
+    if constexpr (MODE == 1) mfma_result_fence(zacc);   // zacc (4x4x1 MFMA results in VGPRs) is read next
     constexpr float RBF_DK = KIND == KIND_RBF ? -0.6931471805599453f : 1.0f;   // see the consume loop
     g[0] += (double)f0;
     g[1 + DP] += (double)f2;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GramF16<D>
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) kk[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq[ni][kh], kk[ni], 0, 0, 0);
       }
-      mfma_result_fence();   // VGPR-destination MFMA results are read by the VALU next (gram_f16.hpp)
+      mfma_result_fence(kk);   // VGPR-destination MFMA results are read by the VALU next (gram_f16.hpp)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GramF16<D>
   }
 
   // D_b[m][n]: registers 4b..4b+3 hold rows m = 4(lane>>4) + reg of block b; block b = (j half b>>1, point half b&1)
-  mfma_result_fence();   // the accumulators of the last contraction MFMAs are read next
+  mfma_result_fence(acc);   // the accumulators of the last contraction MFMAs are read next
   float* Pout = a.P + (int64_t)s * a.pstride;
   const int mrow = 4 * (lane >> 4);
 #pragma unroll

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void kv_gram4_kernel(KvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) kk[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq[ni][kh], kk[ni], 0, 0, 0);
       }
-      mfma_result_fence();   // VGPR-destination MFMA results are read by the VALU next (gram_f16.hpp)
+      mfma_result_fence(kk);   // VGPR-destination MFMA results are read by the VALU next (gram_f16.hpp)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int jl = jb + 8 * q + 4 * h;   // this half-wave's 4 consecutive j rows of register group q
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void kv_gram4_kernel(KvArgs a) {
     }
   }
 
-  mfma_result_fence();   // the accumulators of the last contraction MFMAs are read next
+  mfma_result_fence(acc);   // the accumulators of the last contraction MFMAs are read next
   float* Pout = a.P + (int64_t)s * a.pstride;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) kk[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq[ni][kh], kk[ni], 0, 0, 0);
       }
-      mfma_result_fence();
+      mfma_result_fence(kk);   // data-dependent fence (common.hpp): the Gram MFMAs before, every reader after the wait states
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int jl = jb + 8 * g + 4 * h;  // this half-wave's 4 consecutive j rows of group g (LDS broadcast reads)
