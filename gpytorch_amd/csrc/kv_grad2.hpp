@@ -352,6 +352,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
   }
 
+  if constexpr (WSPLIT) {
+    // this lane's row entered the planes as s_i L_i (kv_wsplit.hpp, ws_rowsign): every sum above is linear in W = L^T R, take the sign back
+    const float sg = ws_rowsign(i);
+#pragma unroll
+    for (int q = 0; q <= DP + 1; ++q) g[q] *= (double)sg;
+#pragma unroll
+    for (int q = 0; q < DP; ++q) gx[q] *= sg;
+  }
 #pragma unroll
   for (int q = 0; q <= DP + 1; ++q) {
     double v = wave_sum(g[q]);

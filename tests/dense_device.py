@@ -115,3 +115,100 @@ def dense_truth(kind, X, y, lengthscale, outputscale, sigma2, device, block=4096
     iq = float((sol * yd).sum())
     del K
     return iq, ld, sol.squeeze(-1)
+
+
+# ---- round 4: derivatives, bilinear forms and the predictive posterior from the same dense float64 machinery -------------------------
+
+def _scaled_operands(kind, X, lengthscale, device):
+    x = X.to(device=device, dtype=torch.float64)
+    ls = torch.as_tensor(lengthscale, dtype=torch.float64, device=device).reshape(1, -1)
+    if kind != "rbf":
+        x = x - x.mean(-2, keepdim=True)
+    x = x / ls
+    x1 = x - x.mean(-2, keepdim=True)
+    norm = x1.pow(2).sum(-1, keepdim=True)
+    one = torch.ones_like(norm)
+    return torch.cat([-2.0 * x1, norm, one], -1), torch.cat([x1, one, norm], -1).t().contiguous()
+
+
+def kernel_rows_and_dl(kind, a_rows, b_, lengthscale: float, row0=None):
+    """(K, dK/dl) for one row block of the UNSCALED kernel (single lengthscale), float64: a_rows [r, d + 2], b_ [d + 2, m].
+    ``row0``: index of the first row when the block sits on the diagonal of a square matrix (exact zeros of sq_dist there)."""
+    res = a_rows @ b_
+    if row0 is not None:
+        idx = torch.arange(a_rows.shape[0], device=res.device)
+        res[idx, idx + row0] = 0.0
+    res.clamp_min_(0.0)
+    if kind == "rbf":
+        K = torch.exp(-0.5 * res)
+        dl = K * res / lengthscale                       # d/dl exp(-d^2 / (2 l^2)) = K d^2 / l^3 = K S / l
+        return K, dl
+    nu = {"matern12": 0.5, "matern32": 1.5, "matern52": 2.5}[kind]
+    r = res.clamp_min_(1e-30).sqrt_().mul_(math.sqrt(2 * nu))
+    ex = torch.exp(-r)
+    if nu == 0.5:
+        return ex, r * ex / lengthscale
+    if nu == 1.5:
+        return (1.0 + r) * ex, r * r * ex / lengthscale
+    return (1.0 + r + r * r / 3.0) * ex, (r * r / 3.0) * (1.0 + r) * ex / lengthscale
+
+
+def bilinear_forms(kind, X, lengthscale: float, outputscale: float, Lv: torch.Tensor, Rv: torch.Tensor, device, block: int = 4096):
+    """Per column c: L_c^T (d K_hat / d theta) R_c for theta in (lengthscale, outputscale, noise), K_hat = outputscale K + noise I, in
+    float64 by dense row blocks.  Lv, Rv: [n, c] float64 on the device.  Returns three [c] tensors."""
+    n = X.shape[0]
+    a_, b_ = _scaled_operands(kind, X, lengthscale, device)
+    c = Lv.shape[1]
+    g_l = torch.zeros(c, dtype=torch.float64, device=device)
+    g_o = torch.zeros(c, dtype=torch.float64, device=device)
+    for a in range(0, n, block):
+        e = min(n, a + block)
+        K, dl = kernel_rows_and_dl(kind, a_[a:e], b_, lengthscale, row0=a)
+        g_o += (Lv[a:e] * (K @ Rv)).sum(0)
+        g_l += (Lv[a:e] * (dl @ Rv)).sum(0)
+        del K, dl
+    return outputscale * g_l, g_o, (Lv * Rv).sum(0)
+
+
+def cross_rows(kind, X, Xs, lengthscale: float, outputscale: float, device):
+    """outputscale * K(Xs, X) in float64 ([ns, n]); both clouds get the TRAINING cloud's centring, as the reference's kernel call on the
+    concatenated inputs does up to a common shift (stationary kernels: any common shift is exact)."""
+    x = X.to(device=device, dtype=torch.float64)
+    xs = Xs.to(device=device, dtype=torch.float64)
+    mu = x.mean(-2, keepdim=True)
+    x, xs = (x - mu) / lengthscale, (xs - mu) / lengthscale
+    d2 = (xs.pow(2).sum(-1, keepdim=True) + x.pow(2).sum(-1).unsqueeze(0) - 2.0 * xs @ x.t()).clamp_min_(0.0)
+    if kind == "rbf":
+        return outputscale * torch.exp(-0.5 * d2)
+    nu = {"matern12": 0.5, "matern32": 1.5, "matern52": 2.5}[kind]
+    r = d2.clamp_min_(1e-30).sqrt_().mul_(math.sqrt(2 * nu))
+    ex = torch.exp(-r)
+    k = ex if nu == 0.5 else ((1.0 + r) * ex if nu == 1.5 else (1.0 + r + r * r / 3.0) * ex)
+    return outputscale * k
+
+
+class DenseGP:
+    """K_hat = outputscale K + noise I factorised once; log det, solves, the exact posterior."""
+
+    def __init__(self, kind, X, y, lengthscale, outputscale, noise, device, block=4096):
+        self.kind, self.X, self.ls, self.os, self.s2, self.dev, self.block = kind, X, float(lengthscale), float(outputscale), float(noise), device, block
+        self.L = cholesky_inplace_(dense_khat(kind, X, lengthscale, outputscale, noise, device, block), block)
+        self.logdet = logdet_from_factor(self.L)
+        self.y = y.to(device=device, dtype=torch.float64).reshape(-1, 1)
+        self.alpha = self.solve(self.y)
+        self.inv_quad = float((self.alpha * self.y).sum())
+
+    def solve(self, b):
+        return solve_with_factor(self.L, b.to(device=self.dev, dtype=torch.float64), self.block)
+
+    def posterior(self, Xs):
+        """(mean, variance of f, K_*X) at the test points, float64 (zero prior mean)."""
+        ks = cross_rows(self.kind, self.X, Xs, self.ls, self.os, self.dev)          # [ns, n]
+        mean = (ks @ self.alpha).squeeze(-1)
+        v = self.solve(ks.t().contiguous())                                           # [n, ns]
+        var = self.os - (ks * v.t()).sum(-1)
+        return mean, var
+
+    def free(self):
+        self.L = None
+        torch.cuda.empty_cache()

@@ -125,3 +125,98 @@ def test_c3_shape_mll_ingredients_vs_dense_cholesky(dev):
     tight-tolerance runs land on the dense float64 values."""
     log = run_case("c3_n60000", "matern52", 60_000, 10, 0.8, dev)
     _check(log, conv_steps=100)
+
+
+# ---- round 4: the predictive posterior at the same sizes ------------------------------------------------------------------------------
+def run_posterior_case(name, kind, n, d, ls, dev, ns=1000,
+                       configs=((15, 0.01, False, 100), (15, 0.01, True, 100), (100, 1e-4, False, 100), (100, 1e-4, True, 100), (100, 1e-4, True, 400),
+                                (100, 1e-4, True, 1600))):
+    """Predictive mean / variance of f at ``ns`` test points through the model API (``ExactGP.__call__`` in eval mode ->
+    ``DefaultPredictionStrategy``: mean cache by mBCG, exact variance by a 1000-column solve, LOVE variance from the Lanczos root) against
+    ``K_*X K_hat^-1 y`` and ``diag(K_** - K_*X K_hat^-1 K_X*)`` from the dense float64 factor.  Mirrors
+    ``gpytorch/models/exact_prediction_strategies.py:371-478`` and the exact-vs-fast checks of ``test/examples/test_simple_gp_regression.py:386-388,
+    396-442`` (LOVE criterion there: |variance error| / noise < 0.05)."""
+    import gpytorch_amd as g
+    from tests.test_gpu_model import _model
+
+    theta, s2v = 1.0, 0.1
+    X, y = synth(n, d)
+    Xs, _ = synth(ns, d, seed=3)
+    log = {"name": name, "kind": kind, "n": n, "d": d, "test_points": ns, "lengthscale": ls, "outputscale": theta, "noise": s2v}
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    gp = DD.DenseGP(kind, X, y, ls, theta, s2v, dev)
+    mean_ref, var_ref = gp.posterior(Xs)
+    mean_ref, var_ref = mean_ref.cpu(), var_ref.cpu()
+    gp.free()
+    torch.cuda.synchronize(dev)
+    log["dense_seconds"] = time.perf_counter() - t0
+    log["dense"] = {"mean_abs_max": float(mean_ref.abs().max()), "var_min": float(var_ref.min()), "var_median": float(var_ref.median()), "var_max": float(var_ref.max())}
+    S = g.settings
+    Xsd = Xs.to(dev)
+    runs = []
+    # (preconditioner rank, eval_cg_tolerance, fast_pred_var, max_root_decomposition_size): the reference defaults first, then a tight solve and
+    # LOVE at growing Lanczos rank
+    for rank, tol, fast, love_rank in configs:
+        if True:
+            if True:
+                _, m, lik = _model(kind, X, y, ls, theta, s2v, dev, mean=0.0)   # a fresh model: cold caches
+                m.eval()
+                lik.eval()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(tol), S.fast_pred_var(fast), S.max_preconditioner_size(rank), \
+                        S.max_root_decomposition_size(love_rank), S.max_cg_iterations(6000):
+                    pred = m(Xsd)
+                    mu, var = pred.mean.double().cpu(), pred.variance.double().cpu()
+                torch.cuda.synchronize(dev)
+                sec = time.perf_counter() - t0
+                runs.append({
+                    "precond_rank": rank, "eval_cg_tolerance": tol, "fast_pred_var": fast, "love_rank": love_rank if fast else None, "seconds": sec,
+                    "mean_rel_err": float((mu - mean_ref).norm() / mean_ref.norm()),
+                    "mean_max_abs_err": float((mu - mean_ref).abs().max()),
+                    "var_max_rel_err": float(((var - var_ref).abs() / var_ref).max()),
+                    "var_max_err_over_noise": float((var - var_ref).abs().max() / s2v),
+                    "yvar_max_rel_err": float(((var - var_ref).abs() / (var_ref + s2v)).max()),
+                })
+                del m, lik
+                torch.cuda.empty_cache()
+    log["fused"] = runs
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/posterior_at_size_{name}.json", "w") as f:
+        json.dump(log, f, indent=1)
+    return log
+
+
+def _check_posterior(log, love_rank_ok=None):
+    love = []
+    for r in log["fused"]:
+        tag = (log["name"], r["precond_rank"], r["eval_cg_tolerance"], r["fast_pred_var"], r["love_rank"])
+        if r["eval_cg_tolerance"] <= 1e-4:
+            assert r["mean_rel_err"] < 1e-3, (tag, r["mean_rel_err"])
+            if not r["fast_pred_var"]:
+                # the predictive variance of y (what likelihood(model(x)) returns): K_** - K_*X K_hat^-1 K_X* + noise.  The variance of f itself is
+                # 1e-4 .. 2e-3 at C2 (1 - 0.9998...): float32 arithmetic cannot hold it to 2e-3 RELATIVE in this or in the reference's own code path
+                assert r["yvar_max_rel_err"] < 2e-3, (tag, r["yvar_max_rel_err"])
+            else:
+                love.append((r["love_rank"], r["var_max_err_over_noise"]))
+        else:
+            # the reference's default eval tolerance (0.01 on the normalised residual) is not a 1e-3 solve: recorded, bounded loosely
+            assert r["mean_rel_err"] < 2e-2, (tag, r["mean_rel_err"])
+    # LOVE is a rank-k Krylov approximation of K_hat^-1: its error is the ALGORITHM's and falls with the rank (max_root_decomposition_size, reference
+    # default 100).  The reference's own criterion -- variance error within 5 % of the noise, test_simple_gp_regression.py:436-442 -- from the
+    # rank given (C2: 400; the Matern d = 10 problem does not get there by rank 1600 -- recorded, and asserted to improve monotonically)
+    love.sort()
+    assert all(b[1] <= a[1] * 1.05 for a, b in zip(love, love[1:])), love
+    if love_rank_ok is not None:
+        assert all(err < 0.05 for rank, err in love if rank >= love_rank_ok), love
+
+
+def test_c2_posterior_vs_dense_cholesky(dev):
+    """BASELINE C2 (RBF, n = 100 000, d = 3): 1000 test points, rank-15 (reference default) and rank-100 preconditioner."""
+    _check_posterior(run_posterior_case("c2", "rbf", 100_000, 3, 0.25, dev), love_rank_ok=400)
+
+
+def test_c3_shape_posterior_vs_dense_cholesky(dev):
+    """C3's model (Matern-5/2, d = 10) at n = 60 000."""
+    _check_posterior(run_posterior_case("c3_n60000", "matern52", 60_000, 10, 0.8, dev))
