@@ -266,12 +266,29 @@ def batch_small_extras(dev, b=64, n=200, d=3, reps=3):
     return res
 
 
+def self_launch(n_ranks: int) -> int:
+    """Re-execute this script under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` with the same
+    arguments; stdout / stderr pass through (rank 0 prints the JSON line); returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["metric", "c2", "c3", "c4", "c5"], default="metric",
+    ap.add_argument("--config", choices=["metric", "c2", "c3", "c4", "c5", "road3d", "protein"], default="metric",
                     help="metric: n=500k, 64 probes/GPU + y (weak scaling; the configuration BASELINE.json's metric is quoted on); "
                          "c2: configs[1] (n=100k); c3: configs[2] (Matern-5/2, n=500k, d=10, rank-100 preconditioner); "
                          "c4: configs[3], n=1e6 with 256 probes IN TOTAL split over the ranks (strong scaling); "
@@ -288,7 +305,21 @@ def main():
     ap.add_argument("--skip-parity", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="skip the untimed API-level MLL fwd+bwd / posterior timings")
+    ap.add_argument("--grid", default=None, help="PxR (c4 / metric with N = P * R ranks): two-dimensional split -- P probe groups x R row blocks "
+                                                 "(bbmm.inv_quad_logdet_forward(group, row_group)); default: probes only (P = N, R = 1)")
     args = ap.parse_args()
+
+    if args.config in ("road3d", "protein"):
+        # the reference's published workloads end to end (training loop + prediction through the gpytorch-shaped API), SURVEY.md 8(f)1:
+        # scripts/reference_workloads.py; --size / --steps shrink them for smoke runs
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import reference_workloads
+
+        return reference_workloads.main(args.config, gpus=args.gpus, size=args.size, steps=args.steps if "--steps" in sys.argv else None)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher (the shape of the N = 1 command): start the N ranks ourselves, exactly as the driver's
+        # multi-GPU line does -- one process per GPU under torch.distributed.run on the loopback address; rank 0 prints the one JSON line
+        return self_launch(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -298,6 +329,20 @@ def main():
     backend = os.environ.get("GPAMD_BENCH_BACKEND", "nccl")
     if os.environ.get("GPAMD_BENCH_SHARE_DEVICE") == "1":
         local_rank = 0
+    if os.environ.get("GPAMD_BENCH_LAUNCH_ONLY") == "1":
+        # launcher test hook (tests/test_bench_launch_cpu.py, no GPU needed): prove that N ranks came up and can talk, then stop
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+            tt = torch.tensor([float(rank + 1)])
+            torch.distributed.all_reduce(tt)
+            tot = float(tt.item())
+            torch.distributed.destroy_process_group()
+        else:
+            tot = 1.0
+        if rank == 0:
+            print(json.dumps({"launched": world, "rank_sum": tot, "n_gpus": args.gpus}), flush=True)
+        return 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
@@ -310,6 +355,20 @@ def main():
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
         group = torch.distributed.group.WORLD
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # --grid PxR: P probe groups x R row blocks, rank = p * R + r.  The probe group of a rank = the P ranks with its r (stopping rule, SLQ sums),
+    # its row group = the R ranks with its p (all-gather of the search directions, inner products).  new_group is collective: every rank
+    # creates every group in the same order.
+    P_, R_ = world, 1
+    row_group = None
+    if args.grid:
+        P_, R_ = (int(v) for v in args.grid.lower().split("x"))
+        assert P_ * R_ == world, f"--grid {args.grid} needs {P_ * R_} ranks, have {world}"
+        if R_ > 1:
+            pgs = [torch.distributed.new_group([p * R_ + r for p in range(P_)]) for r in range(R_)]
+            rgs = [torch.distributed.new_group([p * R_ + r for r in range(R_)]) for p in range(P_)]
+            group = pgs[rank % R_] if P_ > 1 else None
+            row_group = rgs[rank // R_]
+    p_idx = rank // R_          # index of this rank's probe share
 
     from gpytorch_amd import backend as B
     from gpytorch_amd import linear_cg as LCG
@@ -328,18 +387,18 @@ def main():
         from gpytorch_amd.distributed import probe_shard
 
         t_total = args.probes if args.probes is not None else (256 if args.config == "c4" else 64)
-        a_, b_ = probe_shard(t_total, world, rank)
+        a_, b_ = probe_shard(t_total, P_, p_idx)
         t = b_ - a_
     else:
         t = args.probes if args.probes is not None else 64
-        t_total = t * world
+        t_total = t * P_
     ls = {3: 0.25, 10: 0.8, 6: 0.5}.get(d, 0.25)
     X, y = synth(n, d)
     Xd, yd = X.to(dev), y.to(dev)
     lengthscale = torch.tensor([ls], device=dev)
     outputscale = torch.tensor([1.0], device=dev)
     noise = torch.tensor([0.1], device=dev)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    gen = torch.Generator(device=dev).manual_seed(1234 + p_idx)   # one probe stream per probe share (row blocks of a share draw the same)
     rhs_t = B.to_probe_major(yd.unsqueeze(-1))
     shift = Xd.mean(dim=0)
     nvec = n * T
@@ -368,7 +427,7 @@ def main():
         else:
             pre = build_preconditioner(xp, outputscale, noise, rank=precond_rank, min_size=0) if precond_rank else None
             res = inv_quad_logdet_forward(
-                xp, outputscale, noise, rhs_t, num_probes=t, precond=pre, generator=gen, group=group, t_total=t_total
+                xp, outputscale, noise, rhs_t, num_probes=t, precond=pre, generator=gen, group=group, t_total=t_total, row_group=row_group
             )
         mll = -0.5 * (res.inv_quad.sum() + res.logdet + nvec * LOG_2PI) / nvec
         return mll, res.info.iterations
@@ -403,8 +462,9 @@ def main():
     med = durs[len(durs) // 2]
     live = [x for x in durs if x > 0.2 * med]  # launches issued after convergence are device-side no-ops
     kv_ms = sum(live) / len(live)
-    cols = t + (1 if rank == 0 else 0)      # the y column is solved by rank 0 only
-    flop_per_launch = 2.0 * n * n * cols * T   # c5: the fused launch of the Kronecker MVM carries T x columns (+ O(n T t) glue, inside the events)
+    cols = t + (1 if p_idx == 0 else 0)      # the y column is solved by the first probe share only
+    rows_loc = n if R_ == 1 else min(n, B.round_up((n + R_ - 1) // R_, 4))   # row block of this rank (distributed.RowShard)
+    flop_per_launch = 2.0 * rows_loc * n * cols * T   # c5: the fused launch of the Kronecker MVM carries T x columns (+ O(n T t) glue, inside the events)
     achieved = flop_per_launch / (kv_ms * 1e-3) / 1e12
 
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the
@@ -551,7 +611,8 @@ def main():
                                "c5": "BASELINE configs[4], 64 probes split over the ranks, one fused launch with 4 x columns per Kronecker MVM"}[args.config] + ")",
                 "name": args.config, "kind": kind, "tasks": T, "n": n, "d": d, "probes_total": t_total, "probes_rank0": t, "rhs_columns_rank0": cols,
                 "cg_iterations_per_step": iters_total / args.steps,
-                "parallelism": f"probe-sharded x{world}, y column on rank 0",
+                "parallelism": (f"probe-sharded x{world}, y column on rank 0" if R_ == 1 else
+                                f"2-D split: {P_} probe shares x {R_} row blocks, y column on the first share"),
             },
             "mll": float(mll),
             "roofline": roofline,
@@ -571,4 +632,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

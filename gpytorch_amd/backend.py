@@ -65,13 +65,15 @@ FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or
 class PreparedPoints:
     """A point cloud converted for the fused kernels: float32 [n, dp], scaled by 1/lengthscale."""
 
-    __slots__ = ("xp", "n", "d", "dp", "kind", "_zmax2", "param", "_sorted")
+    __slots__ = ("xp", "n", "d", "dp", "kind", "_zmax2", "param", "_sorted", "order_key")
 
     def __init__(self, xp, n, d, dp, kind, param=None):
         self.xp, self.n, self.d, self.dp, self.kind = xp, n, d, dp, kind
         self._zmax2 = None
         self.param = param   # shape parameter of the covariance family (RQ: alpha, a Python float) or None
         self._sorted = None  # lazily: SortedView (Hilbert order + chunk centres) for the block-centred Gram expansion
+        self.order_key = None  # identity of the SOURCE cloud when the scaling is uniform (prep_points): the Hilbert order is then shared
+        #                        by every evaluation of a training run (it is invariant under translation and uniform scaling)
 
     def sorted_view(self):
         """The rows of ``xp`` along a Hilbert curve, with the centre of every 128-row chunk and the largest block radius: what the
@@ -139,6 +141,12 @@ def hilbert_order(z: torch.Tensor, bits: int | None = None) -> torch.Tensor:
     return torch.argsort(key)
 
 
+# Hilbert permutations by source cloud (data pointer, version counter, shape, device): hyper-parameters change every training step and the
+# prepared points with them, but for a single lengthscale the ORDER of the rows along the curve does not (any permutation is valid for the
+# kernels -- compactness is re-evaluated on the actual coordinates every time -- so a stale entry can only cost speed, never accuracy)
+_ORDER_CACHE: dict = {}
+
+
 class SortedView:
     """Hilbert-sorted copy of a prepared cloud for the block-centred Gram expansion (csrc/gram_f16.hpp ``load_center``).
 
@@ -156,7 +164,13 @@ class SortedView:
     def __init__(self, x: "PreparedPoints"):
         n, dp = x.n, x.dp
         dev = x.xp.device
-        perm = hilbert_order(x.xp[:, : x.d])
+        perm = _ORDER_CACHE.get(x.order_key) if x.order_key is not None else None
+        if perm is None:
+            perm = hilbert_order(x.xp[:, : x.d])
+            if x.order_key is not None:
+                while len(_ORDER_CACHE) >= 8:          # a handful of clouds (train / test inputs of a few models), oldest first out
+                    _ORDER_CACHE.pop(next(iter(_ORDER_CACHE)))
+                _ORDER_CACHE[x.order_key] = perm
         xs = x.xp.index_select(0, perm)
         ng = (n + 511) // 512
         wide = torch.zeros(ng, device=dev, dtype=torch.bool)
@@ -281,6 +295,7 @@ def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: to
     n, d = x.shape[-2], x.shape[-1]
     dp = padded_dim(d)
     wd = work_dtype(x)
+    x_src = x if x.dim() == 2 else None
     x = x.detach().to(wd).contiguous()
     ls = lengthscale.detach().to(device=x.device, dtype=wd).reshape(-1).contiguous()
     if ls.numel() not in (1, d):
@@ -290,7 +305,10 @@ def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: to
     fn = lib().gpamd_prep_points_f64 if wd == torch.float64 else lib().gpamd_prep_points_f32
     lead = (KIND_IDS[kind], param if param is not None else 0.0)
     check(fn(*lead, _ptr(x), n, d, x.stride(0), _ptr(ls), ls.numel(), _ptr(sh), _ptr(xp), dp, _stream(x.device)), "prep_points")
-    return PreparedPoints(xp, n, d, dp, kind, param)
+    out = PreparedPoints(xp, n, d, dp, kind, param)
+    if ls.numel() == 1 and x_src is not None:
+        out.order_key = (x_src.data_ptr(), x_src._version, tuple(x_src.shape), str(x_src.device), x_src.dtype)
+    return out
 
 
 def to_probe_major(rhs: torch.Tensor, dtype: torch.dtype | None = None) -> torch.Tensor:
@@ -644,12 +662,39 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
         nx = int(L.gpamd_kv_grad2_xworkspace_floats(x1.n, x2.n, t, x1.d))
         xws = torch.empty(nx, device=dev, dtype=torch.float32)
         gzt = torch.empty(x1.d, ldg, device=dev, dtype=torch.float32)
-    X1, Xc, unsort, _ = gram_operands(x1, x2, KV_GRAM)
+    if gram_mode(x1, x2) == 0 and max(x1.zmax2, x2.zmax2) > GRAM_MAX_SQNORM:
+        # (callers check grad_gram_ok first; a direct call outside the accuracy policy of the quadratic expansion must not pass silently)
+        raise RuntimeError("kv_grad2: the clouds are outside the accuracy policy of the Gram-form expansion (backend.gram_mode == 0); "
+                           "use kv_grad / kv_grad_generic")
+    X1, Xc, unsort, n_c = gram_operands(x1, x2, KV_GRAM)
+    n_rows = x1.n
+    wide = None
     if unsort is not None:
         # block-centred expansion: the left vectors follow x1's Hilbert order (one gather of t x n floats per backward pass)
         lt = lt[:, : x1.n].index_select(1, x1.sorted_view().perm).contiguous()
+        if n_c < x1.n:
+            # the rows of the WIDE groups (sparse tails, SortedView: block radius beyond the 2e-5 policy of the expansion) take the
+            # direct-difference row-block path, as in the forward product (kv_partials_sorted); the Gram-form kernel sees the compact rows only
+            xw = PreparedPoints(X1[n_c:].contiguous(), x1.n - n_c, x1.d, x1.dp, x1.kind, x1.param)
+            ltw = lt[:, n_c:].contiguous()
+            if ltw.shape[1] % 4:
+                ltw = torch.nn.functional.pad(ltw, (0, 4 - ltw.shape[1] % 4))
+            if want_gz1 or x1.kind == "rq":
+                # input gradients / the shape-parameter sum of the tail rows: dense row blocks (HIP generation + library GEMMs, float64 sums)
+                wide = kv_grad_generic(xw, x2, ltw, rt, want_gz1=want_gz1)
+            else:
+                # hyper-parameter sums only: the fused direct-difference derivative kernel (kv_grad.hpp) on the rectangular block
+                gw = kv_grad(xw, x2, ltw, rt, iso=False)
+                wide = torch.cat([gw.double(), torch.zeros(1, device=dev, dtype=torch.float64)])
+            lt = lt[:, :n_c].contiguous()
+            n_rows = n_c
         if lt.shape[1] % 4:
             lt = torch.nn.functional.pad(lt, (0, 4 - lt.shape[1] % 4))
+        nd = int(L.gpamd_kv_grad2_workspace_doubles(n_rows, x2.n, t, x1.d))
+        ws = torch.empty(nd, device=dev, dtype=torch.float64)
+        if want_gz1:
+            nx = int(L.gpamd_kv_grad2_xworkspace_floats(n_rows, x2.n, t, x1.d))
+            xws = torch.empty(nx, device=dev, dtype=torch.float32)
     # W = L^T R on the f16 matrix pipe at f32 accuracy (kv_grad2.hpp WSPLIT; the same switch as the K*V contraction) from 24 columns on: a
     # 32 x 32 tile costs 15 f16 MFMAs (480 cycles) whatever t, the fp32 form t / 2 MFMAs of 64 cycles -- cheaper below 15 columns, and exact
     # to 1e-10 of sum |W dK| where the f16 accumulation leaves a 1.5e-8 floor (measured: profiles/r03_s15_grad_split_error_floor.txt; it only
@@ -658,7 +703,7 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
     split = _split_on() and t >= GRAD_SPLIT_MIN_COLS and (x1.d <= 6 or (iso and not want_gz1))
     sws, ns = None, 0
     if split:
-        ns = int(L.gpamd_kv_grad2_split_workspace_floats(x1.n, x2.n))
+        ns = int(L.gpamd_kv_grad2_split_workspace_floats(n_rows, x2.n))
         sws = torch.empty(ns, device=dev, dtype=torch.float32)
         if lt.stride(0) % 4 or lt.data_ptr() % 16:
             lt = torch.nn.functional.pad(lt, (0, (-lt.shape[1]) % 4)).contiguous()
@@ -666,11 +711,22 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
             rt = torch.nn.functional.pad(rt, (0, (-rt.shape[1]) % 4)).contiguous()
     check(
         L.gpamd_kv_grad2_f32(
-            *kind_args(x1), _ptr(X1), x1.n, _ptr(x2.xp), x2.n, x1.d, _ptr(Xc), _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
+            *kind_args(x1), _ptr(X1), n_rows, _ptr(x2.xp), x2.n, x1.d, _ptr(Xc), _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
             1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, KV_SPLIT if split else 0, _ptr(sws), ns, _stream(dev),
         ),
         "kv_grad2",
     )
+    if wide is not None:
+        gw, gzw = wide if want_gz1 else (wide, None)
+        gw = gw.to(out.dtype)
+        if iso and not want_gz1:   # MODE 0 convention: out[1] holds the single-lengthscale sum
+            out[0] += gw[0]
+            out[1] += gw[1 : 1 + x1.d].sum()
+            out[1 + x1.dp] += gw[1 + x1.dp]
+        else:
+            out += gw
+        if gzt is not None:
+            gzt[:, n_c : x1.n] = gzw.t().to(gzt.dtype)
     if unsort is not None and gzt is not None:
         gzt = gzt.index_select(1, unsort)
     if iso and want_gz1:  # the kernel ran in per-dimension mode: fold to the single-lengthscale convention of kv_grad
@@ -688,7 +744,7 @@ def prep_coef_of(xp: PreparedPoints) -> float:
     return 1.0 / math.sqrt(2.0 * xp.param) if xp.kind == "rq" else prep_coef(xp.kind)
 
 
-def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor) -> torch.Tensor:
+def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor, want_gz1: bool = False):
     """Generic-path (float64, or d > 16) twin of :func:`kv_grad`; same return convention, float64 [2 + dp] (the last element is the
     shape-parameter sum  sum W dk/dp|_s  of a parametrised family -- RQ's alpha --, zero otherwise: as :func:`kv_grad2`).
 
@@ -707,16 +763,21 @@ def kv_grad_generic(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt
     r_all = rt[:, :m].to(dt)
     rows = int(max(1, min(n, 65535, (1 << 26) // max(m, 1))))
     st = _stream(dev)
+    gz = torch.empty(n, x1.d, device=dev, dtype=torch.float64) if want_gz1 else None
     for r0 in range(0, n, rows):
         nr = min(rows, n - r0)
         w = (lt[:, r0 : r0 + nr].to(dt).t() @ r_all).contiguous()
         check(fn(*kind_args(x1), _ptr(x1.xp), r0, nr, _ptr(x2.xp), m, dp, _ptr(w), w.stride(0), _ptr(acc), st), "kernel_grad_block")
         a = w.to(torch.float64)
         zb = z1[r0 : r0 + nr]
-        gq += (zb.pow(2) * a.sum(1, keepdim=True)).sum(0) - 2.0 * (zb * (a @ z2)).sum(0)
+        rs, az = a.sum(1, keepdim=True), a @ z2
+        gq += (zb.pow(2) * rs).sum(0) - 2.0 * (zb * az).sum(0)
         cs += a.sum(0)
+        if want_gz1:   # d/dz_i of sum_j A_ij |z_i - z_j|^2 = 2 (z_i rowsum_i - (A z2)_i): the convention of kv_grad2's Gz1
+            gz[r0 : r0 + nr] = 2.0 * (zb * rs - az)[:, : x1.d]
     gq += (z2.pow(2) * cs.unsqueeze(-1)).sum(0)
-    return torch.cat([acc[:1], gq, acc[1:]])
+    out = torch.cat([acc[:1], gq, acc[1:]])
+    return (out, gz) if want_gz1 else out
 
 
 # d s / d l factors: s = sum_q z_q^2-differences with z = coef * x / l  =>  ds_q/dl_q = -2 s_q / l_q

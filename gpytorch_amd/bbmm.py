@@ -167,7 +167,10 @@ def deterministic_probe_matrix(n: int, t: int, device, dtype=torch.float32, shar
         z = settings.deterministic_probes._drawn.get(key)
         if z is None:
             z = torch.randn(n, t_all, device=device, dtype=dtype)
-            settings.deterministic_probes._drawn[key] = z
+            drawn = settings.deterministic_probes._drawn
+            while len(drawn) >= settings.deterministic_probes.max_kept:   # bounded: the oldest matrix goes (20 MB each at n = 5e5, 10 probes)
+                drawn.pop(next(iter(drawn)))
+            drawn[key] = z
         settings.deterministic_probes.probe_vectors = z
     return z if shard is None else z[:, shard[1] : shard[2]]
 
@@ -242,6 +245,7 @@ def inv_quad_logdet_forward(
     rhs_owner: int = 0,
     kv_partials=None,
     nvec=None,
+    row_group=None,
 ) -> InvQuadLogdetResult:
     """A.6 forward for K_hat = scale*K(x,x) + sigma2*I.
 
@@ -253,7 +257,14 @@ def inv_quad_logdet_forward(
     STRUCTURED operators (sum of kernels, Kronecker, Hadamard): ``x = None``, ``kv_partials(Dt) -> (P, S, ldp)`` is the noise-free
     product (as for :func:`linear_cg`), ``nvec`` the vector length, ``dvec`` the WHOLE diagonal and ``precond`` an explicit
     :class:`Preconditioner` (``build_preconditioner_rows``) or None; everything else -- probes from N(0, P), sharding, SLQ -- is shared.  Communication: the 2-float stopping-rule all-reduce per CG iteration (stream-
-    ordered under RCCL), one scalar all-reduce of the SLQ sums, one broadcast of the c rhs solves."""
+    ordered under RCCL), one scalar all-reduce of the SLQ sums, one broadcast of the c rhs solves.
+    TWO-DIMENSIONAL split (``row_group``, with or without ``group``): the ROWS of the system are sharded over ``row_group`` as well
+    (:class:`gpytorch_amd.distributed.RowShard`): every rank of a row group carries the same probe columns on its own block of rows, the
+    search directions are all-gathered and the solver's inner products all-reduced over the row group each iteration, the stopping rule and
+    the SLQ sums go over the probe group as before.  That is what keeps 64 + 1 columns per GPU when 256 probes meet 8 GPUs (4 probe groups x 2
+    row halves) instead of 32 + 1, where kernel generation no longer hides under the contraction.  The probes are drawn by the first
+    rank of each row group and broadcast (n t floats, once per evaluation); the solves are gathered to full length at the end, so the result
+    -- and the backward pass built on it -- looks exactly like the probe-sharded one on every rank."""
     n = x.n if nvec is None else nvec
     dev = rhs_t.device
     wd = x.dtype if x is not None else rhs_t.dtype
@@ -282,10 +293,25 @@ def inv_quad_logdet_forward(
             t_total = int(tt.item())
     c = rhs_t.shape[0]
     full = torch.cat([zt, rhs_t.to(wd)], dim=0).contiguous() if owns_rhs else zt
-    solves_t, info = linear_cg(
-        x, scale, sigma2, full, n_tridiag=t, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, group=group,
-        dvec=dvec, kv_partials=kv_partials, nvec=nvec,
-    )
+    rs = None
+    if row_group is not None and torch.distributed.get_world_size(row_group) > 1:
+        if x is None or kv_partials is not None or dvec is not None or not x.fused:
+            raise NotImplementedError("row-sharded MLL solves: single fused float32 kernel operator with a constant diagonal")
+        from .distributed import RowShard
+
+        rs = RowShard(x, row_group)
+        rs.broadcast(zt)                      # one probe draw per row group (the first rank's)
+        rs.broadcast(znorm)
+        full = torch.cat([zt, rhs_t.to(wd)], dim=0).contiguous() if owns_rhs else zt
+        loc, info = linear_cg(None, scale, sigma2, rs.local(full), n_tridiag=t, tolerance=tolerance, max_iter=max_iter, preconditioner=precond,
+                              group=group, row_shard=rs)
+        solves_t = torch.zeros(loc.shape[0], B.round_up(n, 4), device=dev, dtype=loc.dtype)
+        solves_t[:, :n] = rs.gather(loc)[:, :n]
+    else:
+        solves_t, info = linear_cg(
+            x, scale, sigma2, full, n_tridiag=t, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, group=group,
+            dvec=dvec, kv_partials=kv_partials, nvec=nvec,
+        )
     if settings.skip_logdet_forward.on():
         ld_slq = torch.zeros((), dtype=torch.float64)
     else:
@@ -333,7 +359,8 @@ def allreduce_grads_(grads: list, group):
     live = [g for g in grads if g is not None]
     if group is None or not live:
         return grads
-    pack = torch.cat([g.reshape(-1).to(torch.float32) for g in live])
+    wide = torch.float64 if any(g.dtype == torch.float64 for g in live) else torch.float32   # float64 models: no truncation under sharding
+    pack = torch.cat([g.reshape(-1).to(wide) for g in live])
     allreduce_sum_(pack, group)
     o = 0
     for g in live:

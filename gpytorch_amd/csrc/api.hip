@@ -673,14 +673,13 @@ int gpamd_pivoted_cholesky_f32(int kind, float kparam, const float* Xp, int n, i
 namespace {
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 nccl_allreduce_fn rccl_allreduce() {
-  static nccl_allreduce_fn fn = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  // function-local static with a lambda initialiser: initialised exactly once, thread-safe by the language rules (no "tried" flag that a
+  // second thread could observe set while the pointer is still null)
+  static const nccl_allreduce_fn fn = []() -> nccl_allreduce_fn {
     void* hdl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!hdl) hdl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (hdl) fn = reinterpret_cast<nccl_allreduce_fn>(dlsym(hdl, "ncclAllReduce"));
-  }
+    return hdl ? reinterpret_cast<nccl_allreduce_fn>(dlsym(hdl, "ncclAllReduce")) : nullptr;
+  }();
   return fn;
 }
 }  // namespace

@@ -52,6 +52,12 @@ def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t, want_x1=Fal
     if B.grad_gram_ok(xp1, xp2):
         g, gz1 = B.kv_grad2(xp1, xp2, left_t, right_t, iso=iso, want_gz1=want_x1)
         if want_x2:  # the same kernel with the roles of the two clouds exchanged
+            # gram_mode is not symmetric (it needs a compact sorted view of its FIRST cloud): the exchanged call has its own check
+            if xp2 is not xp1 and not B.grad_gram_ok(xp2, xp1):
+                raise RuntimeError(
+                    "gradients with respect to the second input cloud need the Gram-form derivative kernel with the clouds exchanged, and "
+                    "k(x2, x1) is outside its accuracy policy (backend.gram_mode(x2, x1) == 0: x2 too small or too wide for the block-centred expansion)"
+                )
             _, gz2 = B.kv_grad2(xp2, xp1, right_t, left_t, iso=iso, want_gz1=True)
     else:
         if want_x1 or want_x2:
@@ -101,7 +107,7 @@ class InvQuadLogdetFn(torch.autograd.Function):
             xp, os_, nz, rhs_t,
             num_probes=opts.get("num_probes"), precond=opts.get("precond", "auto"), probes=opts.get("probes"),
             generator=opts.get("generator"), tolerance=opts.get("tolerance"), max_iter=opts.get("max_iter"),
-            group=opts.get("group"), t_total=opts.get("t_total"), dvec=spec.dvec,
+            group=opts.get("group"), t_total=opts.get("t_total"), dvec=spec.dvec, row_group=opts.get("row_group"),
         )
         ctx.xp, ctx.res, ctx.n = xp, res, n
         ctx.x_dtype = x.dtype

@@ -329,15 +329,33 @@ class MultiDeviceKernel(Kernel):
         from . import settings
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # process-global, like every setting here (and like the reference's settings): said out loud once, undone by `release()`
+            import warnings
+
+            installed = []
             if settings.sharding._probe_group is None:
                 settings.sharding._probe_group = dist.group.WORLD
+                installed.append("probe_group")
             if settings.sharding._row_group is None:
                 settings.sharding._row_group = dist.group.WORLD
+                installed.append("row_group")
+            self._installed = installed
+            if installed:
+                warnings.warn(f"gpytorch_amd.kernels.MultiDeviceKernel installed the WORLD process group as settings.sharding {' / '.join(installed)} "
+                              "for EVERY model of this process; MultiDeviceKernel.release() (or a settings.sharding(...) scope) undoes it.", RuntimeWarning)
         elif len(self.device_ids) > 1:
             import warnings
 
             warnings.warn("gpytorch_amd.kernels.MultiDeviceKernel: multi-GPU runs are one process per GPU (torchrun + settings.sharding); "
                           "this single process evaluates the kernel on the device of its inputs.", RuntimeWarning)
+
+    def release(self):
+        """Take back the process groups this constructor installed in ``settings.sharding`` (no-op if it installed none)."""
+        from . import settings
+
+        for name in getattr(self, "_installed", []):
+            setattr(settings.sharding, "_" + name, None)
+        self._installed = []
 
     @property
     def base_kernel(self):

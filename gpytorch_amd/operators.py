@@ -716,6 +716,9 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         """Solver options of this evaluation: ``bbmm_opts`` completed with the ``settings.sharding`` probe group
         (each rank then draws its share of ``num_trace_samples`` from a rank-specific generator)."""
         opts = self.bbmm_opts
+        rg = settings.sharding.mll_row_group()
+        if rg is not None and "row_group" not in opts and torch.distributed.get_world_size(rg) > 1:
+            opts = dict(opts, row_group=rg)   # two-dimensional split (probe groups x row blocks), bbmm.inv_quad_logdet_forward
         group = opts.get("group", settings.sharding.probe_group())
         if group is None or "group" in opts or torch.distributed.get_world_size(group) == 1:
             return opts

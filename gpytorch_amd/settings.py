@@ -260,6 +260,15 @@ class deterministic_probes(_feature_flag):
     _default = False
     probe_vectors = None   # the most recently used / user-injected matrix
     _drawn = {}            # (n, t) -> matrix drawn by the library: alternating between models of different size keeps each one's probes
+    max_kept = 4           # ... at most this many of them (insertion order; the oldest is dropped).  They deliberately SURVIVE the context --
+    #                        a training loop that re-enters ``deterministic_probes(True)`` per closure call must see the same objective, as with
+    #                        the reference's class attribute -- ``deterministic_probes.reset()`` releases them.
+
+    @classmethod
+    def reset(cls):
+        """Forget the probe matrices the library drew (and the most recently used one)."""
+        cls._drawn.clear()
+        cls.probe_vectors = None
 
 
 class cg_graph(_feature_flag):
@@ -330,17 +339,25 @@ class sharding:
       * ``probe_group``: the probe columns of ``inv_quad_logdet`` (MLL forward / backward) are partitioned over the ranks
         of this group -- each rank draws ``num_trace_samples // world`` (+1 for the first ranks) probes;
       * ``row_group``: the small-t solves of the predictive posterior (mean-cache CG, LOVE Lanczos) are ROW-sharded over
-        this group -- every rank ends up with the full caches.
+        this group -- every rank ends up with the full caches;
+      * ``mll_row_group``: the rows of the ``inv_quad_logdet`` solve are sharded over this group TOO (with ``probe_group``: the
+        two-dimensional split of ``bbmm.inv_quad_logdet_forward`` -- probe groups x row blocks; the two groups must be orthogonal, i.e. a
+        P x R grid of ranks).  For many GPUs and few probes per GPU (C4: 256 probes on 8 GPUs -> 4 x 2 keeps 64 + 1 columns per rank).
 
     Replaces ``gpytorch.kernels.MultiDeviceKernel`` (``multi_device_kernel.py:49-92``).  Not thread-safe, like every
     other setting here (``gpytorch/settings.py:84-144`` are process-global class attributes)."""
 
     _probe_group = None
     _row_group = None
+    _mll_row_group = None
     _generators: dict = {}
 
-    def __init__(self, probe_group=None, row_group=None):
-        self._new = (probe_group, row_group)
+    def __init__(self, probe_group=None, row_group=None, mll_row_group=None):
+        self._new = (probe_group, row_group, mll_row_group)
+
+    @classmethod
+    def mll_row_group(cls):
+        return cls._mll_row_group
 
     @classmethod
     def probe_group(cls):
@@ -368,10 +385,10 @@ class sharding:
         cls._generators.clear()
 
     def __enter__(self):
-        self._old = (sharding._probe_group, sharding._row_group)
-        sharding._probe_group, sharding._row_group = self._new
+        self._old = (sharding._probe_group, sharding._row_group, sharding._mll_row_group)
+        sharding._probe_group, sharding._row_group, sharding._mll_row_group = self._new
         return self
 
     def __exit__(self, *args):
-        sharding._probe_group, sharding._row_group = self._old
+        sharding._probe_group, sharding._row_group, sharding._mll_row_group = self._old
         return False

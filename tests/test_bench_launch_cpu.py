@@ -1,0 +1,29 @@
+"""bench.py's self-launch: `python bench.py --gpus N` WITHOUT a launcher in the environment (the shape of the driver's N = 1 command) must start N
+ranks itself under torch.distributed.run on the loopback address and keep the one-JSON-line contract on rank 0.  No GPU needed: the
+GPAMD_BENCH_LAUNCH_ONLY hook stops every rank after one gloo all-reduce, before anything touches a device."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GPAMD_BENCH_LAUNCH_ONLY="1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout            # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_present():
+    rec = _run(3)
+    assert rec == {"launched": 3, "rank_sum": 6.0, "n_gpus": 3}
+
+
+def test_bench_single_rank_needs_no_launcher():
+    assert _run(1)["launched"] == 1

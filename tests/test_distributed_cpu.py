@@ -32,9 +32,15 @@ def _worker(rank, world, port, q):
     from gpytorch_amd import settings as S0
 
     assert S0.sharding.probe_group() is None and S0.sharding.row_group() is None
-    mdk = g.kernels.MultiDeviceKernel(g.kernels.RBFKernel(), device_ids=[torch.device("cpu")] * world)
+    import warnings as _w
+
+    with _w.catch_warnings(record=True) as caught:
+        _w.simplefilter("always")
+        mdk = g.kernels.MultiDeviceKernel(g.kernels.RBFKernel(), device_ids=[torch.device("cpu")] * world)
+    assert any("installed the WORLD process group" in str(c.message) for c in caught)     # process-global state is announced ...
     assert S0.sharding.probe_group() is dist.group.WORLD and S0.sharding.row_group() is dist.group.WORLD and mdk.base_kernel.has_lengthscale
-    S0.sharding._probe_group = S0.sharding._row_group = None
+    mdk.release()                                                                          # ... and can be taken back
+    assert S0.sharding.probe_group() is None and S0.sharding.row_group() is None
     n, t_total = 300, 6
     X, y = make_data(n, 3)
     Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)

@@ -645,3 +645,94 @@ def test_ciq_square_root_at_size_against_a_tight_cg_solve(dev):
     assert info.tolerance_reached
     ref = B.from_probe_major(sol_t, n)
     assert rel_err(full, ref) < 2e-3, rel_err(full, ref)
+
+
+# ---- round 4: the TWO-DIMENSIONAL split (probe groups x row blocks) through the product's own inv_quad_logdet / linear_cg -----------------
+def _grid_groups(dist, P, R, rank):
+    """P x R grid, rank = p * R + r: (probe group of this rank = the P ranks with the same r, row group = the R ranks with the same p).
+    Every rank creates every group, in the same order (torch.distributed.new_group is collective)."""
+    probe_groups = [dist.new_group([p * R + r for p in range(P)]) for r in range(R)]
+    row_groups = [dist.new_group([p * R + r for r in range(R)]) for p in range(P)]
+    return probe_groups[rank % R], row_groups[rank // R]
+
+
+def _mll_setup(g, dev, n=2600, precond=0):
+    X, y = make_data(n, 3)
+
+    class GPModel(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ZeroMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel())
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood()
+    m = GPModel(X.float().to(dev), y.float().to(dev), lik).to(dev)
+    m.covar_module.base_kernel.lengthscale, m.covar_module.outputscale, lik.noise = 0.25, 1.1, 0.1
+    return m, lik
+
+
+def _mll_and_grads(g, m, lik, precond):
+    S = g.settings
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    m.train()
+    lik.train()
+    with S.max_cholesky_size(0), S.cg_tolerance(1e-4), S.num_trace_samples(16), S.max_preconditioner_size(precond), S.min_preconditioning_size(100), \
+            S.deterministic_probes(True):
+        val = mll(m(m.train_inputs[0]), m.train_targets)
+        val.backward()
+    from gpytorch_amd import linear_cg as LCG
+
+    grads = [float(p.grad.sum()) for p in (m.covar_module.base_kernel.raw_lengthscale, m.covar_module.raw_outputscale, lik.noise_covar.raw_noise)]
+    return float(val.detach()), grads, LCG.LAST_INFO.iterations
+
+
+def _grid_worker(rank, world, port, q, P, R, precond):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import gpytorch_amd as g
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    pg, rg = _grid_groups(dist, P, R, rank)
+    torch.manual_seed(5)      # deterministic_probes: every rank draws the same (n, 16) matrix and takes its probe group's columns
+    m, lik = _mll_setup(g, dev)
+    with g.settings.sharding(probe_group=pg if P > 1 else None, mll_row_group=rg if R > 1 else None):
+        val, grads, iters = _mll_and_grads(g, m, lik, precond)
+    q.put((rank, val, grads, iters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P,R,precond", [(2, 2, 0), (1, 2, 0), (2, 2, 15)])
+def test_two_dimensional_split_of_the_mll_on_device(P, R, precond, dev):
+    """``settings.sharding(probe_group, mll_row_group)`` -> ``bbmm.inv_quad_logdet_forward(group, row_group)`` -> the PRODUCT's ``linear_cg`` with a
+    probe group and a ``RowShard`` at once: P x R processes share cuda:0 (gloo carries the all-gathers of the search directions and the inner
+    products over the row group, the 2-float stopping rule and the SLQ sums over the probe group).  Same marginal log likelihood, same
+    hyper-parameter gradients and the same iteration count as the single-process evaluation with the same 16 probes, on every rank.
+    Replaces ``gpytorch/kernels/multi_device_kernel.py:49-92``; DESIGN section 6."""
+    import gpytorch_amd as g
+
+    world, port = P * R, free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grid_worker, args=(r, world, port, q, P, R, precond)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = _collect(q, procs, world)
+    torch.manual_seed(5)
+    g.settings.deterministic_probes._drawn.clear()          # (other tests of this process may have drawn an (n, 16) matrix already)
+    g.settings.deterministic_probes.probe_vectors = None
+    m, lik = _mll_setup(g, dev)
+    val, grads, iters = _mll_and_grads(g, m, lik, precond)
+    for rank, v, gr, it in results:
+        assert abs(it - iters) <= max(2, 0.05 * iters), (rank, it, iters)
+        # (row blocks run rectangular launches: other split counts and summation orders than the square single-process product -- float32 mBCG
+        # at a 1e-4 residual reproduces the log-det quadrature to a few 1e-4 of its value)
+        assert abs(v - val) < 5e-4 * max(1.0, abs(val)), (rank, v, val)
+        for a, b in zip(gr, grads):
+            assert abs(a - b) < 1e-2 * abs(b) + 1e-6, (rank, gr, grads)

@@ -220,3 +220,50 @@ def test_fallback_outside_the_block_bound_warns(dev):
     got = B.from_probe_major(B.kv(xp, xp, B.to_probe_major(V.to(dev))), 600)
     ref = OK.rbf(X.double(), X.double(), 0.002, x1_eq_x2=True, direct=True) @ V.double()
     assert rel_err(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["f32W", "splitW"])
+def test_backward_on_a_heavy_tailed_cloud_sends_the_wide_rows_to_the_direct_path(split, dev):
+    """Round-3 advisor finding: ``backend.kv_grad2`` ran the Gram-form derivative kernel over ALL sorted rows, including the wide groups
+    (sparse tails whose block radius is outside the 2e-5 policy of the expansion) that the FORWARD already sends to the direct-difference kernel.
+    Now the backward splits the same way (compact rows: kv_grad2; wide rows: the direct row-block path); hyper-parameter sums and input
+    gradients on a Student-t-like cloud against float64 autograd (the reference's dense formulas)."""
+    from gpytorch_amd import backend as B
+
+    n, d, t, ls = 12288, 2, 30, 0.5
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(n, d, generator=g, dtype=torch.float64).clamp_(-3.5, 3.5)
+    X = X * (1.0 + 3.0 * (torch.rand(n, 1, generator=g, dtype=torch.float64) < 0.08).double() * torch.rand(n, 1, generator=g, dtype=torch.float64))   # 8 % outliers, up to 4 x
+    Lv = torch.randn(n, t, generator=g, dtype=torch.float64).abs()
+    Rv = torch.randn(n, t, generator=g, dtype=torch.float64).abs()
+    xp = B.prep_points("rbf", X.float().to(dev), torch.tensor([ls]), X.float().to(dev).mean(0))
+    assert B.gram_mode(xp, xp) == 2
+    sv = xp.sorted_view()
+    assert 0 < xp.n - sv.n_compact < 0.25 * n          # there ARE wide rows
+    B.SPLIT_CONTRACTION = split
+    try:
+        out, gz = B.kv_grad2(xp, xp, B.to_probe_major(Lv.float().to(dev)), B.to_probe_major(Rv.float().to(dev)), iso=False, want_gz1=True)
+        out0, _ = B.kv_grad2(xp, xp, B.to_probe_major(Lv.float().to(dev)), B.to_probe_major(Rv.float().to(dev)), iso=True)
+    finally:
+        B.SPLIT_CONTRACTION = None
+    # float64 truth (on the device) on the PREPARED coordinates z: K = 2^-|zi - zj|^2, sum W K, per-dimension sums and d/dz_i
+    z = xp.xp[:, :d].double().requires_grad_(True)
+    z2 = z.detach().clone()
+    S = (z.unsqueeze(1) - z2.unsqueeze(0)).pow(2)
+    K = torch.exp2(-S.sum(-1))
+    W = Lv.to(dev) @ Rv.to(dev).t()
+    tot = (W * K).sum()
+    (gzr,) = torch.autograd.grad(tot, [z])
+    gzr = gzr.cpu()
+    A = (W * K * (-math.log(2.0))).detach()
+    gq = (A.unsqueeze(-1) * S.detach()).sum((0, 1)).cpu()
+    tot = tot.detach().cpu()
+    del S, K, W, A
+    assert abs(float(out[0]) - float(tot)) < 2e-5 * abs(float(tot))
+    assert float((out[1 : 1 + d].double().cpu() - gq).abs().max() / gq.abs().max()) < 2e-5
+    assert abs(float(out0[1]) - float(gq.sum())) < 2e-5 * abs(float(gq.sum()))
+    # every row, the tail rows included (they were the ones outside the accuracy policy)
+    err = (gz.double().cpu() - gzr).norm(dim=1) / gzr.norm(dim=1).clamp_min(1e-12 * float(gzr.norm(dim=1).max()))
+    tail = sv.perm[sv.n_compact :].cpu()
+    assert float(err[tail].max()) < 1e-4, float(err[tail].max())
+    assert float((gz.double().cpu() - gzr).norm() / gzr.norm()) < 2e-5

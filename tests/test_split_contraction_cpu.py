@@ -189,3 +189,54 @@ def test_sorted_view_host_logic():
     grid = torch.stack(torch.meshgrid(*[torch.arange(8.0)] * 3, indexing="ij"), -1).reshape(-1, 3)
     pg = grid[B.hilbert_order(grid, bits=3)]
     assert float((pg[1:] - pg[:-1]).abs().sum(-1).max()) == 1.0
+
+
+def test_round_down_accumulation_leaves_a_floor_that_row_signs_remove():
+    """Round 4 (kv_wsplit.hpp, ws_rowsign): the split W = L^T R contraction in float64 emulation.
+    * accumulation rounded to NEAREST: the error of sum_ij W_ij K_ij is ~1e-11 of sum |W_ij| K_ij -- the algorithm has no floor;
+    * accumulation rounded DOWN (toward -infinity: what the f16 matrix pipe was measured to do): every W_ij is low by ~half an ulp whatever its
+      sign, the error is ~4e-8 of sum |W K| however strongly the signed sum cancels -- the floor seen on the device (0.9 .. 1.5e-8);
+    * the same with row i of L multiplied by a pseudo-random sign s_i before the split and the row sums multiplied by s_i afterwards: the bias
+      becomes a random walk over the rows, >= 10 x smaller at n = 1500 (1 / sqrt(n) of the coherent sum)."""
+    import numpy as np
+
+    rng = np.random.default_rng(0)
+    n = 1500
+    x = rng.random((n, 3))
+    K = np.exp(-0.5 * ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1) / 0.25 ** 2)
+
+    def split(v):
+        s = 2.0 ** (12 - np.ceil(np.log2(np.abs(v).max())))
+        vs = (v * s).astype(np.float32)
+        hi = vs.astype(np.float16)
+        lo = (vs - hi.astype(np.float32)).astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64), s
+
+    def rne(a):
+        return a.astype(np.float32).astype(np.float64)
+
+    def rdn(a):
+        f = a.astype(np.float32)
+        return np.where(f.astype(np.float64) > a, np.nextafter(f, np.float32(-np.inf)), f).astype(np.float64)
+
+    def contract(L, R, rnd):
+        Lh, Ll, sl = split(L)
+        Rh, Rl, sr = split(R)
+        acc = rnd(np.outer(Lh, Rl))               # the kernel's order: the two small products first, then the leading one
+        acc = rnd(acc + np.outer(Ll, Rh))
+        acc = rnd(acc + np.outer(Lh, Rh))
+        return acc / (sl * sr)
+
+    a = rng.standard_normal(n)
+    L, R = -a, a                                   # the data-fit term of the MLL backward: the same vector on both sides
+    Wt = np.outer(L.astype(np.float32).astype(np.float64), R.astype(np.float32).astype(np.float64))
+    mag = (np.abs(Wt) * K).sum()
+    assert mag / abs((Wt * K).sum()) > 50          # a cancelling sum
+    e_rne = abs(((contract(L, R, rne) - Wt) * K).sum()) / mag
+    e_rdn = abs(((contract(L, R, rdn) - Wt) * K).sum()) / mag
+    sgn = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    Wf = contract(L * sgn, R, rdn) * sgn[:, None]  # flipped rows in, signs taken back on the row sums
+    e_flip = abs(((Wf - Wt) * K).sum()) / mag
+    assert e_rne < 2e-9, e_rne
+    assert 1e-8 < e_rdn < 1e-7, e_rdn
+    assert e_flip < 0.1 * e_rdn, (e_flip, e_rdn)
