@@ -446,12 +446,12 @@ def kernel_row_block(x1: PreparedPoints, r0: int, nrows: int, x2: PreparedPoints
     return out
 
 
-FUSED_F64_MAX_DP = 8   # kv_f64.hpp keeps NI * dp doubles of x_i in registers
+FUSED_F64_MAX_DP = 16   # kv_f64.hpp keeps NI * dp doubles of x_i in registers (two row tiles per wave above dp = 8)
 FORCE_CHUNKED = False  # tests: keep float64 products on the row-block path
 
 
 def fused_f64(x1: PreparedPoints, x2: PreparedPoints) -> bool:
-    """float64 clouds with d <= 8: fused generation + float64 MFMA contraction (csrc/kv_f64.hpp)."""
+    """float64 clouds with d <= 16: fused generation + float64 MFMA contraction (csrc/kv_f64.hpp)."""
     return (x1.dtype == torch.float64 and x2.dtype == torch.float64 and x1.dp == x2.dp and x1.dp <= FUSED_F64_MAX_DP
             and not FORCE_CHUNKED)
 

@@ -159,7 +159,7 @@ namespace {
 // column tiles of 16: 1 (t <= 16), 4 (t <= 64), 5 (t <= 80); wider right-hand sides go in groups of 80
 int kv64_ct_for(int t) { return t <= 16 ? 1 : (t <= 64 ? 4 : 5); }
 int kv64_group(int t, int g0) { return (t - g0) <= 80 ? (t - g0) : 80; }
-int kv64_bm(int ct) { return 4 * kv64_ni_for_ct(ct) * 16; }
+int kv64_bm(int ct, int dp) { return 4 * kv64_ni_for(ct, dp) * 16; }
 
 template <int KIND, int DP>
 const void* kv64_ptr_ct(int ct) {
@@ -172,7 +172,13 @@ const void* kv64_ptr_ct(int ct) {
 }
 template <int KIND>
 const void* kv64_ptr_dp(int dp, int ct) {
-  return dp == 4 ? kv64_ptr_ct<KIND, 4>(ct) : (dp == 8 ? kv64_ptr_ct<KIND, 8>(ct) : nullptr);
+  switch (dp) {
+    case 4: return kv64_ptr_ct<KIND, 4>(ct);
+    case 8: return kv64_ptr_ct<KIND, 8>(ct);
+    case 12: return kv64_ptr_ct<KIND, 12>(ct);
+    case 16: return kv64_ptr_ct<KIND, 16>(ct);
+  }
+  return nullptr;
 }
 const void* kv64_ptr(int kind, int dp, int ct) {
   switch (kind) {
@@ -231,9 +237,9 @@ int gpamd_kernel_grad_block_f64(int kind, double kparam, const double* X1p, int6
 
 int gpamd_kv_plan_f64(int n, int m, int dp, int t, int64_t ldo, int* S, int* jchunk, int64_t* workspace_doubles) {
   if (n <= 0 || m <= 0 || t <= 0 || !S || !jchunk || !workspace_doubles || ldo < n) return fail64(GPAMD_EINVAL, "kv_plan_f64: bad arguments");
-  if (dp != 4 && dp != 8) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: fused float64 kernel needs d <= 8 (generic path otherwise)");
+  if (dp != 4 && dp != 8 && dp != 12 && dp != 16) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: fused float64 kernel needs d <= 16 (generic path otherwise)");
   const int ct = kv64_ct_for(t > 80 ? 80 : t);
-  const int nrb = (n + kv64_bm(ct) - 1) / kv64_bm(ct);
+  const int nrb = (n + kv64_bm(ct, dp) - 1) / kv64_bm(ct, dp);
   int s = (3 * 3 * 256 + nrb - 1) / nrb;  // ~3 rounds of 3 resident workgroups on 256 CUs
   const int smax = m / (4 * KV64_BN) > 0 ? m / (4 * KV64_BN) : 1;
   if (s > smax) s = smax;
@@ -249,7 +255,7 @@ int gpamd_kv_partials_f64(int kind, double kparam, const double* X1p, int n, con
                           int t, double* P, int64_t ldo, int S, int jchunk, const int* done, void* stream) {
   if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || S <= 0 || jchunk <= 0 || jchunk % KV64_BN || ldv < m || ldo < n)
     return fail64(GPAMD_EINVAL, "kv_partials_f64: bad shape");
-  if (dp != 4 && dp != 8) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: fused float64 kernel needs d <= 8 (generic path otherwise)");
+  if (dp != 4 && dp != 8 && dp != 12 && dp != 16) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: fused float64 kernel needs d <= 16 (generic path otherwise)");
   for (int g0 = 0; g0 < t;) {
     const int tg = kv64_group(t, g0);
     const int ct = kv64_ct_for(tg);
@@ -260,7 +266,7 @@ int gpamd_kv_partials_f64(int kind, double kparam, const double* X1p, int n, con
     a.ldv = ldv; a.ldo = ldo; a.pstride = (int64_t)t * ldo;
     a.n = n; a.m = m; a.t = tg;
     a.S = S; a.jchunk = jchunk;
-    a.nrb = (n + kv64_bm(ct) - 1) / kv64_bm(ct);
+    a.nrb = (n + kv64_bm(ct, dp) - 1) / kv64_bm(ct, dp);
     a.done = done;
     a.kparam = kparam;
     const void* fn = kv64_ptr(kind, dp, ct);

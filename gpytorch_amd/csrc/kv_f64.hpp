@@ -29,12 +29,13 @@ struct KvArgs64 {
 typedef double f64x4v __attribute__((ext_vector_type(4)));
 
 constexpr int KV64_BN = 64;            // j tile
-constexpr int KV64_LDV = KV64_BN + 2;  // padded LDS row (doubles)
-constexpr int kv64_ni_for_ct(int ct) { return ct >= 4 ? 2 : 4; }  // accumulators: NI * CT * 8 VGPRs
+constexpr int KV64_LDV = KV64_BN + 1;  // padded LDS row (doubles): stride 130 words -> the 16 lanes of an A-operand read hit 32 distinct banks (BN + 2: 2-way conflicts, 38 % of the LDS cycles, profiles/r04_s10_kv_f64_pmc.json)
+// row tiles per wave: accumulators NI * CT * 8 VGPRs + the wave's own points NI * DP * 2 VGPRs (d > 8: two tiles, or the points alone take 128+)
+constexpr int kv64_ni_for(int ct, int dp) { return (ct >= 4 || dp > 8) ? 2 : 4; }
 
 template <int KIND, int DP, int CT>
 __global__ __launch_bounds__(256) void kv_f64_kernel(KvArgs64 a) {
-  constexpr int NI = kv64_ni_for_ct(CT);
+  constexpr int NI = kv64_ni_for(CT, DP);
   constexpr int BN = KV64_BN, LDV = KV64_LDV, TC = 16 * CT;
   __shared__ __attribute__((aligned(16))) double Vs[TC * LDV];
   __shared__ __attribute__((aligned(16))) double Xs[BN * DP];

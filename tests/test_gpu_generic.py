@@ -234,9 +234,12 @@ def test_posterior_generic_path(dtype, d, dev):
 
 
 @pytest.mark.parametrize("kind,d,n,m,t", [("rbf", 3, 700, 433, 1), ("rbf", 3, 1029, 1500, 11), ("matern52", 7, 515, 900, 64),
-                                          ("matern32", 2, 300, 777, 65), ("matern12", 5, 260, 130, 100), ("rbf", 8, 130, 64, 17)])
+                                          ("matern32", 2, 300, 777, 65), ("matern12", 5, 260, 130, 100), ("rbf", 8, 130, 64, 17),
+                                          # round 4: d <= 16 (DP = 12 / 16 instantiations, two row tiles per wave)
+                                          ("rbf", 9, 700, 433, 1), ("matern52", 10, 515, 900, 65), ("rbf", 12, 300, 777, 17),
+                                          ("matern32", 13, 260, 130, 100), ("matern12", 16, 1029, 1500, 11), ("rbf", 16, 130, 64, 64)])
 def test_fused_float64_kernel(kind, d, n, m, t, dev):
-    """kv_f64.hpp (float64 generation on the VALU + v_mfma_f64_16x16x4_f64 contraction, d <= 8) against the float64 oracle
+    """kv_f64.hpp (float64 generation on the VALU + v_mfma_f64_16x16x4_f64 contraction, d <= 16) against the float64 oracle
     (1e-12) and against the row-block x DGEMM path it replaces; ragged shapes, every column-tile variant (16 / 64 / 80)."""
     from gpytorch_amd import backend as B
 
