@@ -326,6 +326,11 @@ def inv_quad_logdet_forward(
         broadcast_(ysol, rhs_owner, group)
         solves_t[t : t + c] = ysol
     logdet = ld_slq + (precond.logdet if precond is not None else 0.0)
+    if (settings.rhs_refinement.on() and owns_rhs and x is not None and x.fused and kv_partials is None and rs is None and group is None
+            and solves_t.dtype == torch.float32):
+        ysol = solves_t[t : t + c].contiguous()
+        refine_solves_(x, scale, sigma2, rhs_t.to(wd), ysol, tolerance, max_iter, precond, dvec)
+        solves_t[t : t + c] = ysol
     inv_quad = B.coldot(solves_t[t : t + c], rhs_t.to(wd), n)
     return InvQuadLogdetResult(inv_quad, logdet, solves_t, zt, znorm, precond, info, ld_slq, owns_rhs)
 
@@ -389,11 +394,34 @@ def structured_opts(opts: dict, device) -> dict:
     return opts
 
 
+def refine_solves_(x: B.PreparedPoints, scale, sigma2, rhs_t, sol_t, tolerance=None, max_iter=None, precond=None, dvec=None, steps=None):
+    """``settings.rhs_refinement``: in-place mixed-precision iterative refinement of float32 solves ``sol_t`` ([c, ld], probe-major) of
+    K_hat X = rhs.  Per step: r = rhs - K_hat sol with ONE fused float64 product on the same prepared points (widened to float64: the operator
+    the float32 kernels approximate), then K_hat d = r by float32 mBCG, sol += d.  Returns the extra CG iterations."""
+    steps = settings.rhs_refinement.steps if steps is None else steps
+    x64 = B.PreparedPoints(x.xp.to(torch.float64), x.n, x.d, x.dp, x.kind, x.param)
+    sc64 = None if scale is None else scale.detach().to(torch.float64)
+    s264 = None if sigma2 is None else sigma2.detach().to(torch.float64)
+    dv64 = None if dvec is None else dvec.to(torch.float64)
+    extra = 0
+    for _ in range(int(steps)):
+        a64 = sol_t.to(torch.float64)
+        ka = B.kv(x64, x64, a64, scale=sc64, dscale=s264, vd=a64, dvec=dv64)           # K_hat a, float64 (csrc/kv_f64.hpp for d <= 16)
+        r = (rhs_t.to(torch.float64) - ka).to(torch.float32).contiguous()
+        delta, info = linear_cg(x, scale, sigma2, r, n_tridiag=0, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, dvec=dvec)
+        sol_t += delta
+        extra += info.iterations
+    return extra
+
+
 def solve(x: B.PreparedPoints, scale, sigma2, rhs_t, tolerance=None, max_iter=None, precond="auto"):
     """K_hat^-1 rhs by preconditioned mBCG (``LinearOperator.solve`` on the CG branch, A.1)."""
     if precond == "auto":
         precond = build_preconditioner(x, scale, sigma2)
-    return linear_cg(x, scale, sigma2, rhs_t, n_tridiag=0, tolerance=tolerance, max_iter=max_iter, preconditioner=precond)
+    sol, info = linear_cg(x, scale, sigma2, rhs_t, n_tridiag=0, tolerance=tolerance, max_iter=max_iter, preconditioner=precond)
+    if settings.rhs_refinement.on() and x is not None and x.fused and sol.dtype == torch.float32 and rhs_t.shape[0] <= 4:
+        refine_solves_(x, scale, sigma2, rhs_t, sol, tolerance, max_iter, precond)       # (few columns: the mean-cache solve, not the 1000-column variance solves)
+    return sol, info
 
 
 LOG_2PI = math.log(2 * math.pi)

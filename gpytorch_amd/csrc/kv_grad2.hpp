@@ -230,11 +230,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       if (j < jend) sub_center<DP>(zreg, cz);
       gram_pack_a<D>(zreg, j < jend, Xh, tid, BN);
       if constexpr (MODE == 1) {
-        Zs[tid] = j < jend ? 1.f : 0.f;
+        // WSPLIT: the W tile of this row's 32-row block carries the block sign s_J (kv_wsplit.hpp); the columns it is contracted against take it back
+        const float sj = WSPLIT ? ws_blocksign(j >> 5) : 1.f;
+        Zs[tid] = j < jend ? sj : 0.f;
 #pragma unroll
         for (int q = 0; q < D; ++q) {
-          Zs[(1 + q) * LDZ + tid] = zreg[q];
-          Zs[(1 + D + q) * LDZ + tid] = zreg[q] * zreg[q];
+          Zs[(1 + q) * LDZ + tid] = zreg[q] * sj;
+          Zs[(1 + D + q) * LDZ + tid] = zreg[q] * zreg[q] * sj;
         }
       }
     }
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     for (int gz = 0; gz < GZ; ++gz) zacc[gz] = (f32x4)(0.f);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      float fh0 = 0.f, fh1 = 0.f, fh2 = 0.f;   // this 32-row j block alone: WSPLIT un-flips its block sign below
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         f32x4 zv[GZ];
@@ -314,23 +317,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             // dk/ds = -ln2 k: accumulate with A' = W k and apply -ln2 once per step (RBF_DK); a slightly negative S (cancellation)
             // needs no clamp for 2^-S.  3 VALU ops + v_exp_f32 per pair instead of 6.
             av = w * __builtin_amdgcn_exp2f(-sv);
-            f0 += av;
+            fh0 += av;
           } else {
             sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
             float kv, dk, dpar;
             cov_and_dcov<KIND>(sv, a.kparam, kv, dk, dpar);
-            f0 = __builtin_fmaf(w, kv, f0);
-            if constexpr (KIND == KIND_RQ) f2 = __builtin_fmaf(w, dpar, f2);
+            fh0 = __builtin_fmaf(w, kv, fh0);
+            if constexpr (KIND == KIND_RQ) fh2 = __builtin_fmaf(w, dpar, fh2);
             av = w * dk;
           }
           if constexpr (MODE == 0) {
-            f1 = __builtin_fmaf(av, sv, f1);
+            fh1 = __builtin_fmaf(av, sv, fh1);
           } else {
 #pragma unroll
             for (int gz = 0; gz < GZ; ++gz) zacc[gz] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv[gz][e], av, zacc[gz], 0, 0, 0);
           }
         }
       }
+      const float sh = WSPLIT ? ws_blocksign((j0 >> 5) + half) : 1.f;   // wave-uniform
+      f0 = __builtin_fmaf(sh, fh0, f0);
+      f1 = __builtin_fmaf(sh, fh1, f1);
+      f2 = __builtin_fmaf(sh, fh2, f2);
     }
     if constexpr (MODE == 1) mfma_result_fence(zacc);   // zacc (4x4x1 MFMA results in VGPRs) is read next
     constexpr float RBF_DK = KIND == KIND_RBF ? -0.6931471805599453f : 1.0f;   // see the consume loop

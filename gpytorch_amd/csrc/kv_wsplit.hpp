@@ -31,6 +31,10 @@ __host__ __device__ __forceinline__ float ws_rowsign(int i) {
   h ^= h >> 15;
   return (h & 0x10000u) ? -1.0f : 1.0f;
 }
+// ... and 32-row block J of the RIGHT block by an independent sign s_J (a second hash stream): the bias becomes -s_i s_J b_ij, a random walk over
+// n * n / 32 (row, block) pairs.  The kernel un-flips per half step (its two 32-row j blocks have wave-uniform signs) and, for the per-dimension
+// sums, by staging the [1 | z_j | z_j^2] columns of the A-contraction with the sign already applied.
+__host__ __device__ __forceinline__ float ws_blocksign(int J) { return ws_rowsign((int)(0x40000000u | (unsigned)J)); }
 
 // colmax[c] = bits of max_j |V[c][j]| (non-negative floats order like unsigned integers); zeroed by the caller.  (Templates: the header is
 // included by more than one translation unit.)
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void wsplit_planes_kernel(const float* __restr
   const int row = blockIdx.x * 256 + threadIdx.x;
   const int ck = blockIdx.y;   // chunk of 8 columns
   if (row >= rows_pad) return;
-  const float sgn = flip ? ws_rowsign(row) : 1.0f;   // left block: pseudo-random row signs (see ws_rowsign)
+  const float sgn = flip == 1 ? ws_rowsign(row) : (flip == 2 ? ws_blocksign(row >> 5) : 1.0f);   // left block: row signs; right block: 32-row block signs
   f16x8 hi, lo;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {

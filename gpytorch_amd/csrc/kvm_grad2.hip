@@ -211,7 +211,7 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
       hipLaunchKernelGGL(wsplit_planes_kernel<0>, dim3((unsigned)((npad + 255) / 256), WS_CP / 8), dim3(256), 0, st, a.Lt, ldl, n, (int)npad, tg,
                          (const float*)scales, Lh, Ll, 1);
       hipLaunchKernelGGL(wsplit_planes_kernel<0>, dim3((unsigned)((mpad + 255) / 256), WS_CP / 8), dim3(256), 0, st, a.Rt, ldr, m, (int)mpad, tg,
-                         (const float*)(scales + WS_CP), Rh, Rl, 0);
+                         (const float*)(scales + WS_CP), Rh, Rl, 2);
       a.Lh = Lh; a.Ll = Ll; a.Rh = Rh; a.Rl = Rl;
       a.wscale = scales + 2 * WS_CP;
       const int kid = kind == GPAMD_RBF ? KIND_RBF : (kind == GPAMD_MATERN32 ? KIND_MATERN32 : (kind == GPAMD_MATERN52 ? KIND_MATERN52 : KIND_RQ));

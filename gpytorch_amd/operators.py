@@ -778,6 +778,11 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
                 tolerance=settings.cg_tolerance.value(), preconditioner=self._cache["precond"], dvec=self._dvec(),
             )
             self._cache["last_cg_info"] = info
+            if settings.rhs_refinement.on() and p1.fused and sol_t.dtype == torch.float32 and r.shape[-1] <= 4:
+                from .bbmm import refine_solves_   # (few columns: the mean cache; not the 1000-column variance solves)
+
+                refine_solves_(p1, self.kernel_op._os(), self._nz(), B.to_probe_major(r.detach(), p1.dtype), sol_t, settings.cg_tolerance.value(), None,
+                               self._cache["precond"], self._dvec())
             sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
         if lhs is not None:
             sol = lhs @ sol
@@ -925,6 +930,10 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         sol_t, info = linear_cg(p1, os_, nz, B.to_probe_major(r.detach(), p1.dtype), n_tridiag=0, tolerance=settings.cg_tolerance.value(),
                                 preconditioner=self._cache["precond"], dvec=dv, kv_partials=hook)
         self._cache["last_cg_info"] = info
+        if settings.rhs_refinement.on() and p1.fused and sol_t.dtype == torch.float32:
+            from .bbmm import refine_solves_
+
+            refine_solves_(p1, os_, nz, B.to_probe_major(r.detach(), p1.dtype), sol_t, settings.cg_tolerance.value(), None, self._cache["precond"], dv)
         while state["result"] is None:        # CG finished first: the remaining Lanczos steps on one-column products
             q = state["q"]
             feed(B.kv(p1, p1, q, scale=os_, dscale=nz, vd=q, dvec=dv))

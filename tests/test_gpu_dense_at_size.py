@@ -130,7 +130,7 @@ def test_c3_shape_mll_ingredients_vs_dense_cholesky(dev):
 # ---- round 4: the predictive posterior at the same sizes ------------------------------------------------------------------------------
 def run_posterior_case(name, kind, n, d, ls, dev, ns=1000,
                        configs=((15, 0.01, False, 100), (15, 0.01, True, 100), (100, 1e-4, False, 100), (100, 1e-4, True, 100), (100, 1e-4, True, 400),
-                                (100, 1e-4, True, 1600))):
+                                (100, 1e-4, True, 1600), (15, 0.01, True, 400, True))):
     """Predictive mean / variance of f at ``ns`` test points through the model API (``ExactGP.__call__`` in eval mode ->
     ``DefaultPredictionStrategy``: mean cache by mBCG, exact variance by a 1000-column solve, LOVE variance from the Lanczos root) against
     ``K_*X K_hat^-1 y`` and ``diag(K_** - K_*X K_hat^-1 K_X*)`` from the dense float64 factor.  Mirrors
@@ -157,7 +157,9 @@ def run_posterior_case(name, kind, n, d, ls, dev, ns=1000,
     runs = []
     # (preconditioner rank, eval_cg_tolerance, fast_pred_var, max_root_decomposition_size): the reference defaults first, then a tight solve and
     # LOVE at growing Lanczos rank
-    for rank, tol, fast, love_rank in configs:
+    for cfg in configs:
+        rank, tol, fast, love_rank = cfg[:4]
+        refine = len(cfg) > 4 and cfg[4]          # settings.rhs_refinement: float64 residual replacement for the mean-cache solve
         if True:
             if True:
                 _, m, lik = _model(kind, X, y, ls, theta, s2v, dev, mean=0.0)   # a fresh model: cold caches
@@ -166,13 +168,13 @@ def run_posterior_case(name, kind, n, d, ls, dev, ns=1000,
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(tol), S.fast_pred_var(fast), S.max_preconditioner_size(rank), \
-                        S.max_root_decomposition_size(love_rank), S.max_cg_iterations(6000):
+                        S.max_root_decomposition_size(love_rank), S.max_cg_iterations(6000), S.rhs_refinement(refine):
                     pred = m(Xsd)
                     mu, var = pred.mean.double().cpu(), pred.variance.double().cpu()
                 torch.cuda.synchronize(dev)
                 sec = time.perf_counter() - t0
                 runs.append({
-                    "precond_rank": rank, "eval_cg_tolerance": tol, "fast_pred_var": fast, "love_rank": love_rank if fast else None, "seconds": sec,
+                    "precond_rank": rank, "eval_cg_tolerance": tol, "fast_pred_var": fast, "love_rank": love_rank if fast else None, "rhs_refinement": bool(refine), "seconds": sec,
                     "mean_rel_err": float((mu - mean_ref).norm() / mean_ref.norm()),
                     "mean_max_abs_err": float((mu - mean_ref).abs().max()),
                     "var_max_rel_err": float(((var - var_ref).abs() / var_ref).max()),
@@ -201,13 +203,14 @@ def _check_posterior(log, love_rank_ok=None):
             else:
                 love.append((r["love_rank"], r["var_max_err_over_noise"]))
         else:
-            # the reference's default eval tolerance (0.01 on the normalised residual) is not a 1e-3 solve: recorded, bounded loosely
-            assert r["mean_rel_err"] < 2e-2, (tag, r["mean_rel_err"])
+            # the reference's default eval tolerance (0.01 on the normalised residual) is not a 1e-3 solve: recorded, bounded loosely; one step of
+            # settings.rhs_refinement at the SAME tolerance squares the accuracy of the mean
+            assert r["mean_rel_err"] < (1e-3 if r["rhs_refinement"] else 2e-2), (tag, r["mean_rel_err"])
     # LOVE is a rank-k Krylov approximation of K_hat^-1: its error is the ALGORITHM's and falls with the rank (max_root_decomposition_size, reference
     # default 100).  The reference's own criterion -- variance error within 5 % of the noise, test_simple_gp_regression.py:436-442 -- from the
     # rank given (C2: 400; the Matern d = 10 problem does not get there by rank 1600 -- recorded, and asserted to improve monotonically)
     love.sort()
-    assert all(b[1] <= a[1] * 1.05 for a, b in zip(love, love[1:])), love
+    assert all(b[1] <= max(a[1] * 1.05, 1e-3) for a, b in zip(love, love[1:])), love     # (1e-3 of the noise: the float32 floor of the variance itself)
     if love_rank_ok is not None:
         assert all(err < 0.05 for rank, err in love if rank >= love_rank_ok), love
 
