@@ -140,8 +140,17 @@ __device__ __forceinline__ void gram_pack_a_lane(const float* z, bool valid, int
     }
 }
 
-// A operands of one contracted row, written to LDS planes Xh[kh][row][16]  (row stride 32 B: the 64 lanes of a wave
-// read 1 KB contiguous -> conflict-free ds_read_b128)
+// A operands of one contracted row in LDS: planes Xh[kh][k-half][row][8] -- the 16-byte operand of lane (row, h) of k-step kh sits at
+// gram_a_off(kh, row, h, BN).  Consecutive rows are 16 bytes apart, so the staging stores of consecutive threads AND the operand reads of
+// consecutive lanes are both contiguous (conflict-free ds_write_b128 / ds_read_b128).  Rounds 1-3 used [kh][row][16] (row stride 32 bytes): the
+// reads were contiguous over the wave, but the two 16-byte stores of a staging thread hit every other 16-byte slot -- 2-way bank conflicts that
+// showed as 21 % / 17 % of the LDS cycles of the few-column kernels (profiles/r04_r4s11_kv_pmc_split_t1.json), whose tiles carry little else.
+#ifdef GPAMD_XH_OLD_LAYOUT   // A/B builds only (scripts/kv_layout_ab.py): the [kh][row][16] image of rounds 1-3
+__device__ __forceinline__ constexpr int gram_a_off(int kh, int row, int h, int BN) { return (kh * BN + row) * 16 + 8 * h; }
+#else
+__device__ __forceinline__ constexpr int gram_a_off(int kh, int row, int h, int BN) { return ((kh * 2 + h) * BN + row) * 8; }
+#endif
+
 template <int D>
 __device__ __forceinline__ void gram_pack_a(const float* z, bool valid, _Float16* Xh, int row, int BN) {
   constexpr int KH = GramF16<D>::KH;
@@ -161,7 +170,7 @@ __device__ __forceinline__ void gram_pack_a(const float* z, bool valid, _Float16
       f16x8 v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gram_slot_a<D>(kh * 16 + 8 * hh + e, zh, zl, nh, nl, one);
-      *reinterpret_cast<f16x8*>(&Xh[((kh * BN) + row) * 16 + 8 * hh]) = v;
+      *reinterpret_cast<f16x8*>(&Xh[gram_a_off(kh, row, hh, BN)]) = v;
     }
 }
 

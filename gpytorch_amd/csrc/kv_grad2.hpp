@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
     for (int kh = 0; kh < KH; ++kh) {
-      const f16x8 a0 = *reinterpret_cast<const f16x8*>(&Xh[(kh * BN + l31) * 16 + 8 * h]);
-      const f16x8 a1 = *reinterpret_cast<const f16x8*>(&Xh[(kh * BN + 32 + l31) * 16 + 8 * h]);
+      const f16x8 a0 = *reinterpret_cast<const f16x8*>(&Xh[gram_a_off(kh, l31, h, BN)]);
+      const f16x8 a1 = *reinterpret_cast<const f16x8*>(&Xh[gram_a_off(kh, 32 + l31, h, BN)]);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[kh], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[kh], s1, 0, 0, 0);
     }

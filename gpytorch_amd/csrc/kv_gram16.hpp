@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GramF16<D>
         for (int r = 0; r < 16; ++r) kk[ni][r] = 0.f;
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) {
-        const f16x8 aq = *reinterpret_cast<const f16x8*>(&Xh[(kh * BN + jb + l31) * 16 + 8 * h]);
+        const f16x8 aq = *reinterpret_cast<const f16x8*>(&Xh[gram_a_off(kh, jb + l31, h, BN)]);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) kk[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq[ni][kh], kk[ni], 0, 0, 0);
       }

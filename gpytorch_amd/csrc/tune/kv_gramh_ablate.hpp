@@ -150,7 +150,7 @@ void kv_gramh_ablate_kernel(KvhArgs ka) {
 
   auto load_aq = [&](int buf, int jb, f16x8* aq) {
 #pragma unroll
-    for (int kh = 0; kh < KH; ++kh) aq[kh] = *reinterpret_cast<const f16x8*>(&Xh[buf * XHS + (kh * BN + jb + l31) * 16 + 8 * h]);
+    for (int kh = 0; kh < KH; ++kh) aq[kh] = *reinterpret_cast<const f16x8*>(&Xh[buf * XHS + gram_a_off(kh, jb + l31, h, BN)]);
   };
   auto gram = [&](const f16x8* aq, int ni) -> f32x16 {
     f32x16 kk;
