@@ -38,6 +38,31 @@ __device__ __forceinline__ float cov_from_sq(float s, float p = 0.f) {
   }
 }
 
+// The same for TWO squared distances at once (Gram-form kernels: S comes from the matrix pipe, possibly a few 1e-6 below zero).  Everything
+// but the transcendentals runs on the packed-f32 pipe (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two elements per instruction at the issue
+// cost of one), and the clamp of S is a |.| source modifier of v_sqrt_f32 instead of a v_med3_f32 per element: Matern-5/2 2 VALU + 2 transcendental
+// instructions per element instead of 5 + 2 (round 4; the split kernel at C3's shape was VALU-bound: 7 VALU + 2 transcendental per element against
+// 13-15 MFMAs per 32 x 32 block).  `shift` is added to the exponent (kv_gramh.hpp generates 2^12 K).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__device__ __forceinline__ f32x2 cov_pair_from_sq(f32x2 s, float p = 0.f, float shift = 0.f) {
+  if constexpr (KIND == KIND_RBF) {
+    return (f32x2){__builtin_amdgcn_exp2f(shift - s[0]), __builtin_amdgcn_exp2f(shift - s[1])};
+  } else if constexpr (KIND == KIND_RQ) {
+    const f32x2 u = s + 1.0f;   // (a slightly negative s only moves 1 + s by 1e-6)
+    const f32x2 l2 = {__builtin_amdgcn_logf(u[0]), __builtin_amdgcn_logf(u[1])};
+    const f32x2 t = __builtin_elementwise_fma(l2, (f32x2)(-p), (f32x2)(shift));
+    return (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  } else {
+    const f32x2 r = {__builtin_amdgcn_sqrtf(__builtin_fabsf(s[0])), __builtin_amdgcn_sqrtf(__builtin_fabsf(s[1]))};
+    const f32x2 t = __builtin_elementwise_fma(r, (f32x2)(-LOG2E), (f32x2)(shift));
+    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    if constexpr (KIND == KIND_MATERN12) return e;
+    if constexpr (KIND == KIND_MATERN32) return (r + 1.0f) * e;
+    return __builtin_elementwise_fma(s, (f32x2)(1.0f / 3.0f), r + 1.0f) * e;
+  }
+}
+
 // d k / d s (derivative wrt the squared scaled distance), used by the gradient kernels:
 //   RBF: k = exp2(-s) = exp(-s ln2)      -> dk/ds = -ln2 * k
 //   Matern: with r = sqrt(s): dk/ds = k'(r) / (2 r)

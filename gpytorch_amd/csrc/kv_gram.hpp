@@ -173,12 +173,12 @@ void kv_gram_kernel(KvArgs a) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // RBF: a slightly negative S (cancellation) only makes k = 2^-S exceed 1 by <= 1e-5 -- no clamp needed;
-          // Matern takes sqrt(S): clamp with one v_med3_f32
-          float sv = kk[ni][r];
-          if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-          kk[ni][r] = cov_from_sq<KIND>(sv, a.kparam);
+        for (int r = 0; r < 16; r += 2) {
+          // RBF: a slightly negative S (cancellation) only makes k = 2^-S exceed 1 by <= 1e-5 -- no clamp needed; Matern takes sqrt(|S|).
+          // Two elements per call: the arithmetic around the transcendentals runs on the packed-f32 pipe (common.hpp cov_pair_from_sq)
+          const f32x2 k2 = cov_pair_from_sq<KIND>((f32x2){kk[ni][r], kk[ni][r + 1]}, a.kparam);
+          kk[ni][r] = k2[0];
+          kk[ni][r + 1] = k2[1];
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -127,10 +127,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GramF16<D>
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float sv = kk[ni][r];
-          if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-          kk[ni][r] = cov_from_sq<KIND>(sv, a.kparam);
+        for (int r = 0; r < 16; r += 2) {   // pair form (common.hpp cov_pair_from_sq): packed-f32 arithmetic around the transcendentals
+          const f32x2 k2 = cov_pair_from_sq<KIND>((f32x2){kk[ni][r], kk[ni][r + 1]}, a.kparam);
+          kk[ni][r] = k2[0];
+          kk[ni][r + 1] = k2[1];
         }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

@@ -128,14 +128,16 @@ __global__ __launch_bounds__(256) void kv_gram4_kernel(KvArgs a) {
 #pragma unroll
         for (int g = 0; g < G; ++g) av[g] = *reinterpret_cast<const f32x4*>(&Vs[(4 * g + l3) * LDT + jl]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; e += 2)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            float sv = kk[ni][4 * q + e];
-            if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-            const float kv = cov_from_sq<KIND>(sv, a.kparam);
+            // pair form (common.hpp cov_pair_from_sq): packed-f32 arithmetic around the transcendentals
+            const f32x2 kv = cov_pair_from_sq<KIND>((f32x2){kk[ni][4 * q + e], kk[ni][4 * q + e + 1]}, a.kparam);
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[ni][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][e], kv, acc[ni][g], 0, 0, 0);
+            for (int g = 0; g < G; ++g) {
+              acc[ni][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][e], kv[0], acc[ni][g], 0, 0, 0);
+              acc[ni][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][e + 1], kv[1], acc[ni][g], 0, 0, 0);
+            }
           }
       }
     }

@@ -196,17 +196,13 @@ void kv_gramh_kernel(KvhArgs ka) {
   // Generation of elements r = 8 mf + 2 p, + 1 of a step in two halves of three VALU instructions each:
   //   gen_a: K = f(S) for both (2 v_exp_f32), packed hi word (v_cvt_pkrtz)      gen_b: lo = K - hi (2 v_fma_mix), packed lo word
   // the extra column's two multiply-adds ride in gen_a as one v_pk_fma_f32.
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 eacc2[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) eacc2[ni] = (f32x2)(0.f);
   auto gen_a = [&](const f32x16& kk, int mf, int p, const f32x4* ev, int ni, f32x2& kv, u32x4& bh) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      float sv = kk[8 * mf + 2 * p + e];
-      if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
-      kv[e] = cov_scaled<KIND>(sv, a.kparam);
-    }
+    // both elements at once: packed-f32 arithmetic around the transcendentals (common.hpp cov_pair_from_sq); RBF: the 2^KSHIFT scale is already
+    // inside S (gram_pack_b's nshift), the other families add it to the exponent
+    kv = cov_pair_from_sq<KIND>((f32x2){kk[8 * mf + 2 * p], kk[8 * mf + 2 * p + 1]}, a.kparam, KIND == KIND_RBF ? 0.f : (float)KGH_KSHIFT);
     if constexpr (EX) {
       // rows j(r, h) = (r & 3) + 8 (r >> 2) + 4 h, r = 8 mf + 2 p + e: ev[p >> 1] holds rows 16 mf + 8 (p >> 1) + 4 h .. + 3
       const f32x2 e2 = {ev[p >> 1][2 * (p & 1)], ev[p >> 1][2 * (p & 1) + 1]};

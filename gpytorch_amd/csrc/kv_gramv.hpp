@@ -105,12 +105,8 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
             const f32x2 vv = {v4[e], v4[e + 1]};
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              float s0 = kk[ni][4 * g + e], s1 = kk[ni][4 * g + e + 1];
-              if constexpr (KIND != KIND_RBF) {
-                s0 = __builtin_amdgcn_fmed3f(s0, 0.f, 3.0e38f);
-                s1 = __builtin_amdgcn_fmed3f(s1, 0.f, 3.0e38f);
-              }
-              const f32x2 kv = {cov_from_sq<KIND>(s0, a.kparam), cov_from_sq<KIND>(s1, a.kparam)};
+              // (pair form: packed-f32 arithmetic around the transcendentals, |S| as a source modifier of v_sqrt_f32 -- common.hpp)
+              const f32x2 kv = cov_pair_from_sq<KIND>((f32x2){kk[ni][4 * g + e], kk[ni][4 * g + e + 1]}, a.kparam);
               acc2[ni][0] = __builtin_elementwise_fma(kv, vv, acc2[ni][0]);
             }
           }
@@ -123,7 +119,7 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
               float sv = kk[ni][4 * g + e];
-              if constexpr (KIND != KIND_RBF) sv = __builtin_amdgcn_fmed3f(sv, 0.f, 3.0e38f);
+              if constexpr (KIND != KIND_RBF) sv = __builtin_fabsf(sv);   // (|S|: a source modifier of v_sqrt_f32 / harmless for 1 + s; no v_med3_f32)
               const f32x2 kv = (f32x2)(cov_from_sq<KIND>(sv, a.kparam));
 #pragma unroll
               for (int c = 0; c < TP; ++c) acc2[ni][c] = __builtin_elementwise_fma(kv, vp[c], acc2[ni][c]);
