@@ -283,6 +283,16 @@ def self_launch(n_ranks: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def make_grid_groups(world: int, rank: int, P: int, R: int):
+    """--grid PxR: P probe shares x R row blocks, rank = p * R + r.  Returns (probe group of this rank = the P ranks with its r -- stopping rule,
+    SLQ sums --, row group = the R ranks with its p -- all-gather of the search directions, inner products).  ``new_group`` is collective:
+    every rank creates every group, in the same order."""
+    assert P * R == world, f"--grid {P}x{R} needs {P * R} ranks, have {world}"
+    pgs = [torch.distributed.new_group([p * R + r for p in range(P)]) for r in range(R)]
+    rgs = [torch.distributed.new_group([p * R + r for r in range(R)]) for p in range(P)]
+    return pgs[rank % R], rgs[rank // R]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -337,11 +347,24 @@ def main():
             tt = torch.tensor([float(rank + 1)])
             torch.distributed.all_reduce(tt)
             tot = float(tt.item())
+            grid = None
+            if args.grid:   # the subgroups of the 2-D split, exercised over gloo: sums of (rank + 1) over this rank's probe group and row group
+                P_, R_ = (int(v) for v in args.grid.lower().split("x"))
+                pg, rg = make_grid_groups(world, rank, P_, R_)
+                a, b = torch.tensor([float(rank + 1)]), torch.tensor([float(rank + 1)])
+                torch.distributed.all_reduce(a, group=pg)
+                torch.distributed.all_reduce(b, group=rg)
+                allv = [None] * world
+                torch.distributed.all_gather_object(allv, (rank, float(a.item()), float(b.item())))
+                grid = sorted(allv)
             torch.distributed.destroy_process_group()
         else:
-            tot = 1.0
+            tot, grid = 1.0, None
         if rank == 0:
-            print(json.dumps({"launched": world, "rank_sum": tot, "n_gpus": args.gpus}), flush=True)
+            rec = {"launched": world, "rank_sum": tot, "n_gpus": args.gpus}
+            if grid is not None:
+                rec["grid_sums"] = grid
+            print(json.dumps(rec), flush=True)
         return 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -364,10 +387,8 @@ def main():
         P_, R_ = (int(v) for v in args.grid.lower().split("x"))
         assert P_ * R_ == world, f"--grid {args.grid} needs {P_ * R_} ranks, have {world}"
         if R_ > 1:
-            pgs = [torch.distributed.new_group([p * R_ + r for p in range(P_)]) for r in range(R_)]
-            rgs = [torch.distributed.new_group([p * R_ + r for r in range(R_)]) for p in range(P_)]
-            group = pgs[rank % R_] if P_ > 1 else None
-            row_group = rgs[rank // R_]
+            pg, row_group = make_grid_groups(world, rank, P_, R_)
+            group = pg if P_ > 1 else None
     p_idx = rank // R_          # index of this rank's probe share
 
     from gpytorch_amd import backend as B

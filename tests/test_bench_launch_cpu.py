@@ -9,10 +9,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n):
+def _run(n, extra=()):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(GPAMD_BENCH_LAUNCH_ONLY="1", OMP_NUM_THREADS="1")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", *extra], env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -27,3 +27,12 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_present():
 
 def test_bench_single_rank_needs_no_launcher():
     assert _run(1)["launched"] == 1
+
+
+def test_grid_subgroups_of_the_two_dimensional_split():
+    """`--grid 2x2` on 4 ranks (rank = p * 2 + r): the probe group of a rank is {r, 2 + r}, its row group {2 p, 2 p + 1} -- checked by
+    all-reducing (rank + 1) inside each subgroup over gloo."""
+    rec = _run(4, ("--config", "c4", "--grid", "2x2"))
+    assert rec["launched"] == 4
+    want = [[0, 1.0 + 3.0, 1.0 + 2.0], [1, 2.0 + 4.0, 1.0 + 2.0], [2, 1.0 + 3.0, 3.0 + 4.0], [3, 2.0 + 4.0, 3.0 + 4.0]]
+    assert [list(x) for x in rec["grid_sums"]] == want
