@@ -125,8 +125,15 @@ def members_stackable(ops) -> bool:
     if len(ops) < 2 or settings.batched_small_members.off():
         return False
     o0 = ops[0]
-    if type(o0) is not FusedKernelAddedDiagLinearOperator or not o0._use_cholesky(settings.fast_computations.log_prob):
+    if type(o0) is not FusedKernelAddedDiagLinearOperator:
         return False
+    if not o0._use_cholesky(settings.fast_computations.log_prob):
+        # mid-size members (settings.batched_small_members.max_size): stacked dense evaluation instead of one BBMM evaluation per member,
+        # as long as the float64 [b, n, n] work arrays (covariances, factors, inverse) fit the budget
+        n = o0.shape[-1]
+        if not (n <= settings.batched_small_members.max_size and 3.0 * 8.0 * len(ops) * n * n <= settings.batched_small_members.max_bytes
+                and settings.max_cholesky_size.value() >= 800 and settings.fast_computations.log_prob.on()):
+            return False   # (a max_cholesky_size LOWERED by the user -- e.g. 0 to force mBCG -- is respected)
     k0 = o0.kernel_op
     if B.work_dtype(k0.x1) != torch.float32 or k0.x1.shape[-1] > B.MAX_INPUT_DIM or not k0.x1.is_cuda:
         return False

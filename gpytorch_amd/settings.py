@@ -298,8 +298,16 @@ class batched_small_members(_feature_flag):
     members are factorised (``n <= max_cholesky_size``) evaluates its marginal log likelihood with a launch count that does not depend
     on the batch size: ONE launch generates every member's dense covariance matrix, the factorisation / solves are torch's batched
     Cholesky, ONE launch reduces every member's kernel derivative (``gpytorch_amd/batched.py``, ``csrc/extra_batch.hip``).
-    ``batched_small_members(False)`` keeps the launch plan over members (one Cholesky branch per member)."""
+    ``batched_small_members(False)`` keeps the launch plan over members (one Cholesky branch per member).
+    Round 4: the stacked (exact, dense) evaluation also takes batches of MID-SIZE members -- ``max_cholesky_size < n <= max_size`` while the three
+    float64 [b, n, n] work arrays stay within ``max_bytes`` -- which would otherwise run one BBMM evaluation per member: measured on MI355X
+    (``profiles/r04_s18_batch_member_timing.json``, MLL + backward) 64 x 1000 points 137 -> 15.8 ms, 64 x 2000 237 -> 54 ms, break-even at
+    n = 4000 (318 vs 302 ms).  The member loop is launch-bound there (about 2 ms per member whatever its size up to 2000 points); the dense
+    factorisation is exact where mBCG + SLQ would be stochastic, so values only get MORE accurate.  ``max_size = 0`` restores the round-3 reach; a
+    ``max_cholesky_size`` set BELOW its default (e.g. 0, to force mBCG) switches the extension off as well."""
     _default = True
+    max_size = 3000
+    max_bytes = 48e9
 
 
 class split_contraction(_feature_flag):
