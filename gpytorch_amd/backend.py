@@ -644,7 +644,7 @@ def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.
 
 FORCE_GRAD_DIRECT = False  # tests: keep the bilinear derivative on the direct-difference kernel (kv_grad.hpp)
 GRAD_SPLIT_MIN_COLS = 24   # backward: columns from which W = L^T R runs on hi/lo-split f16 operands (kv_grad2 below)
-GRAD_SPLIT_MAX_ARD_DIM = 6  # ... in the per-dimension mode (ARD / input gradients) up to this many dimensions (beyond it the 40 L-operand registers of the split form spill)
+GRAD_SPLIT_MAX_ARD_DIM = 16  # ... in the per-dimension mode (ARD / input gradients) up to this many dimensions (tuning knob: 6 sends d > 6 back to the fp32 W contraction)
 
 
 def grad_gram_ok(x1: PreparedPoints, x2: PreparedPoints) -> bool:
@@ -711,10 +711,10 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
     # to 1e-10 of sum |W dK| where the f16 accumulation leaves a 1.5e-8 floor (measured: profiles/r03_s15_grad_split_error_floor.txt; it only
     # shows where the sum cancels by > 1e4, e.g. the gradient of a few-column solve).  The per-dimension mode keeps 40 more registers live and
     # spills from d = 8 on: those shapes stay on the fp32-MFMA contraction too
-    # per-dimension mode beyond GRAD_SPLIT_MAX_ARD_DIM dimensions: the split form spills (44 .. 182 VGPRs at two waves per SIMD).  Measured at
-    # n = 500 000, 65 columns (profiles/r04_s15_grad_ard_highdim.json): RBF still gains (d = 8: 466 vs 552 ms, d = 16: 1285 vs 1543 ms -- its consume
-    # phase is one v_exp_f32 per pair), Matern-5/2 loses (d = 10: 921 vs 635 ms)
-    split = _split_on() and t >= GRAD_SPLIT_MIN_COLS and (x1.d <= GRAD_SPLIT_MAX_ARD_DIM or (iso and not want_gz1) or x1.kind == "rbf")
+    # the per-dimension mode beyond 6 dimensions runs the split form at ONE wave per SIMD (kv_grad2.hpp g2_waves: its registers do not fit two),
+    # spill-free: n = 500 000, 65 columns (profiles/r04_s20_grad_ard_highdim_one_wave.json) Matern-5/2 d = 10 483 ms (fp32 W 634, the spilling
+    # two-wave build 921), RBF d = 8 338 (552), d = 16 465 (1543)
+    split = _split_on() and t >= GRAD_SPLIT_MIN_COLS and (x1.d <= GRAD_SPLIT_MAX_ARD_DIM or (iso and not want_gz1))
     sws, ns = None, 0
     if split:
         ns = int(L.gpamd_kv_grad2_split_workspace_floats(n_rows, x2.n))

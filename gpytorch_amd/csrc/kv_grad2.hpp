@@ -86,8 +86,13 @@ __device__ __forceinline__ void cov_and_dcov(float s, float p, float& k, float& 
 }
 
 // MODE 0: one lengthscale, no input gradients (VALU: sum A S).   MODE 1: per-dimension sums + optional input gradients.
+// (per-dimension mode of the split form beyond 6 dimensions: its registers -- 40 for the L planes, 16-36 for the [1 | z | z^2] accumulators
+// and operands -- do not fit two waves per SIMD; G2_WAVES = 1 lets the allocator use the whole file instead of spilling 44-182 VGPRs)
+template <int D, int MODE, int WSPLIT>
+constexpr int g2_waves() { return (WSPLIT && MODE == 1 && D > 6) ? 1 : 2; }
+
 template <int KIND, int D, int MODE, int WSPLIT = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void kv_grad2_kernel(Grad2Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(g2_waves<D, MODE, WSPLIT>(), 2))) void kv_grad2_kernel(Grad2Args a) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;
