@@ -240,3 +240,27 @@ def test_round_down_accumulation_leaves_a_floor_that_row_signs_remove():
     assert e_rne < 2e-9, e_rne
     assert 1e-8 < e_rdn < 1e-7, e_rdn
     assert e_flip < 0.1 * e_rdn, (e_flip, e_rdn)
+    # ... and with independent signs on 32-row blocks of the RIGHT block as well (ws_blocksign): a random walk over n * n / 32 pairs
+    sblk = np.repeat(np.where(rng.random((n + 31) // 32) < 0.5, -1.0, 1.0), 32)[:n]
+    Wfb = contract(L * sgn, R * sblk, rdn) * sgn[:, None] * sblk[None, :]
+    e_flip2 = abs(((Wfb - Wt) * K).sum()) / mag
+    assert e_flip2 < 0.5 * max(e_flip, 2e-10) or e_flip2 < 5e-10, (e_flip2, e_flip)
+
+
+def test_round4_settings_scopes_restore_their_state():
+    """The three knobs round 4 added are process-global settings like the reference's: scopes nest and restore."""
+    from gpytorch_amd import settings as S
+
+    assert S.rhs_refinement.off() and S.rhs_refinement.steps == 1
+    with S.rhs_refinement(True):
+        assert S.rhs_refinement.on()
+        with S.rhs_refinement(False):
+            assert S.rhs_refinement.off()
+        assert S.rhs_refinement.on()
+    assert S.rhs_refinement.off()
+    assert S.sharding.mll_row_group() is None
+    tok = object()
+    with S.sharding(probe_group=None, row_group=None, mll_row_group=tok):
+        assert S.sharding.mll_row_group() is tok
+    assert S.sharding.mll_row_group() is None and S.sharding.probe_group() is None
+    assert S.batched_small_members.max_size == 3000 and S.batched_small_members.on()
