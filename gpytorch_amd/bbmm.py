@@ -394,6 +394,19 @@ def structured_opts(opts: dict, device) -> dict:
     return opts
 
 
+def refine_with_(rhs64: torch.Tensor, sol: torch.Tensor, matvec64, solve_lowp, steps: int = 1) -> int:
+    """The refinement loop itself, device-agnostic (the CPU suite drives it with torch operators): ``steps`` times
+    r = rhs - A sol in float64 (``matvec64``), d = A^-1 r by the low-precision solver (``solve_lowp`` -> (d, iterations)), sol += d.
+    Vectors are rows (probe-major).  Returns the solver iterations spent."""
+    extra = 0
+    for _ in range(int(steps)):
+        r = (rhs64 - matvec64(sol.to(torch.float64))).to(sol.dtype).contiguous()
+        delta, its = solve_lowp(r)
+        sol += delta
+        extra += int(its)
+    return extra
+
+
 def refine_solves_(x: B.PreparedPoints, scale, sigma2, rhs_t, sol_t, tolerance=None, max_iter=None, precond=None, dvec=None, steps=None):
     """``settings.rhs_refinement``: in-place mixed-precision iterative refinement of float32 solves ``sol_t`` ([c, ld], probe-major) of
     K_hat X = rhs.  Per step: r = rhs - K_hat sol with ONE fused float64 product on the same prepared points (widened to float64: the operator
@@ -403,15 +416,15 @@ def refine_solves_(x: B.PreparedPoints, scale, sigma2, rhs_t, sol_t, tolerance=N
     sc64 = None if scale is None else scale.detach().to(torch.float64)
     s264 = None if sigma2 is None else sigma2.detach().to(torch.float64)
     dv64 = None if dvec is None else dvec.to(torch.float64)
-    extra = 0
-    for _ in range(int(steps)):
-        a64 = sol_t.to(torch.float64)
-        ka = B.kv(x64, x64, a64, scale=sc64, dscale=s264, vd=a64, dvec=dv64)           # K_hat a, float64 (csrc/kv_f64.hpp for d <= 16)
-        r = (rhs_t.to(torch.float64) - ka).to(torch.float32).contiguous()
+
+    def matvec64(a64):   # K_hat a, float64 (csrc/kv_f64.hpp for d <= 16)
+        return B.kv(x64, x64, a64, scale=sc64, dscale=s264, vd=a64, dvec=dv64)
+
+    def solve32(r):
         delta, info = linear_cg(x, scale, sigma2, r, n_tridiag=0, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, dvec=dvec)
-        sol_t += delta
-        extra += info.iterations
-    return extra
+        return delta, info.iterations
+
+    return refine_with_(rhs_t.to(torch.float64), sol_t, matvec64, solve32, steps)
 
 
 def solve(x: B.PreparedPoints, scale, sigma2, rhs_t, tolerance=None, max_iter=None, precond="auto"):

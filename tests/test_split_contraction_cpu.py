@@ -264,3 +264,47 @@ def test_round4_settings_scopes_restore_their_state():
         assert S.sharding.mll_row_group() is tok
     assert S.sharding.mll_row_group() is None and S.sharding.probe_group() is None
     assert S.batched_small_members.max_size == 3000 and S.batched_small_members.on()
+
+
+def test_rhs_refinement_loop_squares_the_accuracy_of_a_float32_solve():
+    """``bbmm.refine_with_`` (the loop behind ``settings.rhs_refinement``) on the CPU: a float32 CG solve of an ill-conditioned kernel system
+    (kappa ~ 1e6) stalls at 1e-4 .. 1e-3; one float64 residual + one more float32 solve takes it below 1e-6."""
+    import pytest
+
+    try:
+        from gpytorch_amd.bbmm import refine_with_
+    except Exception as exc:      # the package imports its ctypes binding lazily; a missing library must not fail a CPU-only host-logic test
+        pytest.skip(f"gpytorch_amd not importable here: {exc}")
+    g = torch.Generator().manual_seed(0)
+    n = 600
+    X = torch.rand(n, 2, generator=g, dtype=torch.float64)
+    A = torch.exp(-0.5 * torch.cdist(X, X).pow(2) / 0.3 ** 2) * 50.0 + 1e-4 * 50.0 * torch.eye(n, dtype=torch.float64)   # kappa ~ 1e6
+    y = torch.randn(1, n, generator=g, dtype=torch.float64)
+    A32 = A.float()
+
+    def cg32(r, iters=4000):
+        b = r.float().reshape(-1)
+        x = torch.zeros_like(b)
+        res = b.clone()
+        p = res.clone()
+        rs = res @ res
+        for k in range(iters):
+            Ap = A32 @ p
+            al = rs / (p @ Ap)
+            x += al * p
+            res -= al * Ap
+            rs2 = res @ res
+            if rs2.sqrt() < 1e-6 * b.norm():
+                break
+            p = res + (rs2 / rs) * p
+            rs = rs2
+        return x.reshape(1, -1), k + 1
+
+    sol, _ = cg32(y)
+    exact = torch.linalg.solve(A, y.reshape(-1))
+    e0 = float((sol.double().reshape(-1) - exact).norm() / exact.norm())
+    extra = refine_with_(y, sol, lambda v: (A @ v.reshape(-1)).reshape(1, -1), cg32, steps=1)
+    e1 = float((sol.double().reshape(-1) - exact).norm() / exact.norm())
+    assert extra > 0
+    assert e0 > 1e-5, e0                   # float32 CG alone is limited by kappa * eps
+    assert e1 < 0.05 * e0, (e0, e1)        # one refinement step: more than an order of magnitude
