@@ -308,3 +308,40 @@ def test_rhs_refinement_loop_squares_the_accuracy_of_a_float32_solve():
     assert extra > 0
     assert e0 > 1e-5, e0                   # float32 CG alone is limited by kappa * eps
     assert e1 < 0.05 * e0, (e0, e1)        # one refinement step: more than an order of magnitude
+
+
+def test_hilbert_order_cache_is_keyed_by_source_and_guarded_by_a_fingerprint():
+    """``backend._ORDER_CACHE`` (round 4): one Hilbert permutation per SOURCE cloud across the evaluations of a training run (a new lengthscale
+    rescales the prepared points uniformly: same order), and never across different clouds that happen to re-use an address."""
+    from gpytorch_amd import backend as B
+
+    g = torch.Generator().manual_seed(1)
+    n = 4096
+    xa = torch.zeros(n, 4)
+    xa[:, :3] = torch.rand(n, 3, generator=g) * 40.0
+    xb = torch.zeros(n, 4)
+    xb[:, :3] = torch.randn(n, 3, generator=g) * 9.0
+    key = ("fake-address", 0, (n, 3), "cpu", torch.float32)
+    B._ORDER_CACHE.pop(key, None)
+    calls = []
+    orig = B.hilbert_order
+    B.hilbert_order = lambda z, bits=None: (calls.append(1), orig(z, bits))[1]
+    try:
+        pa = B.PreparedPoints(xa, n, 3, 4, "rbf")
+        pa.order_key = key
+        perm_a = pa.sorted_view().perm
+        assert key in B._ORDER_CACHE and len(calls) == 1
+        # the same cloud at another lengthscale (uniformly rescaled, shifted): the cached permutation is re-used, no second Hilbert transform
+        pa2 = B.PreparedPoints(xa * 0.37 + torch.tensor([1.0, -2.0, 0.5, 0.0]), n, 3, 4, "rbf")
+        pa2.order_key = key
+        assert torch.equal(pa2.sorted_view().perm, perm_a) and len(calls) == 1
+        # another cloud behind the same key (address re-use): fingerprint mismatch -> its own order, and the entry is replaced
+        pb = B.PreparedPoints(xb, n, 3, 4, "rbf")
+        pb.order_key = key
+        svb = pb.sorted_view()
+        assert len(calls) == 2
+        assert sorted(svb.perm.tolist()) == list(range(n)) and not torch.equal(svb.perm, perm_a)
+        assert len(B._ORDER_CACHE) <= 8
+    finally:
+        B.hilbert_order = orig
+        B._ORDER_CACHE.pop(key, None)
