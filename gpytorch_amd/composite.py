@@ -20,6 +20,8 @@ from .operators import (
     LinearOperator,
     RootLinearOperator,
     ZeroLinearOperator,
+    check_root_method,
+    lanczos_vectors,
     psd_safe_cholesky,
     split_diag,
 )
@@ -227,7 +229,8 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
         from .lanczos import root_inv_decomposition
 
-        if self._use_cholesky(settings.fast_computations.covar_root_decomposition):
+        method = check_root_method(method)
+        if method == "cholesky" or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
             return super().root_inv_decomposition()
         n = self.shape[-1]
         partials, wd = self._partials()
@@ -239,7 +242,9 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
             out = out + nz * q_row
             return out if dv is None else out + dv.unsqueeze(0) * q_row
 
-        rt = root_inv_decomposition(None, None, None, matvec=mv, nvec=n, device=self.device, generator=self.bbmm_opts.get("generator"))
+        init_t, test_t = lanczos_vectors(initial_vectors, test_vectors, n, wd)
+        rt = root_inv_decomposition(None, None, None, matvec=mv, nvec=n, device=self.device, generator=self.bbmm_opts.get("generator"),
+                                    init_vec_t=init_t, test_vec_t=test_t, dtype=wd)
         return RootLinearOperator(B.from_probe_major(rt, n).to(self.dtype))
 
 

@@ -21,7 +21,8 @@ from .bbmm import allreduce_grads_, backward_vectors, build_preconditioner_rows,
 from .functions import KernelSpec, _prep, hyper_grads
 from .lanczos import root_inv_decomposition
 from .linear_cg import linear_cg
-from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, psd_safe_cholesky, split_diag
+from .operators import (DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, check_root_method, lanczos_vectors,
+                        psd_safe_cholesky, split_diag)
 
 
 class IndexedTaskCovar(LinearOperator):
@@ -241,7 +242,8 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
         return sol.squeeze(-1) if squeeze else sol
 
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
-        if self._use_cholesky(settings.fast_computations.covar_root_decomposition):
+        method = check_root_method(method)
+        if method == "cholesky" or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
             return super().root_inv_decomposition()
         n = self.shape[-1]
         partials, wd = self._partials()
@@ -251,7 +253,9 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
             out, _, _ = partials(q_row)
             return out + dv.unsqueeze(0) * q_row
 
-        rt = root_inv_decomposition(None, None, None, matvec=mv, nvec=n, device=self.device, generator=self.bbmm_opts.get("generator"))
+        init_t, test_t = lanczos_vectors(initial_vectors, test_vectors, n, wd)
+        rt = root_inv_decomposition(None, None, None, matvec=mv, nvec=n, device=self.device, generator=self.bbmm_opts.get("generator"),
+                                    init_vec_t=init_t, test_vec_t=test_t, dtype=wd)
         return RootLinearOperator(B.from_probe_major(rt, n).to(self.dtype))
 
 

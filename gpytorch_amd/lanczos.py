@@ -224,23 +224,223 @@ def _lanczos_torch(x, scale, dscale, max_iter, init_vec_t, tol, generator, dvec,
 
 
 def tridiag_to_diag(T: torch.Tensor):
-    """``lanczos_tridiag_to_diag``: eigh on the host in float64 (tiny), negative eigenvalues masked."""
-    evals, evecs = torch.linalg.eigh(T.detach().to(device="cpu", dtype=torch.float64))
+    """``lanczos_tridiag_to_diag``: eigh in float64 (on the host while the matrix is tiny, as the reference does below 32 rows; on the
+    device from 256 rows on -- block decompositions of rank 400 .. 1600), negative eigenvalues masked.  Results live where they were computed."""
+    T64 = T.detach().to(torch.float64)
+    evals, evecs = torch.linalg.eigh(T64 if (T64.shape[-1] >= 256 and T64.is_cuda) else T64.cpu())
     mask = evals >= 0
     evecs = evecs * mask.to(evecs.dtype).unsqueeze(-2)
     evals = evals.masked_fill(~mask, 1.0)
     return evals, evecs
 
 
+def lanczos_tridiag_multi(matvec, n: int, max_iter: int, init_t: torch.Tensor, tol: float = 1e-5):
+    """b INDEPENDENT recurrences of :func:`_lanczos_torch` in lock-step: ``init_t`` [b, ld] holds one start vector per row and every
+    step sends the b current vectors through ONE b-column operator product ``matvec([b, ld]) -> [b, ld]`` -- the reference's
+    ``lanczos_tridiag(..., init_vecs=[n, b])`` (``linear_operator.utils.lanczos``, third-party; its ``num_init_vecs`` dimension is a
+    batch of recurrences that share nothing but the product call; reached through ``gpytorch.root_inv_decomposition(initial_vectors=...)``,
+    ``gpytorch/__init__.py:190-216``).  On the device that product is what pays: b = 5 .. 16 columns run on the matrix-pipe kernels
+    (one ``kv_gramh`` launch, 45 ms for 11 columns at n = 500 000) where b single-column products are exp-bound (19 ms EACH).
+    Returns Q [b, m, ld] (orthonormal rows per chain) and T [b, m, m]; same stopping rule as the reference: the loop ends when EVERY
+    chain has broken down (beta < 1e-6) or a re-orthogonalisation did not converge in 10 passes."""
+    b, ld = init_t.shape
+    wd, dev = init_t.dtype, init_t.device
+    num_iter = min(max_iter, n)
+    Q = torch.zeros(b, num_iter, ld, device=dev, dtype=wd)
+    T = torch.zeros(b, num_iter, num_iter, device=dev, dtype=wd)
+    tiny = torch.finfo(wd).tiny
+
+    def dot(a, c):
+        return (a[:, :n] * c[:, :n]).sum(-1)
+
+    def mv(q):
+        w = matvec(q.contiguous())
+        w = w if w.dtype == wd else w.to(wd)
+        if ld > n:
+            w[:, n:] = 0
+        return w
+
+    q0 = init_t / dot(init_t, init_t).sqrt().clamp_min(tiny).unsqueeze(-1)
+    if ld > n:
+        q0[:, n:] = 0
+    Q[:, 0] = q0
+    r = mv(q0)
+    a0 = dot(q0, r)
+    r = r - a0.unsqueeze(-1) * q0
+    b0 = dot(r, r).sqrt()
+    T[:, 0, 0] = a0
+    m = 1
+    if num_iter > 1:
+        T[:, 0, 1] = b0
+        T[:, 1, 0] = b0
+        Q[:, 1] = r / b0.clamp_min(tiny).unsqueeze(-1)
+        m = 2
+        for k in range(1, num_iter):
+            q_prev, q = Q[:, k - 1], Q[:, k]
+            r = mv(q) - T[:, k, k - 1].unsqueeze(-1) * q_prev
+            a = dot(q, r)
+            T[:, k, k] = a
+            m = k + 1
+            if k + 1 < num_iter:
+                r = r - a.unsqueeze(-1) * q
+                basis = Q[:, : k + 1]                                          # [b, k + 1, ld]
+                r = r - torch.bmm(torch.bmm(basis, r.unsqueeze(-1)).mT, basis).squeeze(1)
+                bn = dot(r, r).sqrt()
+                r = r / bn.clamp_min(tiny).unsqueeze(-1)
+                T[:, k, k + 1] = bn
+                T[:, k + 1, k] = bn
+                ok = False
+                for _ in range(10):
+                    inner = torch.bmm(basis, r.unsqueeze(-1)).squeeze(-1)      # [b, k + 1]
+                    if not bool((inner.abs() > tol).any()):                    # the one host poll of this pass
+                        ok = True
+                        break
+                    r = r - torch.bmm(inner.unsqueeze(1), basis).squeeze(1)
+                    r = r / dot(r, r).sqrt().clamp_min(tiny).unsqueeze(-1)
+                Q[:, k + 1] = r
+                if not bool((bn.abs() > 1e-6).any()) or not ok:
+                    break
+                m = k + 2
+    return Q[:, :m], T[:, :m, :m]
+
+
+def block_lanczos_steps(n: int, dev, steps: int, init_t: torch.Tensor):
+    """BLOCK Lanczos with full re-orthogonalisation (Golub & Underwood 1977; block size b = rows of ``init_t`` [b, ld]) as a coroutine in the
+    manner of :func:`lanczos_steps`: yields the probe-major block Q_s [b, ld] whose product W = A Q_s it needs next, receives W through ``send``
+    and finally returns (Q [m, ld] with orthonormal rows, T [m, m] = Q A Q^T in float64, m = steps * b) as the StopIteration value.
+
+    No counterpart in the reference -- it is what the reference's multi-vector interface becomes when the b-column product is the unit
+    of cost: the span of the b lock-step recurrences of :func:`lanczos_tridiag_multi` IS the block Krylov space, and the Galerkin inverse on ALL
+    of it (rank steps * b) costs the products of ONE rank-``steps`` recurrence.  For the LOVE cache the error depends on the rank of the space, not
+    on how it was generated (``tests/test_block_lanczos_cpu.py``, ``tests/test_gpu_love_vs_oracle.py``), so a rank-400 cache is 50 eight-column
+    products instead of 400 one-column products.
+    Per step: the product, two classical Gram-Schmidt passes against every earlier block (tall-skinny GEMMs), Cholesky-QR twice on the b new
+    rows (Gram matrix and factor in float64).  No host synchronisation inside the loop: a rank-deficient block (Krylov space exhausted) shows up
+    in ``cholesky_ex``'s info words, read ONCE at the end; the decomposition is then cut before the first such block."""
+    b, ld = init_t.shape
+    wd = init_t.dtype
+    m_max = steps * b
+    Q = torch.zeros(m_max, ld, device=dev, dtype=wd)
+    H = torch.zeros(m_max, m_max, device=dev, dtype=torch.float64)
+    infos = []
+
+    def orthonormalise(R, k):
+        """Rows of R made orthonormal and orthogonal to Q[:k]; two passes ("twice is enough")."""
+        info = None
+        for _ in range(2):
+            if k:
+                R = R - (R[:, :n] @ Q[:k, :n].t()) @ Q[:k]
+            R64 = R[:, :n].to(torch.float64)
+            Lc, inf = torch.linalg.cholesky_ex(R64 @ R64.t())
+            info = inf if info is None else torch.maximum(info, inf)
+            R = torch.zeros_like(R)
+            R[:, :n] = torch.linalg.solve_triangular(Lc, R64, upper=False).to(wd)
+        infos.append(info)
+        return R
+
+    R0 = init_t.clone()
+    if ld > n:
+        R0[:, n:] = 0
+    Q[:b] = orthonormalise(R0, 0)
+    for s in range(steps):
+        k = (s + 1) * b
+        W = yield Q[k - b : k]
+        W = W if W.dtype == wd else W.to(wd)
+        Cf = Q[:k, :n] @ W[:, :n].t()                    # [k, b]: column block s of Q A Q^T down to its diagonal block
+        H[:k, k - b : k] = Cf.to(torch.float64)
+        if s + 1 == steps:
+            break
+        R = torch.zeros_like(Q[:b])
+        R[:, :n] = W[:, :n] - Cf.t() @ Q[:k, :n]
+        Q[k : k + b] = orthonormalise(R, k)
+    bad = [i for i, v in enumerate(torch.stack(infos).reshape(-1).tolist()) if v]       # the one host synchronisation
+    m = m_max if not bad else bad[0] * b
+    if m == 0:
+        raise RuntimeError("block Lanczos: the start block is rank deficient")
+    Hm = H[:m, :m]
+    T = torch.triu(Hm) + torch.triu(Hm, 1).t()
+    return Q[:m], T
+
+
+def block_lanczos(matvec, n: int, dev, steps: int, init_t: torch.Tensor):
+    """Drives :func:`block_lanczos_steps` with ``matvec([b, ld]) -> [b, ld]``."""
+    gen = block_lanczos_steps(n, dev, steps, init_t)
+    try:
+        q = next(gen)
+        while True:
+            q = gen.send(matvec(q))
+    except StopIteration as done:
+        return done.value
+
+
+def block_size_for(n: int, rank: int) -> int:
+    """Block size of the LOVE / root decompositions: ``settings.lanczos_block_size`` ("auto": 8 rows per product once a product fills
+    the chip -- n >= 16 384 -- and the requested rank is at least four blocks; otherwise the reference's single-vector recurrence)."""
+    v = settings.lanczos_block_size.value()
+    if v == "auto":
+        return 8 if (n >= settings.lanczos_block_size.auto_min_size and rank >= 32) else 1
+    return max(1, min(int(v), rank))
+
+
+def root_from_tridiag(Q: torch.Tensor, T: torch.Tensor, inverse: bool = True) -> torch.Tensor:
+    """Rows of (V Lambda^-1/2)^T Q (``inverse``) or (V Lambda^1/2)^T Q for T = V Lambda V^T, eigendecomposition on the host in float64
+    with ``settings.tridiagonal_jitter`` on the diagonal and negative eigenvalues masked (``lanczos_tridiag_to_diag``)."""
+    Tj = T + settings.tridiagonal_jitter.value() * torch.eye(T.shape[-1], device=T.device, dtype=T.dtype)
+    evals, evecs = tridiag_to_diag(Tj)
+    sc = evals.sqrt().unsqueeze(-2)
+    w = (evecs / sc if inverse else evecs * sc).to(device=Q.device, dtype=Q.dtype)
+    return w.mT @ Q
+
+
+def select_by_test_vectors(roots_t: torch.Tensor, test_t: torch.Tensor, matvec, n: int) -> int:
+    """``_postprocess_lanczos_root_inv_decomp`` (linear_operator, third-party; documented at ``gpytorch/__init__.py:190-216``: "the best
+    initialization vector (determined by ``test_vectors``) will be chosen"): every candidate root R_i (rows of ``roots_t[i]``, R_i^T R_i ~= A^-1)
+    solves the test vectors, ONE product with all b * c solves gives the residuals |A s - v|_2, summed over the test vectors; the index of the
+    smallest sum is returned."""
+    b, _, ld = roots_t.shape
+    c = test_t.shape[0]
+    test_t = test_t.to(roots_t.dtype)
+    coef = torch.einsum("cl,bml->bcm", test_t[:, :n], roots_t[:, :, :n])
+    sol = torch.einsum("bcm,bml->bcl", coef, roots_t)
+    prod = matvec(sol.reshape(b * c, ld).contiguous()).reshape(b, c, ld)
+    res = (prod[:, :, :n] - test_t[:, :n].unsqueeze(0)).norm(dim=-1).sum(-1)
+    return int(res.argmin())
+
+
 def root_inv_decomposition(x: B.PreparedPoints, scale, dscale, max_iter=None, init_vec_t=None, generator=None, dvec=None,
-                           matvec=None, nvec=None, device=None, reduce=None, n_global=None):
+                           matvec=None, nvec=None, device=None, reduce=None, n_global=None, test_vec_t=None, block=None, dtype=None):
     """Rt [m, ld] with Rt^T Rt ~= K_hat^-1 on the Krylov space (the ``covar_cache`` of
-    ``exact_prediction_strategies.py:267-272``)."""
+    ``exact_prediction_strategies.py:267-272``).
+
+    ``init_vec_t`` with b > 1 rows is the reference's multi-vector form (``gpytorch.root_inv_decomposition(initial_vectors, test_vectors)``,
+    ``gpytorch/__init__.py:190-216``): b recurrences in lock-step, the one whose root solves ``test_vec_t`` best is returned.  Without start
+    vectors (or with one) ``block`` (default :func:`block_size_for`) > 1 builds the cache on a block Krylov space instead (:func:`block_lanczos_steps`)."""
     max_iter = settings.max_root_decomposition_size.value() if max_iter is None else max_iter
+    n = x.n if nvec is None else nvec
+    dev = x.xp.device if device is None else device
+
+    def mv(q_rows):
+        if matvec is not None:
+            return matvec(q_rows)
+        return B.kv(x, x, q_rows, scale=scale, dscale=dscale, vd=q_rows if dscale is not None else None, dvec=dvec)
+
+    if init_vec_t is not None and init_vec_t.shape[0] > 1:
+        if reduce is not None:
+            raise NotImplementedError("root_inv_decomposition: several initial vectors on row-sharded vectors")
+        if test_vec_t is None:
+            raise ValueError("root_inv_decomposition: several initial_vectors need test_vectors to choose between their decompositions "
+                             "(gpytorch/__init__.py:190-216)")
+        Qb, Tb = lanczos_tridiag_multi(mv, n, max_iter, init_vec_t)
+        roots = torch.stack([root_from_tridiag(Qb[i], Tb[i]) for i in range(Qb.shape[0])])
+        return roots[select_by_test_vectors(roots, test_vec_t, mv, n)]
+    block = block_size_for(n if n_global is None else n_global, max_iter) if block is None else block
+    if block > 1 and reduce is None and init_vec_t is None:
+        ld = B.round_up(n, 4)
+        wd = dtype if dtype is not None else (x.dtype if x is not None else torch.float32)
+        init = torch.zeros(block, ld, device=dev, dtype=wd)
+        init[:, :n] = torch.randn(block, n, device=dev, generator=generator, dtype=wd)
+        Q, T = block_lanczos(mv, n, dev, max(1, min(max_iter, n) // block), init)
+        return root_from_tridiag(Q, T)
     Q, T = lanczos_tridiag(x, scale, dscale, max_iter, init_vec_t, generator=generator, dvec=dvec, matvec=matvec,
                            nvec=nvec, device=device, reduce=reduce, n_global=n_global)
-    jitter = settings.tridiagonal_jitter.value()
-    Tj = T + jitter * torch.eye(T.shape[0], device=T.device, dtype=T.dtype)
-    evals, evecs = tridiag_to_diag(Tj)
-    w = (evecs / evals.sqrt().unsqueeze(-2)).to(device=Q.device, dtype=Q.dtype)  # V Lambda^-1/2
-    return w.t() @ Q  # [m, ld]: rows = columns of Q V Lambda^-1/2
+    return root_from_tridiag(Q, T)

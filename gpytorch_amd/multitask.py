@@ -27,7 +27,7 @@ from .likelihoods import _GaussianLikelihoodBase
 from .linear_cg import linear_cg
 from .means import Mean
 from .module import GreaterThan, Module, Positive
-from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, psd_safe_cholesky
+from .operators import DiagLinearOperator, FusedKernelLinearOperator, LinearOperator, RootLinearOperator, check_root_method, lanczos_vectors, psd_safe_cholesky
 
 
 # ------------------------------------------------------------------------------------------------ layout helpers
@@ -235,7 +235,8 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
         return torch.kron(kmat, self.kron.ktt) + torch.diag(self.task_noise.repeat(kx.shape[0]))
 
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
-        if self._use_cholesky(settings.fast_computations.covar_root_decomposition):
+        method = check_root_method(method)
+        if method == "cholesky" or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
             return super().root_inv_decomposition()
         p1, _ = self.kron.kx.prepared()
         ktt, os_, dv = self.kron.ktt.detach(), self.kron.kx._os(), self._dvec()
@@ -244,7 +245,8 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
         def mv(q_row):
             return kron_matvec(p1, p1, ktt, q_row, os_) + dv.unsqueeze(0) * q_row
 
-        rt = root_inv_decomposition(None, None, None, matvec=mv, nvec=N, device=self.device)
+        init_t, test_t = lanczos_vectors(initial_vectors, test_vectors, N, p1.dtype)
+        rt = root_inv_decomposition(None, None, None, matvec=mv, nvec=N, device=self.device, init_vec_t=init_t, test_vec_t=test_t, dtype=p1.dtype)
         return RootLinearOperator(B.from_probe_major(rt, N).to(self.dtype))
 
 

@@ -214,6 +214,7 @@ class LinearOperator:
         ``max_root_decomposition_size``, through this operator's own matrix-free product) above ``max_cholesky_size`` or when
         ``settings.fast_pred_samples`` asks for the low-rank LOVE-style root."""
         n = self.shape[-1]
+        method = check_root_method(method)
         if method is None:
             big = n > settings.max_cholesky_size.value() or settings.fast_pred_samples.on()
             method = "lanczos" if (big and self.device is not None and torch.device(self.device).type == "cuda") else "cholesky"
@@ -247,6 +248,11 @@ class LinearOperator:
         return torch.movedim(root @ eps, -1, 0)   # [num_samples, ..., n]: batch operators keep their leading dimensions
 
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
+        """Dense default (small operators): the Cholesky root of the inverse.  ``method="lanczos"`` on an operator without a matrix-free
+        Lanczos of its own is an error, not a silent Cholesky."""
+        if check_root_method(method) == "lanczos":
+            raise NotImplementedError(f"{type(self).__name__}.root_inv_decomposition(method='lanczos')")
+        lanczos_vectors(initial_vectors, test_vectors, self.shape[-1], self.dtype)   # (shape errors as the reference raises them; a dense factor needs no start vector)
         Lc = self.cholesky()
         inv_root = torch.linalg.solve_triangular(Lc, torch.eye(Lc.shape[-1], dtype=Lc.dtype, device=Lc.device), upper=False).mT
         return RootLinearOperator(inv_root.to(self.dtype))
@@ -288,6 +294,29 @@ def to_linear_operator(obj):
 
 def to_dense(obj):
     return obj.to_dense() if isinstance(obj, LinearOperator) else obj
+
+
+def check_root_method(method):
+    """``method`` of ``LinearOperator.root_decomposition`` / ``root_inv_decomposition`` (linear_operator: "cholesky", "lanczos", and for
+    the forward root also "symeig" / "pivoted_cholesky"): the two methods built here, or an error -- never silently another one."""
+    if method not in (None, "cholesky", "lanczos"):
+        raise NotImplementedError(f"root decomposition method {method!r}: only 'cholesky' and 'lanczos' are implemented")
+    return method
+
+
+def lanczos_vectors(initial_vectors, test_vectors, n: int, dtype):
+    """The reference's ``initial_vectors`` [n] / [n, b] and ``test_vectors`` [n] / [n, c] as probe-major blocks ([b, ld], [c, ld]) or None;
+    shape errors as ``LinearOperator.root_inv_decomposition`` raises them (RuntimeError on a length mismatch)."""
+    out = []
+    for name, v in (("initial_vectors", initial_vectors), ("test_vectors", test_vectors)):
+        if v is None:
+            out.append(None)
+            continue
+        v = v.unsqueeze(-1) if v.dim() == 1 else v
+        if v.dim() != 2 or v.shape[-2] != n:
+            raise RuntimeError(f"LinearOperator (size={n} x {n}) cannot be multiplied with {name} (size={tuple(v.shape)}).")
+        out.append(B.to_probe_major(v, dtype))
+    return out[0], out[1]
 
 
 class ZeroLinearOperator(LinearOperator):
@@ -835,20 +864,25 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         return rs.gather(rt_loc)
 
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
-        """Lanczos root-inverse (``exact_prediction_strategies.py:271``) -> RootLinearOperator(n x m)."""
+        """Lanczos root-inverse (``exact_prediction_strategies.py:271``) -> RootLinearOperator(n x m).  ``initial_vectors`` [n, b] /
+        ``test_vectors`` [n, c] as documented at ``gpytorch/__init__.py:190-216``: b recurrences in lock-step (ONE b-column product per
+        step), the decomposition that solves the test vectors best is returned."""
         from .lanczos import root_inv_decomposition
 
-        if self._use_cholesky(settings.fast_computations.covar_root_decomposition):
+        method = check_root_method(method)
+        if method == "cholesky" or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
             return super().root_inv_decomposition()
+        n = self.shape[-1]
+        init_t, test_t = lanczos_vectors(initial_vectors, test_vectors, n, B.work_dtype(self.kernel_op.x1))
         if self._row_shard() is not None:
-            init_t = None if initial_vectors is None else B.to_probe_major(initial_vectors.reshape(self.shape[-1], -1)[:, :1])
-            rt = self._root_inv_row_sharded(init_t)
-            return RootLinearOperator(B.from_probe_major(rt, self.shape[-1]).to(self.dtype))
+            if init_t is not None and init_t.shape[0] > 1:
+                raise NotImplementedError("root_inv_decomposition: several initial_vectors on a row-sharded operator")
+            rt = self._root_inv_row_sharded(None if init_t is None else init_t.to(torch.float32))
+            return RootLinearOperator(B.from_probe_major(rt, n).to(self.dtype))
         p1, _ = self.kernel_op.prepared()
-        init_t = None if initial_vectors is None else B.to_probe_major(initial_vectors.reshape(self.shape[-1], -1)[:, :1], B.work_dtype(self.kernel_op.x1))
-        rt = root_inv_decomposition(p1, self.kernel_op._os(), self._nz(), init_vec_t=init_t,
+        rt = root_inv_decomposition(p1, self.kernel_op._os(), self._nz(), init_vec_t=init_t, test_vec_t=test_t,
                                     generator=self.bbmm_opts.get("generator"), dvec=self._dvec())
-        return RootLinearOperator(B.from_probe_major(rt, self.shape[-1]).to(self.dtype))
+        return RootLinearOperator(B.from_probe_major(rt, n).to(self.dtype))
 
     def pivoted_cholesky(self, rank, error_tol=None, return_pivots=False):
         raise NotImplementedError("pivoted_cholesky is defined on the noise-free kernel operator (self.kernel_op)")
@@ -860,7 +894,13 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         p1, _ = self.kernel_op.prepared()
         return (p1.fused and not self._use_cholesky(settings.fast_computations.solves)
                 and not self._use_cholesky(settings.fast_computations.covar_root_decomposition) and self._row_shard() is None
-                and settings.max_root_decomposition_size.value() <= 512)  # (gpamd_lanczos_* kernels: k <= 512)
+                and self._fused_lanczos_ok())
+
+    def _fused_lanczos_ok(self) -> bool:
+        from .lanczos import block_size_for
+
+        rank = settings.max_root_decomposition_size.value()
+        return rank <= 512 or block_size_for(self.shape[-1], rank) > 1     # (gpamd_lanczos_* kernels: k <= 512; the block form has no limit)
 
     def solve_and_root_inv(self, rhs: torch.Tensor):
         """(K_hat^-1 rhs, root of K_hat^-1) -- the mean cache and the LOVE covariance cache of
@@ -871,7 +911,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         import ctypes as C
 
         from ._lib import check, lib
-        from .lanczos import lanczos_steps, tridiag_to_diag
+        from .lanczos import block_lanczos_steps, block_size_for, lanczos_steps, root_from_tridiag
         from .linear_cg import linear_cg
 
         p1, _ = self.kernel_op.prepared()
@@ -880,13 +920,21 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         os_, nz, dv = self.kernel_op._os(), self._nz(), self._dvec()
         self._preconditioner()
         L, st = lib(), B._stream(dev)
-        flags = B.kv_flags(p1, p1, 2)
+        rank = settings.max_root_decomposition_size.value()
+        gen = self.bbmm_opts.get("generator")
+        nb = block_size_for(n, rank)          # rows per Lanczos product: 1 = the reference's recurrence, > 1 = block Lanczos
+        if nb > 1:
+            init = torch.zeros(nb, ld, device=dev, dtype=torch.float32)
+            init[:, :n] = torch.randn(nb, n, device=dev, generator=gen, dtype=torch.float32)
+            steps = block_lanczos_steps(n, dev, max(1, min(rank, n) // nb), init)
+        else:
+            steps = lanczos_steps(n, dev, rank, generator=gen)
+        flags = B.kv_flags(p1, p1, 1 + nb)
         sorted_rows = B.gram_operands(p1, p1, flags)[2] is not None
-        S, jc, wsn = B.kv_plan(p1.kind, n, n, p1.d, 2, flags, ld)
+        S, jc, wsn = B.kv_plan(p1.kind, n, n, p1.d, 1 + nb, flags, ld)
         P = B.workspace(dev, wsn)
-        W = torch.zeros(2, ld, device=dev, dtype=torch.float32)
-        wl = torch.zeros(1, ld, device=dev, dtype=torch.float32)
-        steps = lanczos_steps(n, dev, settings.max_root_decomposition_size.value(), generator=self.bbmm_opts.get("generator"))
+        W = torch.zeros(1 + nb, ld, device=dev, dtype=torch.float32)
+        wl = torch.zeros(nb, ld, device=dev, dtype=torch.float32)
         state = {"q": next(steps), "result": None}
 
         def feed(w):
@@ -907,11 +955,12 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
                 return P1, S1, ld
             q = state["q"]
             W[0].copy_(dt[0])
-            W[1].copy_(q[0])
-            if sorted_rows:
-                # block-centred Gram expansion (wide clouds, backend.gram_mode 2): B.kv takes the Hilbert-ordered output rows back
+            W[1:].copy_(q)
+            if sorted_rows or nb > 1:
+                # (block-centred Gram expansion -- wide clouds, backend.gram_mode 2 -- or a Lanczos BLOCK: B.kv sums the slabs and takes
+                # Hilbert-ordered output rows back; the CG column is handed on as a single finished slab)
                 both = B.kv(p1, p1, W)
-                wl.copy_(both[1:2])
+                wl.copy_(both[1:])
                 if os_ is not None:
                     wl.mul_(os_.reshape(()))
                 wl[:, :n].addcmul_(q[:, :n], (nz.reshape(()) + (dv[:n] if dv is not None else 0.0)).expand(n))
@@ -934,14 +983,11 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
             from .bbmm import refine_solves_
 
             refine_solves_(p1, os_, nz, B.to_probe_major(r.detach(), p1.dtype), sol_t, settings.cg_tolerance.value(), None, self._cache["precond"], dv)
-        while state["result"] is None:        # CG finished first: the remaining Lanczos steps on one-column products
+        while state["result"] is None:        # CG finished first: the remaining Lanczos steps on their own products
             q = state["q"]
             feed(B.kv(p1, p1, q, scale=os_, dscale=nz, vd=q, dvec=dv))
         Q, T = state["result"]
-        Tj = T + settings.tridiagonal_jitter.value() * torch.eye(T.shape[0], device=T.device, dtype=T.dtype)
-        evals, evecs = tridiag_to_diag(Tj)
-        wmat = (evecs / evals.sqrt().unsqueeze(-2)).to(device=Q.device, dtype=Q.dtype)
-        root = B.from_probe_major(wmat.t() @ Q, n).to(self.dtype)
+        root = B.from_probe_major(root_from_tridiag(Q, T), n).to(self.dtype)
         sol = B.from_probe_major(sol_t, n).to(rhs.dtype)
         return (sol.squeeze(-1) if rhs.dim() == 1 else sol), RootLinearOperator(root)
 

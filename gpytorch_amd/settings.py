@@ -144,6 +144,17 @@ class max_root_decomposition_size(_value_context):
     _global_value = 100
 
 
+class lanczos_block_size(_value_context):
+    """(no counterpart in the reference.)  Rows per operator product of the Lanczos decompositions behind the LOVE cache
+    (``root_inv_decomposition`` without start vectors): 1 = the reference's single-vector recurrence (``max_root_decomposition_size``
+    one-column products, exp-bound on MI355X: 19 ms each at n = 500 000); b > 1 = block Lanczos (``lanczos.block_lanczos_steps``):
+    ``max_root_decomposition_size // b`` products of b columns on the matrix-pipe kernels for a cache of the same rank -- the variance error
+    of a LOVE cache follows its rank, not the way its Krylov space was generated (``tests/test_block_lanczos_cpu.py``).
+    "auto" (default): 8 from ``auto_min_size`` rows on (a product then fills the chip) when the rank is at least 32, else 1."""
+    _global_value = "auto"
+    auto_min_size = 16384
+
+
 class num_trace_samples(_value_context):
     _global_value = 10
 

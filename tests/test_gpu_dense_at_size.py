@@ -160,6 +160,7 @@ def run_posterior_case(name, kind, n, d, ls, dev, ns=1000,
     for cfg in configs:
         rank, tol, fast, love_rank = cfg[:4]
         refine = len(cfg) > 4 and cfg[4]          # settings.rhs_refinement: float64 residual replacement for the mean-cache solve
+        blk = cfg[5] if len(cfg) > 5 else "auto"  # settings.lanczos_block_size (round 5): rows per Lanczos product of the LOVE cache
         if True:
             if True:
                 _, m, lik = _model(kind, X, y, ls, theta, s2v, dev, mean=0.0)   # a fresh model: cold caches
@@ -168,13 +169,14 @@ def run_posterior_case(name, kind, n, d, ls, dev, ns=1000,
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(tol), S.fast_pred_var(fast), S.max_preconditioner_size(rank), \
-                        S.max_root_decomposition_size(love_rank), S.max_cg_iterations(6000), S.rhs_refinement(refine):
+                        S.max_root_decomposition_size(love_rank), S.max_cg_iterations(6000), S.rhs_refinement(refine), S.lanczos_block_size(blk):
                     pred = m(Xsd)
                     mu, var = pred.mean.double().cpu(), pred.variance.double().cpu()
                 torch.cuda.synchronize(dev)
                 sec = time.perf_counter() - t0
                 runs.append({
                     "precond_rank": rank, "eval_cg_tolerance": tol, "fast_pred_var": fast, "love_rank": love_rank if fast else None, "rhs_refinement": bool(refine), "seconds": sec,
+                    "lanczos_block_size": blk if fast else None,
                     "mean_rel_err": float((mu - mean_ref).norm() / mean_ref.norm()),
                     "mean_max_abs_err": float((mu - mean_ref).abs().max()),
                     "var_max_rel_err": float(((var - var_ref).abs() / var_ref).max()),

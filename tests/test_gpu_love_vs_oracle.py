@@ -1,0 +1,152 @@
+"""LOVE (``fast_pred_var``) variance error against the RANK of the Lanczos decomposition: the device path and the float64 oracle on the
+SAME start vector at a size the oracle can run (n = 20 000; RBF, d = 3, lengthscale 0.25, noise 0.1 -- C2's model).
+
+Round 4 measured the reference's criterion (|variance error| < 5 % of the noise, ``test/examples/test_simple_gp_regression.py:436-442``)
+missed at the reference-default rank 100 at C2 and called it "the algorithm's rank, not the kernels".  This file is the evidence: with the
+same start vector the error-vs-rank curve of the HIP recurrence (float32 vectors, fused K*V, ``gpamd_lanczos_*`` kernels) coincides with
+the curve of ``oracle/lanczos.py`` (float64, dense matrix) at ranks 50 / 100 / 200 / 400; and the BLOCK form that now builds the cache
+(``lanczos.block_lanczos_steps``: rank = steps x 8 from eight-column products) lies on the same curve as its float64 restatement and as
+the single-vector recurrence of equal rank.  Also here: the reference's multi-vector interface
+(``gpytorch.root_inv_decomposition(initial_vectors [n, b], test_vectors)``, ``gpytorch/__init__.py:190-216``) through the operator on
+the device against the oracle's restatement of it -- same decomposition chosen, same root.
+Numbers -> gpurun_out/love_vs_oracle.json (copied into profiles/)."""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from tests import dense_device as DD
+from tests.test_gpu_dense_at_size import synth
+
+pytestmark = pytest.mark.gpu
+
+N, NS, LS, THETA, S2 = 20_000, 400, 0.25, 1.0, 0.1
+RANKS = (50, 100, 200, 400)
+
+
+@pytest.fixture(scope="module")
+def problem(dev):
+    X, y = synth(N, 3)
+    Xs, _ = synth(NS, 3, seed=3)
+    gp = DD.DenseGP("rbf", X, y, LS, THETA, S2, dev)
+    ks = DD.cross_rows("rbf", X, Xs, LS, THETA, dev)                     # [ns, n] float64
+    exact_q = (ks * gp.solve(ks.t().contiguous()).t()).sum(-1).cpu()     # k_*^T K_hat^-1 k_*
+    gp.free()
+    Khat = DD.dense_khat("rbf", X, LS, THETA, S2, dev).cpu()             # the oracle's operator: dense float64 on the host
+    return {"X": X, "ks": ks.cpu(), "exact_q": exact_q, "Khat": Khat}
+
+
+def _errors(Qrows, T, ks, exact_q, ranks, block=1):
+    """max |k_*^T (Q_k T_k^-1 Q_k^T) k_* - exact| / noise for the leading rank-k part of one decomposition (Lanczos is nested: the first
+    k rows of Q and the leading k x k block of T ARE the k-step decomposition)."""
+    out = []
+    P = ks @ Qrows.t()                                                    # [ns, m]
+    for k in ranks:
+        k = (k // block) * block
+        evals, evecs = torch.linalg.eigh(T[:k, :k])
+        keep = evals > 0
+        W = P[:, :k] @ (evecs[:, keep] / evals[keep].sqrt())
+        out.append(float(((W**2).sum(-1) - exact_q).abs().max() / S2))
+    return out
+
+
+def test_love_error_vs_rank_matches_the_oracle_on_the_same_start_vector(dev, problem):
+    from gpytorch_amd import backend as B
+    from gpytorch_amd import lanczos as LZ
+    from oracle import lanczos as OL
+
+    X, ks, exact_q, Khat = problem["X"], problem["ks"], problem["exact_q"], problem["Khat"]
+    g = torch.Generator().manual_seed(11)
+    init = torch.randn(N, 8, generator=g, dtype=torch.float64)
+    xp = B.prep_points("rbf", X.to(dev), torch.tensor(LS), X.mean(0).to(dev))
+    sc, s2 = torch.tensor([THETA], device=dev), torch.tensor([S2], device=dev)
+    log = {"n": N, "test_points": NS, "ranks": list(RANKS), "noise": S2}
+
+    # ---- single start vector: the reference's recurrence -------------------------------------------------------------------------------
+    t0 = time.perf_counter()
+    Qo, To = OL.lanczos_tridiag(lambda v: Khat @ v, max(RANKS), N, init[:, :1])
+    log["oracle_seconds"] = time.perf_counter() - t0
+    err_o = _errors(Qo.t(), To, ks, exact_q, RANKS)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    Qt, T = LZ.lanczos_tridiag(xp, sc, s2, max(RANKS), B.to_probe_major(init[:, :1].to(dev)))
+    torch.cuda.synchronize(dev)
+    log["device_seconds"] = time.perf_counter() - t0
+    assert Qt.shape[0] == max(RANKS)
+    err_d = _errors(Qt[:, :N].double().cpu(), T.double().cpu(), ks, exact_q, RANKS)
+    log["single_vector"] = {"oracle_float64": err_o, "device_float32": err_d}
+
+    # ---- block of eight: what builds the cache at size (no counterpart in the reference) -----------------------------------------------
+    def mv(q):
+        return B.kv(xp, xp, q, scale=sc, dscale=s2, vd=q)
+
+    steps = max(RANKS) // 8
+    t0 = time.perf_counter()
+    Qbo, Tbo = OL.block_lanczos(lambda v: Khat @ v, steps, N, init)
+    log["oracle_block_seconds"] = time.perf_counter() - t0
+    err_bo = _errors(Qbo.t(), Tbo, ks, exact_q, RANKS, block=8)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    Qb, Tb = LZ.block_lanczos(mv, N, dev, steps, B.to_probe_major(init.to(dev)))
+    torch.cuda.synchronize(dev)
+    log["device_block_seconds"] = time.perf_counter() - t0
+    Qbc = Qb[:, :N].double().cpu()
+    log["block_orthogonality"] = float((Qbc @ Qbc.t() - torch.eye(Qbc.shape[0], dtype=torch.float64)).abs().max())
+    log["block_T_vs_QAQt"] = float((Tb.cpu() - Qbc @ (Khat @ Qbc.t())).abs().max() / Tb.abs().max())
+    err_bd = _errors(Qbc, Tb.double().cpu(), ks, exact_q, RANKS, block=8)
+    log["block_of_8"] = {"oracle_float64": err_bo, "device_float32": err_bd}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/love_vs_oracle.json", "w") as f:
+        json.dump(log, f, indent=1)
+
+    floor = 2e-3      # of the noise: float32 floor of 1 - k^T K^-1 k itself (the variance of f is 1e-4 .. 2e-3 here)
+    for name, dvc, orc in (("single", err_d, err_o), ("block", err_bd, err_bo)):
+        for k, a, b in zip(RANKS, dvc, orc):
+            # "coincide": within 25 % of each other, or both at the float32 floor
+            assert abs(a - b) <= 0.25 * max(a, b) + floor, (name, k, a, b, log)
+    # the error is the ALGORITHM's: above the criterion at the reference-default rank 100, far below it at rank 400 -- on either arithmetic
+    assert err_o[1] > 0.05 and err_d[1] > 0.05 and err_o[3] < 0.01 and err_d[3] < 0.01, log
+    # ... and follows the rank, not the way the space was generated: block of 8 against single vector at equal rank
+    for k, a, b in zip(RANKS, err_bd, err_d):
+        assert a <= 2.0 * b + floor, ("block vs single", k, a, b, log)
+    assert log["block_orthogonality"] < 1e-4 and log["block_T_vs_QAQt"] < 1e-4, log
+
+
+def test_multi_vector_interface_on_device_selects_as_the_reference_documents(dev, problem):
+    """``root_inv_decomposition(initial_vectors [n, 4], test_vectors [n, 3])`` through the model-level operator: four lock-step recurrences
+    (one 4-column fused product per step), the decomposition with the smallest test-vector residual returned -- against the oracle's
+    restatement of ``lanczos_tridiag(init_vecs)`` + ``_postprocess_lanczos_root_inv_decomp`` on the dense float64 matrix."""
+    import gpytorch_amd as gp
+    from oracle import lanczos as OL
+    from tests.test_gpu_model import _model
+
+    X, Khat = problem["X"], problem["Khat"]
+    y = synth(N, 3)[1]
+    g = torch.Generator().manual_seed(12)
+    init = torch.randn(N, 4, generator=g, dtype=torch.float64)
+    init[:, 2] = problem["ks"][:50].sum(0)            # a smooth start vector among random ones: its Krylov space solves smooth test vectors best
+    test = problem["ks"][100:103].t().contiguous()    # [n, 3] columns of K_X*
+    rank = 40
+    _, m, lik = _model("rbf", X, y, LS, THETA, S2, dev, mean=0.0)
+    with torch.no_grad(), gp.settings.max_cholesky_size(0), gp.settings.max_root_decomposition_size(rank), gp.settings.tridiagonal_jitter(0.0):
+        op = lik(m(X.to(dev))).lazy_covariance_matrix.evaluate_kernel()
+        R = op.root_inv_decomposition(initial_vectors=init.to(dev, torch.float32), test_vectors=test.to(dev, torch.float32)).root
+        with pytest.raises(ValueError, match="test_vectors"):
+            op.root_inv_decomposition(initial_vectors=init.to(dev, torch.float32))
+        with pytest.raises(NotImplementedError):
+            op.root_inv_decomposition(method="pivoted_cholesky")
+        with pytest.raises(RuntimeError, match="cannot be multiplied"):
+            op.root_inv_decomposition(initial_vectors=init[:-1].to(dev, torch.float32), test_vectors=test.to(dev, torch.float32))
+    Ro, idx = OL.root_inv_decomposition_multi(lambda v: Khat @ v, N, rank, init, test)
+    assert idx == 2
+    R = R.double().cpu()
+    assert R.shape == (N, rank)
+    # same decomposition: the approximate solves of the test vectors agree (float32 recurrence against float64: Krylov spaces of 40 steps)
+    sd, so = R @ (R.t() @ test), Ro @ (Ro.t() @ test)
+    assert float((sd - so).norm() / so.norm()) < 2e-2
+    # ... and it is the chosen one, not another candidate: the residual of the returned root is the oracle's minimum
+    res_d = float((Khat @ sd - test).norm(dim=0).sum())
+    res_o = float((Khat @ so - test).norm(dim=0).sum())
+    assert abs(res_d - res_o) < 0.05 * res_o
