@@ -464,12 +464,14 @@ def main():
     barrier()
     t0 = time.perf_counter()
     iters_total = 0
+    iters_all = []
     mll = None
     gen_state = None
     for _ in range(args.steps):
         gen_state = gen.get_state()   # (the untimed step on the other contraction path re-uses the last step's probe draw)
         mll, it = step()
         iters_total += it
+        iters_all.append(it)          # (the stopping iteration varies with the probe draw: 93 .. 109 on the metric configuration)
     barrier()
     elapsed = time.perf_counter() - t0
     if group is not None:
@@ -550,6 +552,7 @@ def main():
                 "ms_per_step": el_o * 1e3,
                 "steps_timed": len(step_ms),
                 "ms_per_step_all": step_ms,
+                "cg_iterations_all": its_o,
                 "ms_per_cg_iteration_all": [a_ / max(b_, 1) for a_, b_ in zip(step_ms, its_o)],
                 "kernel_ms_min_median_max": [live_o[0], live_o[len(live_o) // 2], live_o[-1]],
                 "clock": clk.summary(),
@@ -563,7 +566,9 @@ def main():
                 # three f16 MFMAs per f32-equivalent multiply-add: executed flops against the dense f16 peak
                 ex = 3.0 * flop_per_launch / (ms_o * 1e-3) / 1e12
                 other["roofline"] = {"bound": "mfma", "achieved": ex, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s (f16, executed = 3 x algorithmic)",
-                                     "frac": ex / PEAK_F16_MFMA_TFLOPS, "traffic": split_traffic, "kernel": "kv_gramh_kernel (csrc/kv_gramh.hpp)"}
+                                     "frac": ex / PEAK_F16_MFMA_TFLOPS, "traffic": split_traffic,
+                                     "traffic_source": "from profiles/kv_pmc_split_current.json (recorded constant)" if split_traffic is not None else None,
+                                     "kernel": "kv_gramh_kernel (csrc/kv_gramh.hpp)"}
             if not args.skip_parity:
                 other["parity"] = parity_block(B.prep_points(kind, Xd, lengthscale, shift), X, n, d, cols * T, ls, dev, kind=kind)
 
@@ -586,6 +591,8 @@ def main():
             "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic,
             "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+            "traffic_source": "from profiles/kv_pmc_current.json (rocprofv3 --pmc passes of the builder's sessions on the same kernel and shape: a recorded constant, "
+                              "not measured in this process)" if traffic is not None else None,
             "kernel": f"kv_gram_kernel<{kind},D={d},CT={(cols * T - 1) // 32 if (cols * T) % 32 == 1 else (cols * T + 31) // 32},EX={1 if (cols * T) % 32 == 1 else 0}> on rank 0 (Gram-form generation "
                       "on split-f16 MFMA + fp32 MFMA contraction; kv_mfma_kernel when max|z|^2 > 32)",
             "kernel_ms": kv_ms,
@@ -602,6 +609,7 @@ def main():
             "frac": 3.0 * achieved / PEAK_F16_MFMA_TFLOPS,
             "traffic": split_traffic,
             "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+            "traffic_source": "from profiles/kv_pmc_split_current.json (recorded constant, not measured in this process)" if split_traffic is not None else None,
             "kernel": f"kv_gramh_kernel<{kind},D={d}> on rank 0 (Gram-form generation and hi/lo-split contraction on v_mfma_f32_32x32x16_f16)",
             "kernel_ms": kv_ms,
             "launches_timed": len(live),
@@ -632,6 +640,7 @@ def main():
                                "c5": "BASELINE configs[4], 64 probes split over the ranks, one fused launch with 4 x columns per Kronecker MVM"}[args.config] + ")",
                 "name": args.config, "kind": kind, "tasks": T, "n": n, "d": d, "probes_total": t_total, "probes_rank0": t, "rhs_columns_rank0": cols,
                 "cg_iterations_per_step": iters_total / args.steps,
+                "cg_iterations_all": iters_all,
                 "parallelism": (f"probe-sharded x{world}, y column on rank 0" if R_ == 1 else
                                 f"2-D split: {P_} probe shares x {R_} row blocks, y column on the first share"),
             },

@@ -61,6 +61,9 @@ SIGNATURES = {
     "gpamd_lanczos_coef_f32": (_i, [_p, _i, _i, _f, _p, _p, _p]),
     "gpamd_lanczos_subtract_f32": (_i, [_p, _i64, _i, _p, _p, _i, _p, _p]),
     "gpamd_lanczos_normalize_f32": (_i, [_p, _i, _p, _p, _p, _f, _p, _p]),
+    "gpamd_block_project_f32": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _p, _p, _i64, _p]),
+    "gpamd_block_subtract_f32": (_i, [_p, _i64, _i, _p, _p, _i64, _i, _i, _p]),
+    "gpamd_block_transform_f32": (_i, [_p, _p, _i64, _i, _i, _p]),
     "gpamd_msminres_update_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _p]),
     "gpamd_precond_coef_workspace_doubles": (_i64, [_i, _i, _i]),
     "gpamd_precond_coef_f32f64": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _p, _p, _i64, _p]),
@@ -114,7 +117,7 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if h.gpamd_abi_version() != 3:
+        if h.gpamd_abi_version() != 4:
             raise GpamdError("libgpamd.so ABI version mismatch")
         _lib = h
     return _lib

@@ -107,6 +107,34 @@ int gpamd_precond_apply_f32f64(const float* R, int64_t ldr, int t, const double*
   return lz_check("precond_apply");
 }
 
+// ---- block Lanczos vector work (lanczos_kernels.hpp: pc_coef_kernel<1, float>, lzb_subtract_kernel, lzb_transform_kernel) ----
+int gpamd_block_project_f32(const float* Q, int64_t ldq, int k, const float* R, int64_t ldr, int b, int n, double* W, double* workspace,
+                            int64_t workspace_doubles, void* stream) {
+  if (!Q || !R || !W || !workspace || n <= 0 || b <= 0 || b > LZB_MAXB || k <= 0 || ldq < n || ldr < n) return lz_fail("block_project: bad arguments (b <= 16)");
+  long nb = ((long)n + 255) / 256;
+  if (nb > 256) nb = 256;
+  if (workspace_doubles < (int64_t)nb * b * k) return GPAMD_EWORKSPACE;
+  const int slice = (int)(((long)n + nb - 1) / nb + PC_CHUNK - 1) / PC_CHUNK * PC_CHUNK;
+  nb = ((long)n + slice - 1) / slice;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((pc_coef_kernel<1, float>), dim3((unsigned)nb, (unsigned)((k + 16 * PC_MT - 1) / (16 * PC_MT))), dim3(256), 0, st, R, ldr, b, Q, ldq, k, n,
+                     slice, workspace);
+  hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((b * k + 255) / 256), dim3(256), 0, st, (const double*)workspace, (int)nb, b * k, W);
+  return lz_check("block_project");
+}
+
+int gpamd_block_subtract_f32(const float* Q, int64_t ldq, int k, const double* W, float* R, int64_t ldr, int b, int n, void* stream) {
+  if (!Q || !R || !W || n <= 0 || b <= 0 || b > LZB_MAXB || k <= 0 || ldq < n || ldr < n) return lz_fail("block_subtract: bad arguments (b <= 16)");
+  hipLaunchKernelGGL(lzb_subtract_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Q, ldq, k, W, R, ldr, b, n);
+  return lz_check("block_subtract");
+}
+
+int gpamd_block_transform_f32(const double* M, float* R, int64_t ldr, int b, int n, void* stream) {
+  if (!M || !R || n <= 0 || b <= 0 || b > LZB_MAXB || ldr < n) return lz_fail("block_transform: bad arguments (b <= 16)");
+  hipLaunchKernelGGL(lzb_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, R, ldr, b, n);
+  return lz_check("block_transform");
+}
+
 int gpamd_msminres_update_f32(const float* v, const float* d1, float* d2, float* x, const float* coef, int Q, int t, int n, int64_t ld,
                               void* stream) {
   if (!v || !d1 || !d2 || !x || !coef || Q <= 0 || t <= 0 || n <= 0 || ld < n || ld % 4 || Q > 65535 || t > 65535)

@@ -121,13 +121,16 @@ namespace gpamd {
 constexpr int PC_CHUNK = 32;
 constexpr int PC_MT = 8;      // k <= 128
 
-template <int CT>  // t <= 16 * CT
-__global__ __launch_bounds__(256) void pc_coef_kernel(const float* __restrict__ R, int64_t ldr, int t, const double* __restrict__ Q,
+// TQ: type of the basis rows (double: the preconditioner's Q1; float: the Lanczos basis of the block recurrences below).  blockIdx.y selects a
+// tile of 128 basis rows, so k is unbounded for callers that launch a second grid dimension (the preconditioner launches one: k <= 128).
+template <int CT, typename TQ = double>  // t <= 16 * CT
+__global__ __launch_bounds__(256) void pc_coef_kernel(const float* __restrict__ R, int64_t ldr, int t, const TQ* __restrict__ Q,
                                                       int64_t ldq, int k, int n, int slice, double* __restrict__ part) {
   __shared__ float Rs[16 * CT][PC_CHUNK + 1];
-  __shared__ double Qs[16 * PC_MT][PC_CHUNK + 1];
+  __shared__ TQ Qs[16 * PC_MT][PC_CHUNK + 1];
   const int tid = threadIdx.x, tc = tid >> 4, tm = tid & 15;
   const int i0 = blockIdx.x * slice, i1 = min(n, i0 + slice);
+  const int m0 = blockIdx.y * (16 * PC_MT), kt = min(16 * PC_MT, k - m0);   // this block's basis rows [m0, m0 + kt)
   double acc[CT][PC_MT];
 #pragma unroll
   for (int a = 0; a < CT; ++a)
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void pc_coef_kernel(const float* __restrict__ 
     }
     for (int e = tid; e < 16 * PC_MT * PC_CHUNK; e += 256) {
       const int m = e / PC_CHUNK, ii = e % PC_CHUNK;
-      Qs[m][ii] = (m < k && ib + ii < i1) ? Q[(int64_t)m * ldq + ib + ii] : 0.0;
+      Qs[m][ii] = (m < kt && ib + ii < i1) ? Q[(int64_t)(m0 + m) * ldq + ib + ii] : TQ(0);
     }
     __syncthreads();
 #pragma unroll 4
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void pc_coef_kernel(const float* __restrict__ 
 #pragma unroll
       for (int a = 0; a < CT; ++a) rv[a] = (double)Rs[tc + 16 * a][ii];
 #pragma unroll
-      for (int b = 0; b < PC_MT; ++b) qv[b] = Qs[tm + 16 * b][ii];
+      for (int b = 0; b < PC_MT; ++b) qv[b] = (double)Qs[tm + 16 * b][ii];
 #pragma unroll
       for (int a = 0; a < CT; ++a)
 #pragma unroll
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void pc_coef_kernel(const float* __restrict__ 
 #pragma unroll
     for (int b = 0; b < PC_MT; ++b) {
       const int c = tc + 16 * a, m = tm + 16 * b;
-      if (c < t && m < k) out[(int64_t)c * k + m] = acc[a][b];
+      if (c < t && m < kt) out[(int64_t)c * k + m0 + m] = acc[a][b];
     }
 }
 
@@ -204,6 +207,60 @@ __global__ __launch_bounds__(256) void pc_apply_kernel(const float* __restrict__
 #pragma unroll
   for (int c = 0; c < PA_CT; ++c)
     if (c < nc) Out[(int64_t)(c0 + c) * ldo + i] = (float)(((double)R[(int64_t)(c0 + c) * ldr + i] - acc[c]) * inv);
+}
+
+// ---- BLOCK Lanczos (lanczos.py block_lanczos_steps: the LOVE cache on a block Krylov space; b <= 16 rows per block, any number k of basis rows) ----
+// project : W[c][m] = <R[c], Q[m]>      = pc_coef_kernel<1, float> over k tiles of 128 (double accumulation, partials summed in a fixed order)
+// subtract: R[c][i] -= sum_m W[c][m] Q[m][i]      (in place, double arithmetic; W of a 128-row tile of the basis in LDS, every Q element read once)
+// transform: R[r][i] = sum_c M[r][c] R[c][i]      (in place; M: b x b double -- the inverse Cholesky factor of the block's Gram matrix: Cholesky-QR)
+constexpr int LZB_MAXB = 16;
+__global__ __launch_bounds__(256) void lzb_subtract_kernel(const float* __restrict__ Q, int64_t ldq, int k, const double* __restrict__ W, float* R,
+                                                          int64_t ldr, int b, int n) {
+  __shared__ double Ws[LZB_MAXB * 128];   // [c][m] of the current basis tile
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double acc[LZB_MAXB];
+#pragma unroll
+  for (int c = 0; c < LZB_MAXB; ++c) acc[c] = 0.0;
+  for (int m0 = 0; m0 < k; m0 += 128) {
+    const int kt = min(128, k - m0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < b * kt; e += 256) Ws[(e / kt) * 128 + (e % kt)] = W[(int64_t)(e / kt) * k + m0 + (e % kt)];
+    for (int e = threadIdx.x; e < (LZB_MAXB - b) * 128; e += 256) Ws[b * 128 + e] = 0.0;
+    __syncthreads();
+    if (i < n) {
+      for (int m = 0; m < kt; ++m) {
+        const double q = (double)Q[(int64_t)(m0 + m) * ldq + i];
+#pragma unroll
+        for (int c = 0; c < LZB_MAXB; ++c) acc[c] = fma(Ws[c * 128 + m], q, acc[c]);
+      }
+    }
+  }
+  if (i < n) {
+#pragma unroll
+    for (int c = 0; c < LZB_MAXB; ++c)
+      if (c < b) R[(int64_t)c * ldr + i] = (float)((double)R[(int64_t)c * ldr + i] - acc[c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void lzb_transform_kernel(const double* __restrict__ M, float* R, int64_t ldr, int b, int n) {
+  __shared__ double Ms[LZB_MAXB * LZB_MAXB];
+  for (int e = threadIdx.x; e < b * b; e += 256) Ms[e] = M[e];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double v[LZB_MAXB];
+#pragma unroll
+  for (int c = 0; c < LZB_MAXB; ++c) v[c] = c < b ? (double)R[(int64_t)c * ldr + i] : 0.0;
+#pragma unroll
+  for (int r = 0; r < LZB_MAXB; ++r) {
+    if (r < b) {
+      double o = 0.0;
+#pragma unroll
+      for (int c = 0; c < LZB_MAXB; ++c)
+        if (c < b) o = fma(Ms[r * b + c], v[c], o);
+      R[(int64_t)r * ldr + i] = (float)o;
+    }
+  }
 }
 
 // ---- multi-shift MINRES (contour-integral quadrature, gpytorch/__init__.py:252-278 -> linear_operator.utils.minres): the vector part of one

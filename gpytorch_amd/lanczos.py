@@ -323,36 +323,83 @@ def block_lanczos_steps(n: int, dev, steps: int, init_t: torch.Tensor):
     Q = torch.zeros(m_max, ld, device=dev, dtype=wd)
     H = torch.zeros(m_max, m_max, device=dev, dtype=torch.float64)
     infos = []
+    defl = (100.0 * torch.finfo(wd).eps) ** 2
+    native = wd == torch.float32 and torch.device(dev).type == "cuda" and b <= 16 and not FORCE_TORCH
+    if native:
+        # vector work on the gpamd_block_* kernels (csrc/lanczos_kernels.hpp): float32 rows, float64 accumulation, every basis element read once per
+        # pass (rocBLAS' tall-skinny float64 GEMMs -- the b x n x b Gram matrix -- cost tens of ms per call: profiles/r05_s1_love_block_timing_c2_torch.json,
+        # 36 ms per step at n = 100 000 where the eight-column product itself takes 2)
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        L, st, p = lib(), B._stream(dev), B._ptr
+        ws = torch.empty(max(int(L.gpamd_precond_coef_workspace_doubles(n, b, m_max)), 1), device=dev, dtype=torch.float64)
+        eye = torch.eye(b, device=dev, dtype=torch.float64)
+
+        def project(basis, k, R):
+            Wc = torch.empty(b, k, device=dev, dtype=torch.float64)
+            check(L.gpamd_block_project_f32(p(basis), basis.stride(0), k, p(R), R.stride(0), b, n, p(Wc), p(ws), ws.numel(), st), "block_project")
+            return Wc
+
+        def subtract(basis, k, Wc, R):
+            check(L.gpamd_block_subtract_f32(p(basis), basis.stride(0), k, p(Wc), p(R), R.stride(0), b, n, st), "block_subtract")
+
+        def chol_qr(R):
+            G = project(R, b, R)                                           # R R^T (float64 accumulation)
+            G = 0.5 * (G + G.t())
+            Lc, inf = torch.linalg.cholesky_ex(G)
+            Minv = torch.linalg.solve_triangular(Lc, eye, upper=False).contiguous()
+            check(L.gpamd_block_transform_f32(p(Minv), p(R), R.stride(0), b, n, st), "block_transform")
+            return inf, G.diagonal(), Lc.diagonal() ** 2
+    else:
+        def project(basis, k, R):
+            return (R[:, :n] @ basis[:k, :n].t()).to(torch.float64)
+
+        def subtract(basis, k, Wc, R):
+            R[:, :n] -= Wc.to(wd) @ basis[:k, :n]
+
+        def chol_qr(R):
+            R64 = R[:, :n].to(torch.float64)
+            G = R64 @ R64.t()
+            Lc, inf = torch.linalg.cholesky_ex(G)
+            R[:, :n] = torch.linalg.solve_triangular(Lc, R64, upper=False).to(wd)
+            return inf, G.diagonal(), Lc.diagonal() ** 2
 
     def orthonormalise(R, k):
-        """Rows of R made orthonormal and orthogonal to Q[:k]; two passes ("twice is enough")."""
-        info = None
-        for _ in range(2):
+        """Rows of R (modified in place) made orthonormal and orthogonal to Q[:k]; two passes ("twice is enough").  Returns the projection
+        coefficients of the FIRST pass ([b, k] float64: the column block of Q A Q^T when R = A Q_s) or None."""
+        info, first = None, None
+        for it in range(2):
             if k:
-                R = R - (R[:, :n] @ Q[:k, :n].t()) @ Q[:k]
-            R64 = R[:, :n].to(torch.float64)
-            Lc, inf = torch.linalg.cholesky_ex(R64 @ R64.t())
+                Wc = project(Q, k, R)
+                subtract(Q, k, Wc, R)
+                first = Wc if it == 0 else first
+            inf, g_diag, l_diag2 = chol_qr(R)
+            if it == 0:
+                # deflation: a row whose part orthogonal to everything before it (earlier blocks AND earlier rows of this block: the Cholesky pivot) is
+                # rounding noise relative to the row itself (|w_c|^2 = |coefficients|^2 + |residual|^2) -- the block Krylov space is exhausted
+                wn2 = g_diag if first is None else g_diag + (first * first).sum(-1)
+                inf = torch.maximum(inf, (l_diag2 < defl * wn2).any().to(inf.dtype))
             info = inf if info is None else torch.maximum(info, inf)
-            R = torch.zeros_like(R)
-            R[:, :n] = torch.linalg.solve_triangular(Lc, R64, upper=False).to(wd)
         infos.append(info)
-        return R
+        return first
 
     R0 = init_t.clone()
     if ld > n:
         R0[:, n:] = 0
-    Q[:b] = orthonormalise(R0, 0)
+    orthonormalise(R0, 0)
+    Q[:b] = R0
     for s in range(steps):
         k = (s + 1) * b
         W = yield Q[k - b : k]
-        W = W if W.dtype == wd else W.to(wd)
-        Cf = Q[:k, :n] @ W[:, :n].t()                    # [k, b]: column block s of Q A Q^T down to its diagonal block
-        H[:k, k - b : k] = Cf.to(torch.float64)
+        R = torch.zeros(b, ld, device=dev, dtype=wd)
+        R[:, :n] = W[:, :n]
         if s + 1 == steps:
+            H[:k, k - b : k] = project(Q, k, R).t()
             break
-        R = torch.zeros_like(Q[:b])
-        R[:, :n] = W[:, :n] - Cf.t() @ Q[:k, :n]
-        Q[k : k + b] = orthonormalise(R, k)
+        H[:k, k - b : k] = orthonormalise(R, k).t()
+        Q[k : k + b] = R
     bad = [i for i, v in enumerate(torch.stack(infos).reshape(-1).tolist()) if v]       # the one host synchronisation
     m = m_max if not bad else bad[0] * b
     if m == 0:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GPAMD_ABI_VERSION 3
+#define GPAMD_ABI_VERSION 4
 
 /* covariance families: gpytorch/kernels/rbf_kernel.py:68-85, matern_kernel.py:85-110 (nu = 1/2, 3/2, 5/2) */
 enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3,
@@ -33,7 +33,8 @@ enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3
 /* `kparam`: shape parameter of the parametrised covariance families (RQ: alpha > 0; ignored by the others), an EXPLICIT argument of
  * every entry point that evaluates the covariance or prepares points for it (ABI version 2: the library holds no per-thread kernel
  * state, so operators with different alpha may interleave freely on one thread -- AdditiveKernel(RQ, RQ)).  ABI version 3: the
- * float64 / generic entry points take it too (`double kparam`), so the family runs on every path. */
+ * float64 / generic entry points take it too (`double kparam`), so the family runs on every path.  ABI version 4 (additive): the block-Lanczos
+ * vector entry points gpamd_block_{project,subtract,transform}_f32, and fused float32 kernels for input dimensions up to 32 (was 16). */
 
 enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 
@@ -196,6 +197,18 @@ int gpamd_lanczos_project_f32(const float* Q, int64_t ldq, int k, const float* r
 int gpamd_lanczos_coef_f32(const float* part, int k, int nb, float tol, float* coef, int* flag, void* stream);
 int gpamd_lanczos_subtract_f32(const float* Q, int64_t ldq, int k, const float* coef, float* r, int n, float* part_rr, void* stream);
 int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* out, float* norm_out, float tiny, int* stop, void* stream);
+
+/* ---- BLOCK Lanczos with full re-orthogonalisation: the vector work of one step for a block of b <= 16 probe-major rows R [b][ldr] against a basis
+ * Q [k][ldq] of ANY length k (float32 vectors, float64 accumulation).  Behind LinearOperator.root_inv_decomposition (the LOVE covar_cache,
+ * gpytorch/models/exact_prediction_strategies.py:267-272) and the multi-vector form of gpytorch.root_inv_decomposition (gpytorch/__init__.py:190-216): the b
+ * vectors ride through ONE b-column gpamd_kv_partials_f32 per step instead of b single-column products.
+ *   project  : W[c][m] = <R[c], Q[m]>                  W: double [b][k]; workspace: double[gpamd_precond_coef_workspace_doubles(n, b, k)]
+ *   subtract : R[c] -= sum_m W[c][m] Q[m]              (in place)
+ *   transform: R[r] = sum_c M[r][c] R[c]               (in place; M: double [b][b], e.g. the inverse Cholesky factor of R R^T: Cholesky-QR) ---- */
+int gpamd_block_project_f32(const float* Q, int64_t ldq, int k, const float* R, int64_t ldr, int b, int n, double* W, double* workspace,
+                            int64_t workspace_doubles, void* stream);
+int gpamd_block_subtract_f32(const float* Q, int64_t ldq, int k, const double* W, float* R, int64_t ldr, int b, int n, void* stream);
+int gpamd_block_transform_f32(const double* M, float* R, int64_t ldr, int b, int n, void* stream);
 
 /* ---- multi-shift MINRES (contour-integral quadrature: gpytorch.sqrt_inv_matmul, gpytorch/__init__.py:252-278 ->
  * linear_operator.utils.minres; consumer variational/ciq_variational_strategy.py:217): the vector part of ONE iteration for all Q shifts:

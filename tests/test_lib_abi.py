@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
     for name in declared:
         assert hasattr(h, name), f"{name} declared in gpamd.h but not exported"
     assert sorted(SIGNATURES) == declared, "ctypes table and gpamd.h disagree"
-    assert h.gpamd_abi_version() == 3
+    assert h.gpamd_abi_version() == 4
 
 
 def test_library_exports_nothing_beyond_the_header():
