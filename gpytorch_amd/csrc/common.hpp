@@ -133,9 +133,11 @@ template <int KIND> __device__ __forceinline__ double dcov_any(double s, double 
 // Round 4: the fence must carry DATA dependencies.  `sched_barrier` only binds the machine scheduler; the MFMA builtins are pure
 // functions of their operands, so the IR-level passes that run before it (code sinking, instruction combining) are free to move an MFMA
 // BELOW a fence that merely sits between it and its reader in the source -- and did: in kv_grad2_kernel<RBF, 3, 0, WSPLIT> the last W MFMA
-// and the second Gram MFMA of every j step were emitted AFTER the wait states, back on the compiler's (insufficient) hazard table, which
-// is where the 1e-3 .. 4e-3 deviations of the split backward at n = 500 000 came from (a full chip, three waves per SIMD sharing the
-// matrix pipe; invisible at n <= 2048).  `mfma_result_fence(regs...)` therefore ties every result register to the wait states: an empty
+// and the second Gram MFMA of every j step were emitted AFTER the wait states, back on the compiler's hazard table.  (That was found while
+// chasing the 1e-3 .. 4e-3 deviation of the split backward at n = 500 000 and is NOT what caused it: builds with and without the ties give
+// bitwise the same sums there, profiles/r04_s1_*, r04_s2_*; the deviation was the round-down accumulation of the f16 matrix pipe, kv_wsplit.hpp.
+// It is still exactly the class of defect that produced the 4 % errors above, so the fence closes it by construction.)
+// `mfma_result_fence(regs...)` ties every result register to the wait states: an empty
 // volatile asm with a "+v" operand BEFORE the s_nops (the producing MFMA must precede it), the same AFTER them (every reader must follow it);
 // volatile asms keep their program order among themselves.  The zero-argument form remains for the epilogues of the AGPR-destination
 // kernels (kv_gram, kv_gramh, kv_mfma, kv_f64), whose v_accvgpr_read IS interlocked.
