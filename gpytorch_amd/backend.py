@@ -14,7 +14,8 @@ from ._lib import check, lib
 
 KIND_IDS = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3, "rq": 4}
 NU_TO_KIND = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}
-MAX_INPUT_DIM = 16
+MAX_INPUT_DIM = 32          # fused float32 kernels: 1 .. 32 input dimensions (csrc/kv_dispatch.hpp KV_MAX_DIM; 16 until round 5)
+MAX_GRAD2_ARD_DIM = 16      # per-dimension sums / input gradients of the Gram-form derivative kernel (kv_grad2.hpp MODE 1) exist up to here
 
 
 def _ptr(t):
@@ -37,7 +38,8 @@ def round_up(x: int, m: int) -> int:
 
 
 def padded_dim(d: int) -> int:
-    return round_up(d, 4)
+    """Row stride of a prepared cloud: 4 * ceil(d / 4), except 25 .. 32 dimensions, which share the D = 32 kernels (stride 32)."""
+    return 32 if 24 < d <= 32 else round_up(d, 4)
 
 
 def work_dtype(t: torch.Tensor) -> torch.dtype:
@@ -89,7 +91,7 @@ class PreparedPoints:
 
     @property
     def fused(self) -> bool:
-        """True when the fused float32 MFMA / VALU kernels apply (float32, d <= 16); otherwise products go through
+        """True when the fused float32 MFMA / VALU kernels apply (float32, d <= 32); otherwise products go through
         the generic path: HIP-generated dense row blocks of K times V with a library GEMM (``kv_chunked``)."""
         return self.xp.dtype == torch.float32 and self.d <= MAX_INPUT_DIM and not FORCE_GENERIC
 

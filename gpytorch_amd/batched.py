@@ -135,7 +135,7 @@ def members_stackable(ops) -> bool:
                 and settings.max_cholesky_size.value() >= 800 and settings.fast_computations.log_prob.on()):
             return False   # (a max_cholesky_size LOWERED by the user -- e.g. 0 to force mBCG -- is respected)
     k0 = o0.kernel_op
-    if B.work_dtype(k0.x1) != torch.float32 or k0.x1.shape[-1] > B.MAX_INPUT_DIM or not k0.x1.is_cuda:
+    if B.work_dtype(k0.x1) != torch.float32 or k0.x1.shape[-1] > 16 or not k0.x1.is_cuda:   # (csrc/extra_batch.hip GB_MAXDP: the stacked kernels hold a point in 16 registers)
         return False
     for o in ops:
         if type(o) is not FusedKernelAddedDiagLinearOperator or (o.noise_vec is None) != (o0.noise_vec is None):

@@ -95,10 +95,10 @@ KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool
     v.ct = (t - v.ex + 31) / 32;
     // four row tiles per wave with two column tiles ("lean", kv_gramh.hpp) where they fit: one Gram MFMA per block (dk <= 3) and, with the extra
     // column, the light generation of the RBF only (the other families would spill 7..15 registers there)
-    v.ni = small ? 1 : kgh_ni(v.ct, (v.ex && !light) ? 16 : dk);
+    v.ni = small ? 1 : kgh_ni(v.ct, (v.ex && !light && dk <= 16) ? 16 : dk);
     v.bm = kgh_bm(v.ni);
     v.bn = KGH_BN;
-  } else if (gram && !wide && t >= 5 && t <= 24) {
+  } else if (gram && !wide && t >= 5 && t <= 24 && dk <= 16) {   // (beyond 16 dimensions: no 4-column / 16-column tile kernels -- kv_gramv up to 16 columns, the 32-column tile above)
     if (t <= 8) v.g4 = 2;
     else if (t <= 12 && (flags & GPAMD_KV_G4)) v.g4 = 3;
     else if (t <= 16) v.g4 = 16;   // kv_gram16
@@ -124,7 +124,7 @@ KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool
       v.ct = (t + 31) / 32;
       v.ex = 0;
     }
-    v.bm = kv_bm_for_ct(v.ct);
+    v.bm = kv_bm_for_ct(v.ct, dk);
     v.bn = KV_BN;
   }
   return v;
@@ -172,9 +172,7 @@ SplitLayout split_layout(int kind, int flags, int m, int t, int S, int64_t ldo) 
   return L;
 }
 
-int kernel_dims(int d) {  // kernels exist for these valid-dimension counts; other d use the next one
-  return d <= 6 ? d : (d <= 8 ? 8 : (d <= 10 ? 10 : (d <= 12 ? 12 : 16)));
-}
+int kernel_dims(int d) { return kv_kernel_dims(d); }  // kernels exist for these valid-dimension counts; other d use the next one
 
 const void* family_ptr(int kind, int mode, int d, int v, int ex, int ni = 0) {
   if (mode == KV_MODE_GRAMH) {
@@ -313,7 +311,7 @@ int gpamd_prep_points_f32(int kind, float kparam, const float* X, int n, int d, 
 
 int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, int* S_host, int* jchunk_host,
                   int64_t* workspace_floats_host) {
-  if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return fail(GPAMD_EINVAL, "kv_plan: bad shape");
+  if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > KV_MAX_DIM) return fail(GPAMD_EINVAL, "kv_plan: bad shape");
   int S, jc;
   plan_split(kind, n, m, d, t, flags, &S, &jc);
   if (S_host) *S_host = S;
@@ -330,8 +328,8 @@ int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const
                           void* stream) {
   if (kind < 0 || kind > GPAMD_RQ) return fail(GPAMD_EINVAL, "kv: unknown kind");
   if (n <= 0 || m <= 0 || t <= 0 || S <= 0) return fail(GPAMD_EINVAL, "kv: bad shape");
-  if (d < 1 || d > 16) return fail(GPAMD_EUNSUPPORTED, "kv: input dimension must be in 1..16");
-  // kernels are instantiated for D in {1,2,3,4,5,6,8,10,12,16} valid dimensions; other d use the next one
+  if (d < 1 || d > KV_MAX_DIM) return fail(GPAMD_EUNSUPPORTED, "kv: input dimension must be in 1..32");
+  // kernels are instantiated for D in {1,2,3,4,5,6,8,10,12,16,20,24,32} valid dimensions; other d use the next one
   // (same padded stride, the extra coordinates are the zeros written by prep_points)
   const int dk = kernel_dims(d);
   if (ldv % 4 || ldv < m || ldo < n) return fail(GPAMD_EINVAL, "kv: leading dimensions must be >= extent and ldv % 4 == 0");
@@ -411,7 +409,7 @@ int gpamd_kv_f32(int kind, float kparam, const float* X1p, int n, const float* X
                  int t, const float* scale, const float* dscale, const float* Vd, int64_t ldd, float* Out,
                  int64_t ldo, float* workspace, int64_t workspace_floats, int flags, void* stream) {
   int S, jc;
-  if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return fail(GPAMD_EINVAL, "kv: bad shape");
+  if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > KV_MAX_DIM) return fail(GPAMD_EINVAL, "kv: bad shape");
   plan_split(kind, n, m, d, t, flags, &S, &jc);
   const int64_t ldp = (n + 3) / 4 * 4;
   const SplitLayout L = split_layout(kind, flags, m, t, S, ldp);

@@ -56,7 +56,7 @@ int launch_grad(int dp, const GradArgs& a, unsigned grid, size_t lds, hipStream_
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);                                                 \
     return 0;                                                                                                   \
   }
-  switch (dp) { L(4) L(8) L(12) L(16) }
+  switch (dp) { L(4) L(8) L(12) L(16) L(20) L(24) L(32) }
 #undef L
   return -2;
 }
@@ -79,7 +79,7 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
     snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad: bad arguments");
     return GPAMD_EINVAL;
   }
-  if (dp != 4 && dp != 8 && dp != 12 && dp != 16) return GPAMD_EUNSUPPORTED;
+  if (dp != 4 && dp != 8 && dp != 12 && dp != 16 && dp != 20 && dp != 24 && dp != 32) return GPAMD_EUNSUPPORTED;
   int S, jc, nrb;
   grad_plan(n, m, &S, &jc, &nrb);
   const int groups = (t + GRAD_TGROUP - 1) / GRAD_TGROUP;

@@ -8,8 +8,14 @@ enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3, 
 
 // MFMA / Gram variants: CT 32-column tiles (1..4) + EX extra VALU column; NI row tiles per wave by CT.
 // NI*CT*16 accumulator registers: 64 (CT <= 2) .. 128 (CT = 4)
-constexpr int kv_ni_for_ct(int ct) { return ct == 1 ? 4 : 2; }
-inline int kv_bm_for_ct(int ct) { return 4 * kv_ni_for_ct(ct) * 32; }
+// (beyond 16 dimensions a wave's own points -- NI rows of D coordinates or KH split operands each -- leave no room for four row tiles: two everywhere)
+constexpr int KV_MAX_DIM = 32;          // fused float32 kernels exist for 1 .. 32 input dimensions (ABI version 4; 16 before)
+constexpr int kv_ni_for_ct(int ct, int dk = 16) { return (ct == 1 && dk <= 16) ? 4 : 2; }
+inline int kv_bm_for_ct(int ct, int dk = 16) { return 4 * kv_ni_for_ct(ct, dk) * 32; }
+// kernels exist for these valid-dimension counts; other d use the next one (the extra coordinates are the zeros written by prep_points)
+constexpr int kv_kernel_dims(int d) {
+  return d <= 6 ? d : (d <= 8 ? 8 : (d <= 10 ? 10 : (d <= 12 ? 12 : (d <= 16 ? 16 : (d <= 20 ? 20 : (d <= 24 ? 24 : 32))))));
+}
 
 const void* kv_kernel_ptr_rbf(int mode, int d, int v, int ex);
 const void* kv_kernel_ptr_matern12(int mode, int d, int v, int ex);

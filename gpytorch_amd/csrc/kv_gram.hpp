@@ -34,7 +34,8 @@ namespace gpamd {
 template <int KIND, int D, int CT, int NI, int EX>
 // (CT = 1 runs four row tiles per wave: 64 accumulators + 64 distance registers do not fit 168 registers -- 6..44 spilled, and with the extra
 // column the Matern-3/2 / RQ instantiations returned wrong rows on a full chip, tests/test_gpu_kv.py regression sweep -> two waves there)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 2 || (CT == 1 && NI < 4)) ? 3 : 2, (CT == 2 || (CT == 1 && NI < 4)) ? 3 : 2)))
+// (beyond 16 dimensions the split x_i operands -- NI * KH * 4 registers, KH = 4 .. 7 -- take the room of the third wave: two waves per SIMD)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((CT == 2 || (CT == 1 && NI < 4)) && D <= 16) ? 3 : 2, ((CT == 2 || (CT == 1 && NI < 4)) && D <= 16) ? 3 : 2)))
 void kv_gram_kernel(KvArgs a) {
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
   constexpr int KH = GramF16<D>::KH;    // 32x32x16 f16 MFMAs per 32x32 block of squared distances

@@ -42,7 +42,7 @@ constexpr int KGH_VEXP = 14;            // max |V_c| * scale_c in [2^13, 2^14)
 constexpr int KGH_GROUP = 64;           // columns per launch group (+ 1 extra VALU column)
 constexpr int KGH_SMALL_N = 16384;      // fewer output rows: one row tile per wave (NI = 1), four times as many workgroups
 constexpr int KGH_MIN_COLS = 5;         // fewer columns: the VALU-contraction kernel (kv_gramv.hpp) wins
-constexpr int kgh_ni(int ct, int d = 16) { return (ct == 1 || d <= 3) ? 4 : 2; }   // 32-row tiles per wave: 16 NI CT accumulators (d: kernel dims)
+constexpr int kgh_ni(int ct, int d = 16) { return d > 16 ? 2 : ((ct == 1 || d <= 3) ? 4 : 2); }   // 32-row tiles per wave: 16 NI CT accumulators (d: kernel dims)
 inline int kgh_bm(int ni) { return 4 * ni * 32; }
 
 struct KvhArgs {
@@ -82,8 +82,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // (The ablation and geometry variants this loop was measured through -- no generation / no MFMAs / staged once / no barriers, one or three
 // waves per SIMD, eight waves per workgroup, register prefetch of the next tile, a deeper Gram look-ahead -- live in tune/kv_gramh_ablate.hpp
 // and libgpamd_tune.so; DESIGN.md 3.1b has the numbers.)
+// (beyond 20 dimensions: KH >= 5 Gram MFMAs per block -- the split x_i / x_j operands no longer fit 256 registers next to 64 accumulators, and the two
+// Xh buffers push the LDS image past half a CU: ONE wave per SIMD with the whole register file instead of 46 .. 94 spilled registers)
+template <int D>
+constexpr int kgh_waves() { return D > 20 ? 1 : 2; }
 template <int KIND, int D, int CT, int NI, int EX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kgh_waves<D>(), kgh_waves<D>())))
 void kv_gramh_kernel(KvhArgs ka) {
   constexpr int NW = 4, NT = 64 * NW;   // four waves per workgroup: row block = NW * NI * 32 rows sharing one staged V tile
   const KvArgs& a = ka.a;

@@ -78,7 +78,7 @@ void g2_plan(int n, int m, int* S, int* jchunk, int* nrb) {
   *S = (m + jc - 1) / jc;
 }
 
-int kdims(int d) { return d <= 6 ? d : (d <= 8 ? 8 : (d <= 10 ? 10 : (d <= 12 ? 12 : 16))); }
+int kdims(int d) { return d <= 6 ? d : (d <= 8 ? 8 : (d <= 10 ? 10 : (d <= 12 ? 12 : (d <= 16 ? 16 : (d <= 20 ? 20 : (d <= 24 ? 24 : 32)))))); }
 
 template <int KIND, int D>
 size_t g2_lds(int rs, int mode) {
@@ -94,6 +94,8 @@ int launch_d(int mode, const Grad2Args& a, unsigned grid, hipStream_t st) {
     auto kfn = kv_grad2_kernel<KIND, D, 0>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
+  } else if constexpr (D > 16) {
+    return -2;   // per-dimension sums / input gradients beyond 16 dimensions: the caller's row-block path (backend.kv_grad_generic)
   } else {
     auto kfn = kv_grad2_kernel<KIND, D, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -115,6 +117,9 @@ int launch_kind(int dk, int mode, const Grad2Args& a, unsigned grid, hipStream_t
     case 10: return launch_d<KIND, 10>(mode, a, grid, st);
     case 12: return launch_d<KIND, 12>(mode, a, grid, st);
     case 16: return launch_d<KIND, 16>(mode, a, grid, st);
+    case 20: return launch_d<KIND, 20>(mode, a, grid, st);
+    case 24: return launch_d<KIND, 24>(mode, a, grid, st);
+    case 32: return launch_d<KIND, 32>(mode, a, grid, st);
   }
   return -2;
 }
@@ -123,7 +128,7 @@ int launch_kind(int dk, int mode, const Grad2Args& a, unsigned grid, hipStream_t
 extern "C" {
 
 int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d) {
-  if (n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return 0;
+  if (n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 32) return 0;
   int S, jc, nrb;
   g2_plan(n, m, &S, &jc, &nrb);
   const int dp = (d + 3) / 4 * 4;
@@ -131,7 +136,7 @@ int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d) {
 }
 
 int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d) {
-  if (n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 16) return 0;
+  if (n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 32) return 0;
   int S, jc, nrb;
   g2_plan(n, m, &S, &jc, &nrb);
   const int dp = (d + 3) / 4 * 4;
@@ -148,7 +153,7 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
                        const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
                        int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, int flags, float* sworkspace,
                        int64_t sworkspace_floats, void* stream) {
-  if (n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m || d < 1 || d > 16) {
+  if (n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m || d < 1 || d > 32) {
     snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: bad arguments");
     return GPAMD_EINVAL;
   }

@@ -19,6 +19,8 @@ int launch_d(int mode, const Grad2Args& a, unsigned grid, hipStream_t st) {
     auto kfn = kv_grad2_kernel<KIND, D, 0, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
+  } else if constexpr (D > 16) {
+    return -2;   // per-dimension sums / input gradients beyond 16 dimensions: the caller's row-block path (backend.kv_grad_generic)
   } else {
     auto kfn = kv_grad2_kernel<KIND, D, 1, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -40,6 +42,9 @@ int launch_kind(int dk, int mode, const Grad2Args& a, unsigned grid, hipStream_t
     case 10: return launch_d<KIND, 10>(mode, a, grid, st);
     case 12: return launch_d<KIND, 12>(mode, a, grid, st);
     case 16: return launch_d<KIND, 16>(mode, a, grid, st);
+    case 20: return launch_d<KIND, 20>(mode, a, grid, st);
+    case 24: return launch_d<KIND, 24>(mode, a, grid, st);
+    case 32: return launch_d<KIND, 32>(mode, a, grid, st);
   }
   return -2;
 }

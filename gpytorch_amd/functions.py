@@ -49,7 +49,11 @@ def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t, want_x1=Fal
     ls = lengthscale.detach().to(wd).reshape(-1)
     iso = ls.numel() == 1
     gz1 = gz2 = None
-    if B.grad_gram_ok(xp1, xp2):
+    want_x = want_x1 or want_x2
+    # beyond 16 dimensions the Gram-form derivative kernel exists for ONE lengthscale without input gradients (kv_grad2.hpp MODE 0: its work does not
+    # grow with d); per-dimension sums take the direct-difference kernel, input gradients the row-block path
+    per_dim_ok = xp1.d <= B.MAX_GRAD2_ARD_DIM or (iso and not want_x)
+    if B.grad_gram_ok(xp1, xp2) and per_dim_ok:
         g, gz1 = B.kv_grad2(xp1, xp2, left_t, right_t, iso=iso, want_gz1=want_x1)
         if want_x2:  # the same kernel with the roles of the two clouds exchanged
             # gram_mode is not symmetric (it needs a compact sorted view of its FIRST cloud): the exchanged call has its own check
@@ -59,15 +63,22 @@ def hyper_grads(xp1, xp2, lengthscale, outputscale, left_t, right_t, want_x1=Fal
                     "k(x2, x1) is outside its accuracy policy (backend.gram_mode(x2, x1) == 0: x2 too small or too wide for the block-centred expansion)"
                 )
             _, gz2 = B.kv_grad2(xp2, xp1, right_t, left_t, iso=iso, want_gz1=True)
+    elif want_x and xp1.fused and xp2.fused and not per_dim_ok:
+        # 17 .. 32 dimensions with input gradients: dense row blocks (HIP generation + library GEMMs, float64 sums), both roles
+        g, gz1 = B.kv_grad_generic(xp1, xp2, left_t, right_t, want_gz1=True)
+        g = g.to(wd)
+        gz1 = gz1.to(wd) if want_x1 else None
+        if want_x2:
+            gz2 = B.kv_grad_generic(xp2, xp1, right_t, left_t, want_gz1=True)[1].to(wd)
     else:
-        if want_x1 or want_x2:
+        if want_x:
             raise RuntimeError(
                 "gradients with respect to the inputs need the Gram-form derivative kernel (float32, d <= 16, RBF / Matern "
                 "3/2 / 5/2, max |x / lengthscale|^2 within the accuracy policy); this operator is outside it"
             )
         if xp1.fused and xp2.fused and xp1.kind != "rq":
             g = B.kv_grad(xp1, xp2, left_t, right_t, iso=iso)
-        else:  # float64, d > 16, or a parametrised family outside the Gram-form accuracy policy
+        else:  # float64, d > 32, or a parametrised family outside the Gram-form accuracy policy
             g = B.kv_grad_generic(xp1, xp2, left_t, right_t).to(wd)
     d = xp1.d
     theta = 1.0 if outputscale is None else outputscale.detach().reshape(()).to(wd)

@@ -75,8 +75,8 @@ def test_argument_validation_without_gpu():
     h = lib()
     assert h.gpamd_kv_plan(0, 0, 10, 3, 1, 0, 12, None, None, None) == -1
     assert b"bad shape" in h.gpamd_last_error()
-    # input dimensions beyond 16 are refused before any launch
-    rc = h.gpamd_kv_partials_f32(0, 0.0, None, 10, None, 10, 20, None, None, 12, 1, None, 12, 1, 128, 0, None, None)
+    # input dimensions beyond 32 are refused before any launch (ABI version 4; 16 before)
+    rc = h.gpamd_kv_partials_f32(0, 0.0, None, 10, None, 10, 40, None, None, 12, 1, None, 12, 1, 128, 0, None, None)
     assert rc == -2
     # split-operand contraction: the j chunk must be the plan's (a multiple of the 128-row LDS tile) -- refused before any launch
     rc = h.gpamd_kv_partials_f32(0, 0.0, None, 1000, None, 1000, 3, None, None, 1000, 11, None, 1000, 1, 1004, 1 | 8, None, None)
