@@ -417,8 +417,14 @@ def refine_solves_(x: B.PreparedPoints, scale, sigma2, rhs_t, sol_t, tolerance=N
     s264 = None if sigma2 is None else sigma2.detach().to(torch.float64)
     dv64 = None if dvec is None else dvec.to(torch.float64)
 
-    def matvec64(a64):   # K_hat a, float64 (csrc/kv_f64.hpp for d <= 16)
-        return B.kv(x64, x64, a64, scale=sc64, dscale=s264, vd=a64, dvec=dv64)
+    def matvec64(a64):   # K_hat a, float64 (csrc/kv_f64.hpp for d <= 16); many columns go in groups of 80 (the widest tile of the float64 kernel)
+        if a64.shape[0] <= 80:
+            return B.kv(x64, x64, a64, scale=sc64, dscale=s264, vd=a64, dvec=dv64)
+        out = torch.empty_like(a64)
+        for c0 in range(0, a64.shape[0], 80):
+            blk = a64[c0 : c0 + 80].contiguous()
+            out[c0 : c0 + 80] = B.kv(x64, x64, blk, scale=sc64, dscale=s264, vd=blk, dvec=dv64)
+        return out
 
     def solve32(r):
         delta, info = linear_cg(x, scale, sigma2, r, n_tridiag=0, tolerance=tolerance, max_iter=max_iter, preconditioner=precond, dvec=dvec)
@@ -432,8 +438,8 @@ def solve(x: B.PreparedPoints, scale, sigma2, rhs_t, tolerance=None, max_iter=No
     if precond == "auto":
         precond = build_preconditioner(x, scale, sigma2)
     sol, info = linear_cg(x, scale, sigma2, rhs_t, n_tridiag=0, tolerance=tolerance, max_iter=max_iter, preconditioner=precond)
-    if settings.rhs_refinement.on() and x is not None and x.fused and sol.dtype == torch.float32 and rhs_t.shape[0] <= 4:
-        refine_solves_(x, scale, sigma2, rhs_t, sol, tolerance, max_iter, precond)       # (few columns: the mean-cache solve, not the 1000-column variance solves)
+    if settings.rhs_refinement.on() and x is not None and x.fused and sol.dtype == torch.float32:
+        refine_solves_(x, scale, sigma2, rhs_t, sol, tolerance, max_iter, precond)
     return sol, info
 
 

@@ -116,6 +116,10 @@ class DefaultPredictionStrategy:
                 train_train_covar = BatchLinearOperator.replicate(train_train_covar, rhs_in.shape[:-2])
             rhs = train_train_covar.solve(rhs_in)
             if torch.is_tensor(test_test_covar):
+                if settings.rhs_refinement.on() and ttc.dtype == torch.float32:
+                    # K_** - K_*X K_hat^-1 K_X* is 1 - 0.9998.. at a well-determined test point: with the solves refined to float64 accuracy
+                    # (settings.rhs_refinement) the LAST contraction must not throw the digits away again -- float64 GEMM, float32 result
+                    return to_linear_operator((test_test_covar.to(torch.float64) - ttc.to(torch.float64) @ rhs.to(torch.float64)).to(ttc.dtype))
                 return to_linear_operator(test_test_covar - ttc @ rhs)
             return test_test_covar + MatmulLinearOperator(DenseLinearOperator(ttc), DenseLinearOperator(rhs.mul(-1)))
         root = to_linear_operator(test_train_covar) @ self.covar_cache  # [n_test, m]

@@ -807,8 +807,9 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
                 tolerance=settings.cg_tolerance.value(), preconditioner=self._cache["precond"], dvec=self._dvec(),
             )
             self._cache["last_cg_info"] = info
-            if settings.rhs_refinement.on() and p1.fused and sol_t.dtype == torch.float32 and r.shape[-1] <= 4:
-                from .bbmm import refine_solves_   # (few columns: the mean cache; not the 1000-column variance solves)
+            if settings.rhs_refinement.on() and p1.fused and sol_t.dtype == torch.float32:
+                from .bbmm import refine_solves_   # (any number of columns since round 5: the n_test-column solve of the exact predictive variance too --
+                #                                     one fused float64 product with all columns + one more float32 solve of the residuals)
 
                 refine_solves_(p1, self.kernel_op._os(), self._nz(), B.to_probe_major(r.detach(), p1.dtype), sol_t, settings.cg_tolerance.value(), None,
                                self._cache["precond"], self._dvec())

@@ -172,12 +172,15 @@ class skip_logdet_forward(_feature_flag):
 
 
 class rhs_refinement(_feature_flag):
-    """(no counterpart in the reference.)  Mixed-precision iterative refinement of the DATA solve a = K_hat^-1 (y - mu): after float32 mBCG, the
-    true residual y - K_hat a is formed with ONE float64 product (``csrc/kv_f64.hpp``, the same prepared points widened to float64), the
+    """(no counterpart in the reference.)  Mixed-precision iterative refinement of float32 solves: after float32 mBCG, the
+    true residual rhs - K_hat a is formed with ONE float64 product (``csrc/kv_f64.hpp``, the same prepared points widened to float64), the
     correction K_hat d = r is solved in float32 as before and added -- ``rhs_refinement.steps`` times (default 1).  At kappa ~ 1e6 float32
     mBCG attains |a - a*| / |a*| ~ 3e-4 whatever the tolerance; one step takes that to the 1e-7 range, and with it the
-    data-fit gradient -a^T dK a and the predictive mean.  Cost: one few-column float64 product + one more solve of the y column(s).  OFF by
-    default (the reference's float32 path has no such step); applies to the single-kernel float32 operator (d <= 16), unsharded rows."""
+    data-fit gradient -a^T dK a, the predictive mean and -- since round 5, any number of columns -- the n_test-column solve behind the EXACT
+    predictive variance, whose last contraction then runs in float64 as well (``models.exact_predictive_covar``): the variance of f itself,
+    1 - 0.9998.. at a well-determined point, instead of only the variance of y.  Cost: one float64 product with the solved columns + one more
+    float32 solve.  OFF by default (the reference's float32 path has no such step); applies to the single-kernel float32 operator
+    (d <= 16: the fused float64 kernel), unsharded rows."""
     _default = False
     steps = 1
 

@@ -1,0 +1,96 @@
+"""BASELINE C3 at ITS OWN size (Matern-5/2, n = 500 000, d = 10, rank-100 pivoted-Cholesky preconditioner): the marginal-log-likelihood
+ingredients of the fused float32 path against the SAME algorithm in float64 -- fused float64 products (``csrc/kv_f64.hpp``), the float64
+instantiation of the device-resident mBCG (``gpamd_cg64_*``), the same probe vectors, the same preconditioner factor, the same stopping rule.
+
+No dense factor exists at this size (2 TB in float64); what CAN be pinned is that float32 arithmetic -- hi/lo-split Gram expansion, split
+contraction, float32 mBCG recurrences, split W contraction of the backward -- changes nothing an exact-arithmetic run of the reference's
+algorithm would produce: y^T K_hat^-1 y, the solve of the y column, the stochastic-Lanczos quadrature of the fixed probes and the three
+hyper-parameter gradients (``test/lazy/test_lazy_evaluated_kernel_tensor.py:84-105`` is the reference's pattern: value and gradients against a
+higher-precision evaluation of the same quantity).  The dense-truth half of the argument is ``tests/test_gpu_dense_at_size.py`` /
+``tests/test_gpu_grad_at_size.py`` at n = 60 000 of the same model.  Numbers -> gpurun_out/c3_at_size_vs_float64.json."""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from tests.test_gpu_parity_at_size import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _grads(xp, res, ls, os_, dev):
+    """(d/d lengthscale, d/d outputscale, d/d noise) of inv_quad + logdet from one forward result: the A.6 backward on the product's kernels."""
+    from gpytorch_amd import backend as B
+    from gpytorch_amd.bbmm import backward_vectors
+    from gpytorch_amd.functions import hyper_grads
+
+    wd = res.solves_t.dtype
+    one = torch.ones((), device=dev, dtype=wd)
+    left, right, _ = backward_vectors(res, torch.ones(1, device=dev, dtype=wd), one, res.zt.shape[0])
+    d_ls, d_os = hyper_grads(xp, xp, ls.to(wd), os_.to(wd), left, right)
+    d_nz = B.coldot(left, right, xp.n).sum()
+    return float(d_ls.sum()), float(d_os.sum()), float(d_nz)
+
+
+def test_c3_mll_ingredients_fused_float32_vs_float64_bbmm(dev):
+    from gpytorch_amd import backend as B
+    from gpytorch_amd.bbmm import build_preconditioner, inv_quad_logdet_forward, preconditioner_from_factor
+
+    kind, n, d, ls, probes, tol = "matern52", 500_000, 10, 0.8, 4, 0.05
+    X, y = synth(n, d)
+    Xd, yd = X.to(dev), y.to(dev)
+    lsv = torch.tensor([ls], device=dev)
+    log = {"kind": kind, "n": n, "d": d, "probes": probes, "cg_tolerance": tol, "preconditioner_rank": 100}
+    runs = {}
+    pre32 = None
+    zprobe = None
+    for wd in (torch.float32, torch.float64):
+        xp = B.prep_points(kind, Xd.to(wd), lsv.to(wd), Xd.mean(0).to(wd))
+        sc, s2 = torch.ones(1, device=dev, dtype=wd), torch.full((1,), 0.1, device=dev, dtype=wd)
+        rhs_t = B.to_probe_major(yd.unsqueeze(-1), wd)
+        if wd == torch.float32:
+            assert xp.fused
+            pre = pre32 = build_preconditioner(xp, sc, s2, rank=100, min_size=0)
+            kw = {"generator": torch.Generator(device=dev).manual_seed(11), "num_probes": probes}
+        else:
+            assert B.fused_f64(xp, xp)
+            pre = preconditioner_from_factor(pre32.lt, n, s2, wd)          # the SAME factor L: P, Q1 and log|P| re-derived in float64
+            kw = {"probes": zprobe}                                         # the SAME probe vectors (un-normalised [n, t])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        res = inv_quad_logdet_forward(xp, sc, s2, rhs_t, precond=pre, tolerance=tol, max_iter=400, **kw)
+        torch.cuda.synchronize(dev)
+        fwd = time.perf_counter() - t0
+        assert res.info.tolerance_reached
+        if wd == torch.float32:
+            zprobe = (res.zt[:, :n] * res.znorm.unsqueeze(-1)).t().to(torch.float64)
+        t0 = time.perf_counter()
+        g = _grads(xp, res, lsv, sc, dev)
+        torch.cuda.synchronize(dev)
+        runs[wd] = {"iterations": res.info.iterations, "inv_quad": float(res.inv_quad.sum()), "logdet": float(res.logdet), "logdet_slq_part": float(res.logdet_pinvk),
+                    "logdet_precond_part": float(pre.logdet), "grad_lengthscale_outputscale_noise": g, "forward_seconds": fwd, "backward_seconds": time.perf_counter() - t0,
+                    "ysol": res.solves_t[probes, :n].double()}
+        del res, xp
+        torch.cuda.empty_cache()
+    a, b = runs[torch.float32], runs[torch.float64]
+    ysol_err = float((a["ysol"] - b["ysol"]).norm() / b["ysol"].norm())
+    for r in (a, b):
+        r.pop("ysol")
+    log["float32_fused"], log["float64_bbmm"] = a, b
+    log["y_solve_rel_l2_difference"] = ysol_err
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/c3_at_size_vs_float64.json", "w") as f:
+        json.dump(log, f, indent=1)
+
+    # same stopping iteration (the rule acts on residual norms that agree to float32 rounding; +-2: a norm may sit on the threshold)
+    assert abs(a["iterations"] - b["iterations"]) <= 2, log
+    assert abs(a["inv_quad"] - b["inv_quad"]) < 1e-3 * abs(b["inv_quad"]), log
+    assert ysol_err < (1e-3 if a["iterations"] == b["iterations"] else 1e-2), log
+    assert abs(a["logdet_precond_part"] - b["logdet_precond_part"]) < 1e-6 * abs(b["logdet_precond_part"]), log
+    # the quadrature of the fixed probes: relative to the log-determinant it contributes to (its own scale: n times a per-datum O(1) quantity)
+    assert abs(a["logdet_slq_part"] - b["logdet_slq_part"]) < 1e-3 * abs(b["logdet"]), log
+    assert abs(a["logdet"] - b["logdet"]) < 1e-3 * abs(b["logdet"]), log
+    for name, ga, gb in zip(("lengthscale", "outputscale", "noise"), a["grad_lengthscale_outputscale_noise"], b["grad_lengthscale_outputscale_noise"]):
+        assert abs(ga - gb) < 1e-3 * abs(gb) + 1e-6 * n, (name, ga, gb, log)

@@ -130,7 +130,7 @@ def test_c3_shape_mll_ingredients_vs_dense_cholesky(dev):
 # ---- round 4: the predictive posterior at the same sizes ------------------------------------------------------------------------------
 def run_posterior_case(name, kind, n, d, ls, dev, ns=1000,
                        configs=((15, 0.01, False, 100), (15, 0.01, True, 100), (100, 1e-4, False, 100), (100, 1e-4, True, 100), (100, 1e-4, True, 400),
-                                (100, 1e-4, True, 1600), (15, 0.01, True, 400, True))):
+                                (100, 1e-4, True, 1600), (15, 0.01, True, 400, True), (100, 1e-4, False, 100, True))):
     """Predictive mean / variance of f at ``ns`` test points through the model API (``ExactGP.__call__`` in eval mode ->
     ``DefaultPredictionStrategy``: mean cache by mBCG, exact variance by a 1000-column solve, LOVE variance from the Lanczos root) against
     ``K_*X K_hat^-1 y`` and ``diag(K_** - K_*X K_hat^-1 K_X*)`` from the dense float64 factor.  Mirrors
@@ -182,6 +182,9 @@ def run_posterior_case(name, kind, n, d, ls, dev, ns=1000,
                     "var_max_rel_err": float(((var - var_ref).abs() / var_ref).max()),
                     "var_max_err_over_noise": float((var - var_ref).abs().max() / s2v),
                     "yvar_max_rel_err": float(((var - var_ref).abs() / (var_ref + s2v)).max()),
+                    # the variance of f itself against rtol 2e-3 + an absolute floor of 2e-6: K_*X is held in float32 (6e-8 relative per entry) and
+                    # k_*^T K_hat^-1 k_* sums n products of them whose absolute sum is ~10-30 -> a few 1e-6 is what float32 INPUTS allow whatever the solve
+                    "fvar_max_err_over_bound": float(((var - var_ref).abs() / (2e-3 * var_ref + 2e-6)).max()),
                 })
                 del m, lik
                 torch.cuda.empty_cache()
@@ -198,6 +201,10 @@ def _check_posterior(log, love_rank_ok=None):
         tag = (log["name"], r["precond_rank"], r["eval_cg_tolerance"], r["fast_pred_var"], r["love_rank"])
         if r["eval_cg_tolerance"] <= 1e-4:
             assert r["mean_rel_err"] < 1e-3, (tag, r["mean_rel_err"])
+            if not r["fast_pred_var"] and r["rhs_refinement"]:
+                # round 5: with settings.rhs_refinement on the n_test-column solve (float64 residual replacement) and a float64 last contraction the variance
+                # of F is asserted, not only the variance of y: north_star's "predictive mean/variance rtol 1e-3" at the 2e-3 of the solve path
+                assert r["fvar_max_err_over_bound"] < 1.0, (tag, r["fvar_max_err_over_bound"], r["var_max_rel_err"])
             if not r["fast_pred_var"]:
                 # the predictive variance of y (what likelihood(model(x)) returns): K_** - K_*X K_hat^-1 K_X* + noise.  The variance of f itself is
                 # 1e-4 .. 2e-3 at C2 (1 - 0.9998...): float32 arithmetic cannot hold it to 2e-3 RELATIVE in this or in the reference's own code path
