@@ -96,6 +96,8 @@ def product(split):
 
 cases = [("idle", None), ("kv_gramh full loop (tune build, 2 row tiles)", tune(0, 2)), ("kv_gramh without the generation VALU", tune(1, 2)),
          ("kv_gramh without the contraction MFMAs", tune(2, 2)), ("kv_gramh, one wave per SIMD", tune(7, 2)),
+         ("kv_gramh, V planes staged once (no LDS re-staging)", tune(3, 2)), ("kv_gramh, staged once and no barriers", tune(4, 2)),
+         ("kv_gramh, A operands from one block (no LDS operand traffic growth)", tune(5, 2)),
          ("product kernel, split contraction (4 row tiles)", product(True)), ("product kernel, fp32 MFMA contraction", product(False))]
 out = {"n": n, "columns": 64, "seconds_per_case": secs, "cases": []}
 for name, run in cases:
