@@ -62,6 +62,7 @@ SIGNATURES = {
     "gpamd_lanczos_subtract_f32": (_i, [_p, _i64, _i, _p, _p, _i, _p, _p]),
     "gpamd_lanczos_normalize_f32": (_i, [_p, _i, _p, _p, _p, _f, _p, _p]),
     "gpamd_block_project_f32": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _p, _p, _i64, _p]),
+    "gpamd_block_project_f64": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _p, _p, _i64, _p]),
     "gpamd_block_subtract_f32": (_i, [_p, _i64, _i, _p, _p, _i64, _i, _i, _p]),
     "gpamd_block_transform_f32": (_i, [_p, _p, _i64, _i, _i, _p]),
     "gpamd_msminres_update_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _p]),

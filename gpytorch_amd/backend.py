@@ -341,8 +341,9 @@ def from_probe_major(vt: torch.Tensor, n: int) -> torch.Tensor:
 _ws_cache: dict = {}
 
 
-def workspace(device, nfloats: int) -> torch.Tensor:
-    key = (device.type, device.index)
+def workspace(device, nfloats: int, slot: int = 0) -> torch.Tensor:
+    """A cached float32 scratch buffer per (device, slot): slot 0 holds the partial slabs of a product, slot 1 the wide-row launch's own slabs."""
+    key = (device.type, device.index, slot)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(nfloats, 1 << 20), device=device, dtype=torch.float32)
@@ -382,13 +383,29 @@ def kv_partials_sorted(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor,
             "kv_partials",
         )
     if n_c < x1.n:
-        check(
-            L.gpamd_kv_partials_f32(
-                *kind_args(x1), C.c_void_p(X1.data_ptr() + 4 * x1.dp * n_c), x1.n - n_c, _ptr(x2.xp), x2.n, x1.d, None, _ptr(vt), vt.stride(0), t,
-                C.c_void_p(P.data_ptr() + 4 * n_c), ldo, S, jc, 0, done_ptr, st
-            ),
-            "kv_partials (wide rows)",
-        )
+        n_w = x1.n - n_c
+        x1w = C.c_void_p(X1.data_ptr() + 4 * x1.dp * n_c)
+        # The wide rows are a SMALLER product (<= 25 % of the rows) on a different kernel: with the split count of the compact launch it would
+        # leave most of the chip idle -- measured on the reference's own workloads (profiles/r05_s1_workload_*_kernel_stats.csv): 11.3 ms for 10 % of
+        # the rows against 11.8 ms for the other 90 % (road3d shape), 0.83 against 0.31 ms (protein shape).  It gets its own plan and slabs; their sum
+        # lands in slab 0 of the shared layout, the other slabs' rows are zeroed.
+        ldw = round_up(n_w, 4)
+        Sw, jcw, wsw = kv_plan(x1.kind, n_w, x2.n, x1.d, t, 0, ldw)
+        if Sw == S and jcw == jc:
+            check(L.gpamd_kv_partials_f32(*kind_args(x1), x1w, n_w, _ptr(x2.xp), x2.n, x1.d, None, _ptr(vt), vt.stride(0), t,
+                                          C.c_void_p(P.data_ptr() + 4 * n_c), ldo, S, jc, 0, done_ptr, st), "kv_partials (wide rows)")
+        else:
+            Pw = workspace(vt.device, wsw, slot=1)
+            check(L.gpamd_kv_partials_f32(*kind_args(x1), x1w, n_w, _ptr(x2.xp), x2.n, x1.d, None, _ptr(vt), vt.stride(0), t, _ptr(Pw), ldw, Sw, jcw, 0,
+                                          done_ptr, st), "kv_partials (wide rows)")
+            slabs = P[: S * t * ldo].view(S, t, ldo)
+            if n_c % 4 == 0:
+                check(L.gpamd_kv_reduce_f32(_ptr(Pw), Sw, ldw, t, n_w, None, None, None, None, 0, C.c_void_p(P.data_ptr() + 4 * n_c), ldo, done_ptr, st),
+                      "kv_reduce (wide rows)")
+            else:   # (the reduction kernel stores 16-byte vectors: an unaligned first wide row goes through torch)
+                slabs[0, :, n_c : x1.n] = Pw[: Sw * t * ldw].view(Sw, t, ldw)[:, :, :n_w].sum(0)
+            if S > 1:
+                slabs[1:, :, n_c : x1.n].zero_()
     return unsort
 
 

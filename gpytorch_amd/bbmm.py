@@ -54,6 +54,23 @@ def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=
     return preconditioner_from_factor(lt, n, sigma2, x.dtype)
 
 
+def gram_rows(rows: torch.Tensor) -> torch.Tensor:
+    """rows rows^T in float64 for tall-skinny probe-major ``rows`` [k, n] (float32 or float64, unit column stride): the library's reduction kernel
+    on the device, a torch GEMM elsewhere."""
+    k, n = rows.shape
+    if not rows.is_cuda or rows.dtype not in (torch.float32, torch.float64) or rows.stride(1) != 1:
+        r64 = rows.to(torch.float64)
+        return r64 @ r64.t()
+    from ._lib import check, lib
+
+    L = lib()
+    G = torch.empty(k, k, device=rows.device, dtype=torch.float64)
+    ws = torch.empty(max(int(L.gpamd_precond_coef_workspace_doubles(n, min(k, 16), k)), 1), device=rows.device, dtype=torch.float64)
+    fn = L.gpamd_block_project_f32 if rows.dtype == torch.float32 else L.gpamd_block_project_f64
+    check(fn(B._ptr(rows), rows.stride(0), k, B._ptr(rows), rows.stride(0), k, n, B._ptr(G), B._ptr(ws), ws.numel(), B._stream(rows.device)), "block_project")
+    return 0.5 * (G + G.t())
+
+
 def preconditioner_from_factor(lt: torch.Tensor, n: int, noise: torch.Tensor, wd, noise_is_vector: bool = False) -> Preconditioner:
     """P = L L^T + D from the (pivoted-Cholesky) factor ``lt`` [k, >= n] and the diagonal D: a scalar sigma^2 (A.4's constant branch)
     or a vector [>= n] (the reference's ``_init_cache_for_non_constant_diag``: fixed heteroskedastic noise, per-task noise).
@@ -78,11 +95,13 @@ def preconditioner_from_factor(lt: torch.Tensor, n: int, noise: torch.Tensor, wd
         dinv_sqrt[:n] = di
     else:
         s2 = noise.detach().reshape(()).to(torch.float64)
-    # Cholesky-QR twice, all in float64 (n x k GEMMs: 2 n k^2 flop each, < 10 ms at n = 5e5, k = 100)
-    r1 = torch.linalg.cholesky(ltd @ ltd.t() + s2 * eye, upper=True)           # G = L^T L + s2 I = R1^T R1
+    # Cholesky-QR twice, all in float64.  The two k x n x k Gram products go through the library's own reduction kernel on the device (float64
+    # accumulation, gpamd_block_project_*): rocBLAS' float64 GEMM takes 35 ms for k = 15, n = 217 437 and 5.9 ms for k = 100, n = 36 584 -- 70 / 12 ms
+    # per MLL evaluation of the reference's road3d / protein workloads (profiles/r05_s1_workload_*_kernel_stats.csv: "Cijk_Alik_Bljk_DB_...")
+    r1 = torch.linalg.cholesky(gram_rows(lt[:, :n] if not noise_is_vector else ltd) + s2 * eye, upper=True)   # G = L^T L + s2 I = R1^T R1
     r1inv = torch.linalg.solve_triangular(r1, eye, upper=True)
     q1t = r1inv.t() @ ltd                                                       # [k, n] = (L R1^-1)^T
-    g2 = q1t @ q1t.t() + s2 * (r1inv.t() @ r1inv)                               # re-orthogonalise over all n + k rows
+    g2 = gram_rows(q1t) + s2 * (r1inv.t() @ r1inv)                              # re-orthogonalise over all n + k rows
     r2 = torch.linalg.cholesky(g2, upper=True)
     r2inv = torch.linalg.solve_triangular(r2, eye, upper=True)
     q1t = r2inv.t() @ q1t

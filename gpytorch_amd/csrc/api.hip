@@ -110,7 +110,7 @@ KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool
     if (v.g4 == 16 && t <= 12 && light) v.g4 = 3;
     v.bm = v.g4 >= 16 ? KG16_BM : kg4_bm(v.g4);
     v.bn = v.g4 >= 16 ? KG16_BN : KG4_BN;
-  } else if (t <= 8 || (gram && t <= 16)) {
+  } else if (t <= 8 || (gram && t <= 16) || (t <= 16 && dk <= 12)) {   // (direct differences, 9 .. 16 columns, <= 12 dimensions: kv_valu<T = 16>, kv_family.inc)
     v.valu = true;
     v.tpad = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : (t <= 8 ? 8 : 16)));
     v.bm = KVV_BM;

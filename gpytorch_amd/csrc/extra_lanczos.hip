@@ -108,19 +108,39 @@ int gpamd_precond_apply_f32f64(const float* R, int64_t ldr, int t, const double*
 }
 
 // ---- block Lanczos vector work (lanczos_kernels.hpp: pc_coef_kernel<1, float>, lzb_subtract_kernel, lzb_transform_kernel) ----
-int gpamd_block_project_f32(const float* Q, int64_t ldq, int k, const float* R, int64_t ldr, int b, int n, double* W, double* workspace,
-                            int64_t workspace_doubles, void* stream) {
-  if (!Q || !R || !W || !workspace || n <= 0 || b <= 0 || b > LZB_MAXB || k <= 0 || ldq < n || ldr < n) return lz_fail("block_project: bad arguments (b <= 16)");
+extern "C++" {
+namespace {
+// W[c][m] = <R[c], Q[m]> for ANY number b of rows R, in column groups of 16, and any number k of basis rows (k tiles of 128 over blockIdx.y)
+template <typename TQ, typename TR>
+int block_project(const TQ* Q, int64_t ldq, int k, const TR* R, int64_t ldr, int b, int n, double* W, double* workspace, int64_t workspace_doubles,
+                  hipStream_t st) {
   long nb = ((long)n + 255) / 256;
   if (nb > 256) nb = 256;
-  if (workspace_doubles < (int64_t)nb * b * k) return GPAMD_EWORKSPACE;
+  const int bg = b < 16 ? b : 16;
+  if (workspace_doubles < (int64_t)nb * bg * k) return GPAMD_EWORKSPACE;
   const int slice = (int)(((long)n + nb - 1) / nb + PC_CHUNK - 1) / PC_CHUNK * PC_CHUNK;
   nb = ((long)n + slice - 1) / slice;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((pc_coef_kernel<1, float>), dim3((unsigned)nb, (unsigned)((k + 16 * PC_MT - 1) / (16 * PC_MT))), dim3(256), 0, st, R, ldr, b, Q, ldq, k, n,
-                     slice, workspace);
-  hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((b * k + 255) / 256), dim3(256), 0, st, (const double*)workspace, (int)nb, b * k, W);
+  for (int c0 = 0; c0 < b; c0 += 16) {
+    const int tg = b - c0 < 16 ? b - c0 : 16;
+    hipLaunchKernelGGL((pc_coef_kernel<1, TQ, TR>), dim3((unsigned)nb, (unsigned)((k + 16 * PC_MT - 1) / (16 * PC_MT))), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg,
+                       Q, ldq, k, n, slice, workspace);
+    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((tg * k + 255) / 256), dim3(256), 0, st, (const double*)workspace, (int)nb, tg * k, W + (int64_t)c0 * k);
+  }
   return lz_check("block_project");
+}
+}  // namespace
+}  // extern "C++"
+
+int gpamd_block_project_f32(const float* Q, int64_t ldq, int k, const float* R, int64_t ldr, int b, int n, double* W, double* workspace,
+                            int64_t workspace_doubles, void* stream) {
+  if (!Q || !R || !W || !workspace || n <= 0 || b <= 0 || k <= 0 || ldq < n || ldr < n) return lz_fail("block_project: bad arguments");
+  return block_project<float, float>(Q, ldq, k, R, ldr, b, n, W, workspace, workspace_doubles, (hipStream_t)stream);
+}
+
+int gpamd_block_project_f64(const double* Q, int64_t ldq, int k, const double* R, int64_t ldr, int b, int n, double* W, double* workspace,
+                            int64_t workspace_doubles, void* stream) {
+  if (!Q || !R || !W || !workspace || n <= 0 || b <= 0 || k <= 0 || ldq < n || ldr < n) return lz_fail("block_project: bad arguments");
+  return block_project<double, double>(Q, ldq, k, R, ldr, b, n, W, workspace, workspace_doubles, (hipStream_t)stream);
 }
 
 int gpamd_block_subtract_f32(const float* Q, int64_t ldq, int k, const double* W, float* R, int64_t ldr, int b, int n, void* stream) {

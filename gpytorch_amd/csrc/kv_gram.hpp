@@ -31,7 +31,7 @@ namespace gpamd {
 // Register budget: 64 accumulators (CT <= 2) fit three waves per SIMD (<= 168 unified registers) only if the
 // allocator is told to: left alone it parks the 16 distance registers in AGPRs (v_accvgpr_read before every v_exp)
 // and lands at 180.
-template <int KIND, int D, int CT, int NI, int EX>
+template <int KIND, int D, int CT, int NI, int EX, int SAFE = 0>   // SAFE = 1: hazard stress builds only (tune/tune_hazard.hip): the full mfma_result_fence after the Gram MFMAs
 // (CT = 1 runs four row tiles per wave: 64 accumulators + 64 distance registers do not fit 168 registers -- 6..44 spilled, and with the extra
 // column the Matern-3/2 / RQ instantiations returned wrong rows on a full chip, tests/test_gpu_kv.py regression sweep -> two waves there)
 // (beyond 16 dimensions the split x_i operands -- NI * KH * 4 registers, KH = 4 .. 7 -- take the room of the third wave: two waves per SIMD)
@@ -170,7 +170,19 @@ void kv_gram_kernel(KvArgs a) {
       // first, then the tiles are converted one after the other.  A second MFMA cannot issue while the first occupies the matrix pipe, so
       // tile 0 is complete when the last MFMA has issued, and tile ni is read only after the >= 16 transcendental instructions of every
       // earlier tile (>= 128 cycles against the 32 + pipeline cycles of an 8-pass MFMA).
+      // Round 5: the distance from a Gram MFMA to the first read of ITS registers no longer rests on the toolchain's table (12 wait states: the
+      // very distance measured insufficient in kv_gramv): 8 explicit wait states more behind the whole group (20 in all), tied to the result registers
+      // so that no MFMA can sink below them -- 8 more idle cycles per 32-row block against the ~2500 of its contraction (the static audit's bar for
+      // this kernel is now 20, tests/test_isa_hazard_cpu.py; the on-device stress test compares bitwise with the fully fenced build)
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SAFE) {
+        mfma_result_fence(kk);
+      } else {
+        mfma_tie(kk);
+        asm volatile("s_nop 7");   // (+ the toolchain's own 12 behind it: the hazard recogniser does not count wait states inside inline asm)
+        mfma_tie(kk);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll

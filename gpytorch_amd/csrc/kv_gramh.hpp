@@ -86,7 +86,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Xh buffers push the LDS image past half a CU: ONE wave per SIMD with the whole register file instead of 46 .. 94 spilled registers)
 template <int D>
 constexpr int kgh_waves() { return D > 20 ? 1 : 2; }
-template <int KIND, int D, int CT, int NI, int EX>
+template <int KIND, int D, int CT, int NI, int EX, int SAFE = 0>   // SAFE = 1: hazard stress builds only (tune/tune_hazard.hip): every Gram result behind the full mfma_result_fence
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kgh_waves<D>(), kgh_waves<D>())))
 void kv_gramh_kernel(KvhArgs ka) {
   constexpr int NW = 4, NT = 64 * NW;   // four waves per workgroup: row block = NW * NI * 32 rows sharing one staged V tile
@@ -195,6 +195,7 @@ void kv_gramh_kernel(KvhArgs ka) {
     for (int r = 0; r < 16; ++r) kk[r] = 0.f;
 #pragma unroll
     for (int kh = 0; kh < KH; ++kh) kk = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[kh], bq[ni][kh], kk, 0, 0, 0);
+    if constexpr (SAFE) mfma_result_fence(kk);   // (stress builds: 32 wait states tied to the result; the product reads kk >= one contraction MFMA later)
     return kk;
   };
   // Generation of elements r = 8 mf + 2 p, + 1 of a step in two halves of three VALU instructions each:

@@ -131,7 +131,7 @@ int64_t gpamd_kv_grad2_workspace_doubles(int n, int m, int t, int d) {
   if (n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 32) return 0;
   int S, jc, nrb;
   g2_plan(n, m, &S, &jc, &nrb);
-  const int dp = (d + 3) / 4 * 4;
+  const int dp = (kdims(d) + 3) / 4 * 4;
   return (int64_t)g2_groups(t) * nrb * S * (2 + dp);
 }
 
@@ -139,7 +139,7 @@ int64_t gpamd_kv_grad2_xworkspace_floats(int n, int m, int t, int d) {
   if (n <= 0 || m <= 0 || t <= 0 || d < 1 || d > 32) return 0;
   int S, jc, nrb;
   g2_plan(n, m, &S, &jc, &nrb);
-  const int dp = (d + 3) / 4 * 4;
+  const int dp = (kdims(d) + 3) / 4 * 4;
   return (int64_t)g2_groups(t) * S * dp * ((n + 3) / 4 * 4);
 }
 
@@ -161,7 +161,7 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
     snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: Gram-form generation needs RBF / Matern 3/2 / Matern 5/2 (use gpamd_kv_grad_f32)");
     return GPAMD_EUNSUPPORTED;
   }
-  const int dp = (d + 3) / 4 * 4, dk = kdims(d);
+  const int dk = kdims(d), dp = (dk + 3) / 4 * 4;   // row stride of the prepared clouds = the kernel's DP (25 .. 28 dimensions share the D = 32 kernels: stride 32)
   int S, jc, nrb;
   g2_plan(n, m, &S, &jc, &nrb);
   const bool split = (flags & GPAMD_KV_SPLIT) != 0;

@@ -121,12 +121,13 @@ namespace gpamd {
 constexpr int PC_CHUNK = 32;
 constexpr int PC_MT = 8;      // k <= 128
 
-// TQ: type of the basis rows (double: the preconditioner's Q1; float: the Lanczos basis of the block recurrences below).  blockIdx.y selects a
+// TQ / TR: types of the basis rows and of the projected rows (double / float: the preconditioner's Q1 against float32 residuals; float / float: the Lanczos
+// basis of the block recurrences below and the Gram matrix of the pivoted-Cholesky factor; double / double: the second Cholesky-QR pass of the preconditioner).  blockIdx.y selects a
 // tile of 128 basis rows, so k is unbounded for callers that launch a second grid dimension (the preconditioner launches one: k <= 128).
-template <int CT, typename TQ = double>  // t <= 16 * CT
-__global__ __launch_bounds__(256) void pc_coef_kernel(const float* __restrict__ R, int64_t ldr, int t, const TQ* __restrict__ Q,
+template <int CT, typename TQ = double, typename TR = float>  // t <= 16 * CT
+__global__ __launch_bounds__(256) void pc_coef_kernel(const TR* __restrict__ R, int64_t ldr, int t, const TQ* __restrict__ Q,
                                                       int64_t ldq, int k, int n, int slice, double* __restrict__ part) {
-  __shared__ float Rs[16 * CT][PC_CHUNK + 1];
+  __shared__ TR Rs[16 * CT][PC_CHUNK + 1];
   __shared__ TQ Qs[16 * PC_MT][PC_CHUNK + 1];
   const int tid = threadIdx.x, tc = tid >> 4, tm = tid & 15;
   const int i0 = blockIdx.x * slice, i1 = min(n, i0 + slice);
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void pc_coef_kernel(const float* __restrict__ 
     __syncthreads();
     for (int e = tid; e < 16 * CT * PC_CHUNK; e += 256) {
       const int c = e / PC_CHUNK, ii = e % PC_CHUNK;
-      Rs[c][ii] = (c < t && ib + ii < i1) ? R[(int64_t)c * ldr + ib + ii] : 0.f;
+      Rs[c][ii] = (c < t && ib + ii < i1) ? R[(int64_t)c * ldr + ib + ii] : TR(0);
     }
     for (int e = tid; e < 16 * PC_MT * PC_CHUNK; e += 256) {
       const int m = e / PC_CHUNK, ii = e % PC_CHUNK;

@@ -202,10 +202,15 @@ int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* o
  * Q [k][ldq] of ANY length k (float32 vectors, float64 accumulation).  Behind LinearOperator.root_inv_decomposition (the LOVE covar_cache,
  * gpytorch/models/exact_prediction_strategies.py:267-272) and the multi-vector form of gpytorch.root_inv_decomposition (gpytorch/__init__.py:190-216): the b
  * vectors ride through ONE b-column gpamd_kv_partials_f32 per step instead of b single-column products.
- *   project  : W[c][m] = <R[c], Q[m]>                  W: double [b][k]; workspace: double[gpamd_precond_coef_workspace_doubles(n, b, k)]
+ *   project  : W[c][m] = <R[c], Q[m]>                  W: double [b][k]; ANY b (column groups of 16); workspace: double[gpamd_precond_coef_workspace_doubles(n, min(b, 16), k)].
+ *              With R = Q it is the Gram matrix of tall-skinny rows -- the two Gram products of the preconditioner's Cholesky-QR
+ *              (AddedDiagLinearOperator._preconditioner's QR of [L; sigma I]; rocBLAS' float64 GEMM takes 35 ms for the 15 x 217 437 x 15 shape); _f64: both
+ *              operands double (the second Cholesky-QR pass)
  *   subtract : R[c] -= sum_m W[c][m] Q[m]              (in place)
  *   transform: R[r] = sum_c M[r][c] R[c]               (in place; M: double [b][b], e.g. the inverse Cholesky factor of R R^T: Cholesky-QR) ---- */
 int gpamd_block_project_f32(const float* Q, int64_t ldq, int k, const float* R, int64_t ldr, int b, int n, double* W, double* workspace,
+                            int64_t workspace_doubles, void* stream);
+int gpamd_block_project_f64(const double* Q, int64_t ldq, int k, const double* R, int64_t ldr, int b, int n, double* W, double* workspace,
                             int64_t workspace_doubles, void* stream);
 int gpamd_block_subtract_f32(const float* Q, int64_t ldq, int k, const double* W, float* R, int64_t ldr, int b, int n, void* stream);
 int gpamd_block_transform_f32(const double* M, float* R, int64_t ldr, int b, int n, void* stream);

@@ -29,6 +29,14 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 FENCED = ("kv_gramv_kernel", "kv_gram4_kernel", "kv_gram16_kernel", "kv_grad2_kernel")
 COMPILER_TABLE = 12   # wait states the toolchain itself guarantees after an 8-pass XDL write (s_nop 11)
+# per-family bars above the toolchain's table (round 5): the headline fp32-contraction kernel carries 8 explicit wait states behind its Gram MFMAs
+# (kv_gram.hpp) -- 20 in all; kv_gramh_kernel stays on the table + one intervening contraction MFMA and is covered by the on-device stress test
+# against its fully fenced build (tests/test_gpu_hazard_stress.py)
+MIN_BY_FAMILY = {"kv_gram_kernel": 20}
+
+
+def required(fam: str, fenced_min: int = 32) -> int:
+    return fenced_min if fam in FENCED else MIN_BY_FAMILY.get(fam, COMPILER_TABLE)
 
 
 def extract_code_objects(lib_path: str, arch: str = "gfx950"):

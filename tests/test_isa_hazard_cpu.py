@@ -6,7 +6,9 @@ before the first non-matrix instruction reads one of them:
   * kernels that consume MFMA results on the VALU behind ``mfma_result_fence(regs...)`` (kv_gramv / kv_gram4 / kv_gram16 / kv_grad2):
     at least the fence's 32 wait states -- i.e. no MFMA has been moved below its fence by the optimiser (which round 3's fence, lacking
     data dependencies, allowed: two MFMAs of kv_grad2_kernel<.., WSPLIT> were emitted after the s_nops);
-  * every other kernel: never closer than the toolchain's own hazard table for an 8-pass XDL write (12 wait states).
+  * kv_gram_kernel (the headline fp32-contraction kernel): at least 20 -- 8 explicit wait states behind its Gram MFMAs on top of the table (round 5);
+  * every other kernel: never closer than the toolchain's own hazard table for an 8-pass XDL write (12 wait states); kv_gramh_kernel, which sits
+    on that table plus one intervening MFMA, is stress-tested on the device against its fully fenced build (tests/test_gpu_hazard_stress.py).
 A compiler or flag change that breaks either shows up here, at build time, without a GPU."""
 import os
 import sys
@@ -28,8 +30,18 @@ def test_every_vgpr_destination_mfma_is_read_behind_its_fence():
     fams = {A.family(r["kernel"]) for r in rows}
     assert set(A.FENCED) <= fams, fams                       # the audit saw the kernels it is meant to guard
     assert len(rows) > 1000                                  # ... in all their instantiations
-    bad = [r for r in rows if r["min_wait_states"] < (32 if A.family(r["kernel"]) in A.FENCED else A.COMPILER_TABLE)]
+    # only the Gram MFMA (32x32x16 f16, VGPR destination under the register cap) of kv_gram_kernel carries the raised bar; its contraction MFMAs
+    # accumulate in AGPRs / are read in the epilogue behind the zero-argument fence
+    def bar(r):
+        fam = A.family(r["kernel"])
+        if fam == "kv_gram_kernel" and "32x32x16_f16" not in r["mfma"]:
+            return A.COMPILER_TABLE
+        return A.required(fam)
+
+    bad = [r for r in rows if r["min_wait_states"] < bar(r)]
     assert not bad, bad[:5]
+    gram = [r["min_wait_states"] for r in rows if A.family(r["kernel"]) == "kv_gram_kernel" and "32x32x16_f16" in r["mfma"]]
+    assert gram and min(gram) >= 20, min(gram)
 
 
 def test_audit_measures_a_synthetic_hazard():
