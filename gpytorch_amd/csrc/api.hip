@@ -110,7 +110,8 @@ KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool
     if (v.g4 == 16 && t <= 12 && light) v.g4 = 3;
     v.bm = v.g4 >= 16 ? KG16_BM : kg4_bm(v.g4);
     v.bn = v.g4 >= 16 ? KG16_BN : KG4_BN;
-  } else if (t <= 8 || (gram && t <= 16) || (t <= 16 && dk <= 12)) {   // (direct differences, 9 .. 16 columns, <= 12 dimensions: kv_valu<T = 16>, kv_family.inc)
+  } else if (t <= 8 || (gram && t <= 16) || (t <= 16 && dk <= 4)) {   // (direct differences, 9 .. 16 columns: kv_valu<T = 16> up to 4 dimensions -- 33 -> 27 ms per
+    // product on the road3d shape (d = 3); at d = 10 the 32-column matrix-pipe tile wins, 0.83 against 1.16 ms on the protein shape's wide rows)
     v.valu = true;
     v.tpad = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : (t <= 8 ? 8 : 16)));
     v.bm = KVV_BM;
@@ -259,6 +260,15 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   const int min_chunk = 16 * v.bn;
   int smax = m / min_chunk;
   if (smax < 1) smax = (m >= 4 * v.bn) ? m / (4 * v.bn) : 1;  // small problems: favour parallelism
+  // few output rows against many contracted ones (the wide-row launch of a block-centred product, a test set against the training set): 16-tile chunks
+  // would leave most of the chip without a workgroup -- 72 workgroups for 9 000 x 36 584 pairs on the protein-shaped workload, 1.16 ms where the pairs
+  // are worth 0.16 (profiles/r05_s4_workload_protein_kernel_stats.csv) -- so chunks go down to 4 tiles until one round of workgroups exists
+  if ((long)nrb * smax < slots && m >= 8 * v.bn) {
+    const long want = (slots + nrb - 1) / nrb;
+    const int cap4 = m / (4 * v.bn);
+    smax = (int)(want < cap4 ? want : cap4);
+    if (smax < 1) smax = 1;
+  }
   if (smax > 48) smax = 48;
   int best_s = 1;
   double best = -1.0;

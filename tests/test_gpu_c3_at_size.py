@@ -42,7 +42,7 @@ def test_c3_mll_ingredients_fused_float32_vs_float64_bbmm(dev):
     from gpytorch_amd import backend as B
     from gpytorch_amd.bbmm import build_preconditioner, inv_quad_logdet_forward, preconditioner_from_factor
 
-    kind, n, d, ls, probes, tol = "matern52", 500_000, 10, 0.8, 4, 0.2
+    kind, n, d, ls, probes, tol = "matern52", 500_000, 10, 0.8, 4, 0.05
     X, y = synth(n, d)
     Xd, yd = X.to(dev), y.to(dev)
     lsv = torch.tensor([ls], device=dev)
@@ -96,8 +96,9 @@ def test_c3_mll_ingredients_fused_float32_vs_float64_bbmm(dev):
     # (measured at tolerance 0.05: 174 float32 against 157 float64 iterations with every ingredient below within 1.5e-4) -- bounded loosely, recorded
     assert abs(a["iterations"] - b["iterations"]) <= 0.2 * b["iterations"], log
     assert abs(a["inv_quad"] - b["inv_quad"]) < 1e-3 * abs(b["inv_quad"]), log
-    # both are tolerance-0.2 solves of the y column stopped a few iterations apart: their difference is bounded by that tolerance, not by float32
-    assert ysol_err < 2e-2, log
+    # (at a LOOSE tolerance the two runs are different iterates of the same sequence -- 0.2: 113 against 98 iterations, inv_quad 2.7e-3 apart,
+    # profiles/r05_s4_c3_at_size_vs_float64_tol0.2.json -- so the comparison is made where both have converged to the level it asserts)
+    assert ysol_err < 2e-3, log
     assert abs(a["logdet_precond_part"] - b["logdet_precond_part"]) < 1e-6 * abs(b["logdet_precond_part"]), log
     # the quadrature of the fixed probes: relative to the log-determinant it contributes to (its own scale: n times a per-datum O(1) quantity)
     assert abs(a["logdet_slq_part"] - b["logdet_slq_part"]) < 1e-3 * abs(b["logdet"]), log
