@@ -57,8 +57,13 @@ GRAM_MAX_SQNORM = 32.0   # max |z|^2 for which the split-f16 quadratic expansion
 # cloud-centred rule accepts for EVERY point (relative error <= 2e-5 in K, worst case) run on the Gram-form kernels, the rows of wider
 # blocks (sparse tails) on the direct-difference kernel; beyond GRAM_MAX_WIDE_FRACTION of the rows the whole product falls back
 GRAM_MAX_BLOCK_SQRADIUS = 32.0
-GRAM_MAX_WIDE_FRACTION = 0.25
-GRAM_MAX_EXTENT_SQ = 60000.0    # block-centred expansion: (max |z1| + max |z2|)^2 must stay inside the f16 range of the split norms
+GRAM_MAX_WIDE_FRACTION = 0.8    # (0.25 until round 5: any row off the direct-difference kernels is a gain -- the Hilbert order is cached per cloud)
+# block-centred expansion: (max |z1| + max |z2|)^2.  The split norm |z_j - c|^2 of a contracted point saturates at 60000 (f16 range,
+# csrc/gram_f16.hpp gram_norm_clamp): invisible for the families that are zero to f32 precision at such distances as long as |z_j - c| <= 5000;
+# the heavy-tailed RQ keeps the unsaturated range
+GRAM_MAX_EXTENT_SQ = 2.5e7
+GRAM_MAX_EXTENT_SQ_RQ = 60000.0
+KV_BLOCK128 = 16         # flag of gpamd_kv_partials_f32: the caller bounds 128-row blocks only (SortedView's medium groups)
 _warned_fallback = set()
 FORCE_GENERIC = False    # tests: send float32 / d <= 16 problems down the generic (row-block + GEMM) path too
 FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or KV_GRAM regardless of |z|
@@ -161,7 +166,10 @@ class SortedView:
 
     ``perm``: sorted row k is original row perm[k];  ``inv_pad``: [round_up(n, 4)] gather index that takes a probe-major row in sorted
     order back to the original order (identity on the padding);  ``centers``: [ceil(n / 128), dp] chunk means of the sorted rows;
-    ``n_compact``: rows [0, n_compact) are the compact groups;  ``r2``: the largest block radius^2 among them."""
+    ``n_compact``: rows [0, n_compact) are the compact groups;  ``n_block``: rows [n_compact, n_block) are the MEDIUM chunks -- 128-row blocks
+    within the policy whose 256 / 512-row blocks are not (elongated runs: points along a curve, short lengthscales): the kernels that centre
+    128-row blocks serve them (the split kernel at one row tile per wave, flag GPAMD_KV_BLOCK128; the derivative kernel always centres 128-row blocks),
+    rows [n_block, n) are the wide groups;  ``r2``: the largest admitted block radius^2."""
 
     def __init__(self, x: "PreparedPoints"):
         n, dp = x.n, x.dp
@@ -184,36 +192,34 @@ class SortedView:
                     _ORDER_CACHE.pop(next(iter(_ORDER_CACHE)))
                 _ORDER_CACHE[x.order_key] = (perm, samp)
         xs = x.xp.index_select(0, perm)
-        ng = (n + 511) // 512
-        wide = torch.zeros(ng, device=dev, dtype=torch.bool)
-        r2c = torch.zeros(ng, device=dev, dtype=xs.dtype)
-        for bm in (128, 256, 512):
-            nb = (n + bm - 1) // bm
-            padb = nb * bm - n
-            xb = torch.cat([xs, xs[-1:].expand(padb, -1)], 0) if padb else xs
-            # block centre = mean of the means of its 128-row chunks (csrc/gram_f16.hpp load_center; equal to the block mean for full blocks)
-            bc = xb.reshape(nb * (bm // 128), 128, dp).mean(1).reshape(nb, bm // 128, dp).mean(1, keepdim=True)
-            rb = (xb.reshape(nb, bm, dp) - bc).pow(2).sum(-1).max(1).values                       # [nb]
-            per_group = torch.nn.functional.pad(rb, (0, ng * (512 // bm) - nb)).reshape(ng, 512 // bm).max(1).values
-            r2c = torch.maximum(r2c, per_group)
-        wide = r2c > GRAM_MAX_BLOCK_SQRADIUS
-        n_wide_groups = int(wide.sum().item())
-        if n_wide_groups:
-            # compact groups first (Hilbert order kept), wide groups behind them; a ragged last group goes with the wide ones unless
-            # nothing follows it (the compact region must consist of whole 512-row groups followed by at most one ragged group)
-            ragged = n % 512 != 0
-            if ragged and not bool(wide[-1]):
-                wide[-1] = True
-                n_wide_groups += 1
-            order = torch.cat([torch.nonzero(~wide).reshape(-1), torch.nonzero(wide).reshape(-1)])
-            rows = (order.unsqueeze(1) * 512 + torch.arange(512, device=dev).unsqueeze(0)).reshape(-1)
+        ng, nch = (n + 511) // 512, (n + 127) // 128
+        r2_128, r2_grp = self._block_radii(xs, n, dp, ng)
+        # class of every 128-row chunk: 0 COMPACT -- it lies in a 512-row group all of whose 128 / 256 / 512-row blocks are within the policy;
+        # 1 MEDIUM -- the chunk itself is (against its own centre), its group is not; 2 WIDE.  A compact chunk also qualifies as medium, and
+        # anything may be treated as wide.
+        grp_ok = (r2_grp <= GRAM_MAX_BLOCK_SQRADIUS).repeat_interleave(4)[:nch]
+        cls = torch.where(grp_ok, 0, torch.where(r2_128 <= GRAM_MAX_BLOCK_SQRADIUS, 1, 2))
+        top = int(cls.max().item())
+        if top > 0:
+            # compact groups first (Hilbert order kept), then the medium chunks, then the wide ones.  The compact region must consist of whole
+            # 512-row groups and a ragged chunk can only stand at the very end of the order
+            if n % 512 != 0:
+                cls[4 * (ng - 1):] = cls[4 * (ng - 1):].clamp_min(1)          # a ragged last group: its chunks are medium at best
+            if n % 128 != 0:
+                cls[-1] = top                                                 # a ragged last chunk joins the last class present
+            order = torch.sort(cls, stable=True).indices
+            rows = (order.unsqueeze(1) * 128 + torch.arange(128, device=dev).unsqueeze(0)).reshape(-1)
             rows = rows[rows < n]
             perm = perm[rows]
             xs = xs[rows]
-            self.n_compact = int((~wide).sum().item()) * 512
+            sizes = torch.full((nch,), 128, device=dev, dtype=torch.int64)
+            sizes[-1] = n - 128 * (nch - 1)
+            n0, n1 = (int(v) for v in torch.stack([sizes[cls == 0].sum(), sizes[cls == 1].sum()]).tolist())
+            self.n_compact, self.n_block = n0, n0 + n1
         else:
-            self.n_compact = n
-        self.r2 = float(r2c[~wide].max().item()) if self.n_compact else 0.0
+            self.n_compact = self.n_block = n
+        r2c = torch.where(cls == 0, r2_grp.repeat_interleave(4)[:nch], r2_128)[cls < 2]
+        self.r2 = float(r2c.max().item()) if self.n_block else 0.0
         self.perm = perm
         self.xs = xs.contiguous()
         ld = round_up(n, 4)
@@ -224,6 +230,28 @@ class SortedView:
         pad = nch * 128 - n
         xs_pad = torch.cat([self.xs, self.xs[-1:].expand(pad, -1)], 0) if pad else self.xs
         self.centers = xs_pad.reshape(nch, 128, dp).mean(1).contiguous()
+
+
+    @staticmethod
+    def _block_radii(xs: torch.Tensor, n: int, dp: int, ng: int):
+        """(largest |z - centre|^2 of every 128-row chunk of ``xs`` against its own centre [nch];  per 512-row group, the largest over its 128 /
+        256 / 512-row blocks [ng]) -- each block against ITS OWN centre as the kernels form it (csrc/gram_f16.hpp ``load_center``): the mean of
+        the centres of the block's 128-row chunks, chunk indices clamped to the last chunk; the last chunk is padded with copies of the last row
+        (what ``centers`` stores)."""
+        dev = xs.device
+        nch = (n + 127) // 128
+        pad = nch * 128 - n
+        xc = (torch.cat([xs, xs[-1:].expand(pad, -1)], 0) if pad else xs).reshape(nch, 128, dp)
+        c128 = xc.mean(1)
+        per_chunk = []
+        for m in (1, 2, 4):
+            nb = (nch + m - 1) // m
+            idx = (torch.arange(nb, device=dev).unsqueeze(1) * m + torch.arange(m, device=dev).unsqueeze(0)).clamp_max(nch - 1)
+            bc = c128[idx].mean(1)                                                        # [nb, dp] block centres
+            cb = bc[torch.arange(nch, device=dev) // m]                                    # the centre every chunk is measured against
+            per_chunk.append((xc - cb.unsqueeze(1)).pow(2).sum(-1).max(1).values)          # [nch]
+        worst = torch.maximum(per_chunk[0], torch.maximum(per_chunk[1], per_chunk[2]))
+        return per_chunk[0], torch.nn.functional.pad(worst, (0, ng * 4 - nch)).reshape(ng, 4).max(1).values
 
 
 def kind_id(xp: PreparedPoints) -> int:
@@ -255,11 +283,11 @@ def gram_mode(x1: PreparedPoints, x2: PreparedPoints) -> int:
     z2 = x2.zmax2 if x2 is not x1 else z1
     if max(z1, z2) <= GRAM_MAX_SQNORM:
         return 1
-    if (math.sqrt(z1) + math.sqrt(z2)) ** 2 <= GRAM_MAX_EXTENT_SQ and x1.n >= 128:
+    if (math.sqrt(z1) + math.sqrt(z2)) ** 2 <= (GRAM_MAX_EXTENT_SQ_RQ if x1.kind == "rq" else GRAM_MAX_EXTENT_SQ) and x1.n >= 128:
         sv = x1.sorted_view()
-        if x1.n - sv.n_compact <= GRAM_MAX_WIDE_FRACTION * x1.n:
+        if x1.n - sv.n_block <= GRAM_MAX_WIDE_FRACTION * x1.n:
             return 2
-        reason = (f"{x1.n - sv.n_compact} of {x1.n} points (d = {x1.d}) lie in 512-point runs of the Hilbert order wider than "
+        reason = (f"{x1.n - sv.n_block} of {x1.n} points (d = {x1.d}) lie in 128-point runs of the Hilbert order wider than "
                   f"|z - centre|^2 = {GRAM_MAX_BLOCK_SQRADIUS}")
     else:
         reason = f"cloud extent (max |x / lengthscale|^2 = {max(z1, z2):.0f}) outside the range of the split-f16 expansion"
@@ -359,20 +387,48 @@ def kv_plan(kind: str, n: int, m: int, d: int, t: int, flags: int, ldo: int):
 
 
 def gram_operands(x1: PreparedPoints, x2: PreparedPoints, flags: int):
-    """(X1 array, chunk centres or None, un-sort index or None, rows of the compact region) for a Gram-form launch of k(x1, x2).
-    Block-centred mode: the OUTPUT rows come out in x1's sorted order -- ``unsort`` (an index for ``index_select(1, .)`` on a probe-major
-    [t, round_up(n, 4)] block) takes them back; x2 and the right-hand sides stay in their original order."""
+    """(X1 array, chunk centres or None, un-sort index or None, rows of the compact region, rows of the compact + medium regions) for a
+    Gram-form launch of k(x1, x2).  Block-centred mode: the OUTPUT rows come out in x1's sorted order -- ``unsort`` (an index for
+    ``index_select(1, .)`` on a probe-major [t, round_up(n, 4)] block) takes them back; x2 and the right-hand sides stay in their original order."""
     if (flags & KV_GRAM) and FORCE_KV_FLAGS is None and gram_mode(x1, x2) == 2:
         sv = x1.sorted_view()
-        return sv.xs, sv.centers, sv.inv_pad, sv.n_compact
-    return x1.xp, None, None, x1.n
+        return sv.xs, sv.centers, sv.inv_pad, sv.n_compact, sv.n_block
+    return x1.xp, None, None, x1.n, x1.n
+
+
+def _kv_region(x1, x2, X1, Xc, row0: int, n_r: int, flags_r: int, vt, t: int, P, ldo: int, S: int, jc: int, done_ptr, st, slot: int, what: str):
+    """Rows [row0, row0 + n_r) of a block-centred product (row0 a multiple of 512) on the kernels ``flags_r`` selects, into the shared slabs P.
+    A region is a SMALLER product than the compact launch, possibly on another kernel: with that launch's split count it would leave most of the
+    chip idle -- measured on the reference's own workloads (profiles/r05_s1_workload_*_kernel_stats.csv): 11.3 ms for 10 % of the rows against
+    11.8 ms for the other 90 % (road3d shape), 0.83 against 0.31 ms (protein shape).  So it gets its own plan and, unless the plan coincides, its
+    own slabs (workspace ``slot``; always with the split-operand planes, which live behind the slabs): their sum lands in slab 0 of the shared
+    layout, the other slabs' rows are zeroed."""
+    L = lib()
+    assert row0 % 4 == 0
+    x1r = C.c_void_p(X1.data_ptr() + 4 * x1.dp * row0)
+    xcr = C.c_void_p(Xc.data_ptr() + 4 * x1.dp * (row0 // 128)) if (Xc is not None and (flags_r & KV_GRAM)) else None
+    ldr = round_up(n_r, 4)
+    Sr, jcr, wsr = kv_plan(x1.kind, n_r, x2.n, x1.d, t, flags_r, ldr)
+    if Sr == S and jcr == jc and not (flags_r & KV_SPLIT):
+        check(L.gpamd_kv_partials_f32(*kind_args(x1), x1r, n_r, _ptr(x2.xp), x2.n, x1.d, xcr, _ptr(vt), vt.stride(0), t,
+                                      C.c_void_p(P.data_ptr() + 4 * row0), ldo, S, jc, flags_r, done_ptr, st), f"kv_partials ({what})")
+        return
+    Pr = workspace(vt.device, wsr, slot=slot)
+    check(L.gpamd_kv_partials_f32(*kind_args(x1), x1r, n_r, _ptr(x2.xp), x2.n, x1.d, xcr, _ptr(vt), vt.stride(0), t, _ptr(Pr), ldr, Sr, jcr, flags_r,
+                                  done_ptr, st), f"kv_partials ({what})")
+    check(L.gpamd_kv_reduce_f32(_ptr(Pr), Sr, ldr, t, n_r, None, None, None, None, 0, C.c_void_p(P.data_ptr() + 4 * row0), ldo, done_ptr, st),
+          f"kv_reduce ({what})")
+    if S > 1:
+        P[: S * t * ldo].view(S, t, ldo)[1:, :, row0 : row0 + n_r].zero_()
 
 
 def kv_partials_sorted(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor, t: int, flags: int, P, ldo: int, S: int, jc: int, done_ptr, st):
     """One fused K*V launch group into the partial slabs P; returns the un-sort index of the output rows (None: original order).
-    Block-centred mode: the compact rows on the Gram-form kernels, the rows of the wide groups (``SortedView``) on the direct-difference
-    kernel -- a second launch into the same slabs, same split count and chunk length."""
-    X1, Xc, unsort, n_c = gram_operands(x1, x2, flags)
+    Block-centred mode (``SortedView``): the compact rows on the Gram-form kernels; the rows of the MEDIUM groups (128-row blocks within the
+    policy, larger ones not) on the kernels that centre 128-row blocks (flag GPAMD_KV_BLOCK128: the split kernel at one row tile per wave; column
+    groups it does not serve fall to the direct-difference kernels inside the library); the rows of the WIDE groups on the direct-difference
+    kernels -- further launches into the same slabs."""
+    X1, Xc, unsort, n_c, n_b = gram_operands(x1, x2, flags)
     L = lib()
     if n_c:
         check(
@@ -382,30 +438,10 @@ def kv_partials_sorted(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor,
             ),
             "kv_partials",
         )
-    if n_c < x1.n:
-        n_w = x1.n - n_c
-        x1w = C.c_void_p(X1.data_ptr() + 4 * x1.dp * n_c)
-        # The wide rows are a SMALLER product (<= 25 % of the rows) on a different kernel: with the split count of the compact launch it would
-        # leave most of the chip idle -- measured on the reference's own workloads (profiles/r05_s1_workload_*_kernel_stats.csv): 11.3 ms for 10 % of
-        # the rows against 11.8 ms for the other 90 % (road3d shape), 0.83 against 0.31 ms (protein shape).  It gets its own plan and slabs; their sum
-        # lands in slab 0 of the shared layout, the other slabs' rows are zeroed.
-        ldw = round_up(n_w, 4)
-        Sw, jcw, wsw = kv_plan(x1.kind, n_w, x2.n, x1.d, t, 0, ldw)
-        if Sw == S and jcw == jc:
-            check(L.gpamd_kv_partials_f32(*kind_args(x1), x1w, n_w, _ptr(x2.xp), x2.n, x1.d, None, _ptr(vt), vt.stride(0), t,
-                                          C.c_void_p(P.data_ptr() + 4 * n_c), ldo, S, jc, 0, done_ptr, st), "kv_partials (wide rows)")
-        else:
-            Pw = workspace(vt.device, wsw, slot=1)
-            check(L.gpamd_kv_partials_f32(*kind_args(x1), x1w, n_w, _ptr(x2.xp), x2.n, x1.d, None, _ptr(vt), vt.stride(0), t, _ptr(Pw), ldw, Sw, jcw, 0,
-                                          done_ptr, st), "kv_partials (wide rows)")
-            slabs = P[: S * t * ldo].view(S, t, ldo)
-            if n_c % 4 == 0:
-                check(L.gpamd_kv_reduce_f32(_ptr(Pw), Sw, ldw, t, n_w, None, None, None, None, 0, C.c_void_p(P.data_ptr() + 4 * n_c), ldo, done_ptr, st),
-                      "kv_reduce (wide rows)")
-            else:   # (the reduction kernel stores 16-byte vectors: an unaligned first wide row goes through torch)
-                slabs[0, :, n_c : x1.n] = Pw[: Sw * t * ldw].view(Sw, t, ldw)[:, :, :n_w].sum(0)
-            if S > 1:
-                slabs[1:, :, n_c : x1.n].zero_()
+    if n_b > n_c:
+        _kv_region(x1, x2, X1, Xc, n_c, n_b - n_c, flags | KV_BLOCK128, vt, t, P, ldo, S, jc, done_ptr, st, 1, "medium rows")
+    if n_b < x1.n:
+        _kv_region(x1, x2, X1, None, n_b, x1.n - n_b, 0, vt, t, P, ldo, S, jc, done_ptr, st, 2, "wide rows")
     return unsort
 
 
@@ -696,7 +732,7 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
         # (callers check grad_gram_ok first; a direct call outside the accuracy policy of the quadratic expansion must not pass silently)
         raise RuntimeError("kv_grad2: the clouds are outside the accuracy policy of the Gram-form expansion (backend.gram_mode == 0); "
                            "use kv_grad / kv_grad_generic")
-    X1, Xc, unsort, n_c = gram_operands(x1, x2, KV_GRAM)
+    X1, Xc, unsort, _, n_c = gram_operands(x1, x2, KV_GRAM)   # (the derivative kernel centres 128-row blocks: compact AND medium rows)
     n_rows = x1.n
     wide = None
     if unsort is not None:

@@ -73,6 +73,7 @@ struct KvVariant {
   int g4;      // > 0: kv_gram4 with this many column groups of four (2, 3, 6); 16 / 17: kv_gram16 without / with EX
   bool split;  // kv_gramh: contraction of hi/lo-split operands on the f16 matrix pipe (ct, ex as for mfma)
   int ni;      // kv_gramh: 32-row tiles per wave
+  bool gram;   // the selected kernel forms the squared distances by the quadratic expansion (false: direct differences)
   int bm;      // rows per workgroup
   int bn;      // j tile
 };
@@ -86,9 +87,16 @@ bool gram_ok(int kind, int flags);
 // tile above), GPAMD_KV_G4 sends 9..12 columns to kv_gram4 with three groups
 // small: few output rows (n < KGH_SMALL_N) -- the split kernels then take ONE 32-row tile per wave (128 rows per workgroup) so that
 // the launch still spreads over the chip
+// GPAMD_KV_BLOCK128 (the caller bounds the radius of 128-row blocks only): the split kernels take one row tile per wave (128 rows per workgroup, the
+// `small` geometry), every other column count leaves the Gram form (its kernels centre 256 / 512-row blocks) for the direct-difference kernels
 KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool small = false, int dk = 16) {   // dk: kernel dims (light: dk <= 3 and RBF)  // t <= 129 handled per launch group; light: RBF, d <= 3
   KvVariant v{};
   const bool wide = flags & GPAMD_KV_WIDE;
+  if (flags & GPAMD_KV_BLOCK128) {
+    if (gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KGH_GROUP + 1) small = true;
+    else gram = false;
+  }
+  v.gram = gram;
   if (gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KGH_GROUP + 1) {
     v.split = true;
     v.ex = (t % 32 == 1) ? 1 : 0;
@@ -216,7 +224,7 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex, int ni = 0) {
 bool gram_ok(int kind, int flags) { return (flags & GPAMD_KV_GRAM) && kind != GPAMD_MATERN12; }
 
 int kv_mode(int kind, int flags, int d, const KvVariant& v) {
-  const bool gram = gram_ok(kind, flags);
+  const bool gram = v.gram;   // (= gram_ok(kind, flags) unless GPAMD_KV_BLOCK128 sent this column group to the direct-difference kernels)
   if (v.split) return KV_MODE_GRAMH;
   if (v.g4) return KV_MODE_GRAM4;
   if (v.valu) return gram ? KV_MODE_GRAMV : KV_MODE_VALU;

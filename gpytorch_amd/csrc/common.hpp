@@ -85,15 +85,80 @@ __device__ __forceinline__ float dcov_dsq(float s, float p = 0.f) {
   }
 }
 
+// ---- float64 exp2 / exp / sqrt of the float64 generation (kv_f64.hpp, the generic row-block kernels).  The float64 kernels are bound by the VALU
+// work per covariance value, which issues ALONGSIDE the float64 MFMAs, not under them (profiles/r04_s10_kv_f64_pmc.json: ~5 cycles per VALU
+// instruction + 64 per MFMA, additive): the library's exp2 / exp / sqrt carry ~35 / ~35 / ~17 instructions each (special cases, range scaling for
+// denormal and huge arguments).  Here the argument is known to be <= 0 (resp. >= 0) and far inside the exponent range, so:
+//   exp2(x), x <= 0: n = rint(x), f = x - n in [-1/2, 1/2] (exact), 2^f by a degree-11 polynomial (Chebyshev-node interpolant, 2.0e-17 relative in
+//       exact arithmetic, coefficients from mpmath at 60 digits; c0 = 1 exactly so that k(x, x) = 1), v_ldexp_f64 -- 17 instructions;
+//   exp(x),  x <= 0: n = rint(x log2 e), f = x - n ln2 with ln2 = hi + lo (hi has 11 trailing zero bits: n hi exact for |n| < 2048), e^f likewise (1.7e-17);
+//   sqrt(s), s >= 0: v_rsq_f64 seed, one Goldschmidt step and two residual corrections (the compiler's own expansion without its range scaling).
+// No clamp of the argument: v_cvt_i32_f64 saturates (written as an instruction -- the C++ conversion of an out-of-range double is undefined) and
+// v_ldexp_f64 with an exponent below -1100 returns zero, so arbitrarily distant pairs give k = 0; NaN arguments stay NaN.  Results within 2-3e-16
+// relative of the correctly rounded values (tests/test_gpu_generic.py compares the entries with float64 torch at 1e-12).
+__device__ __forceinline__ int cvt_i32_sat_f64(double n) {
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(n));
+  return r;
+}
+__device__ __forceinline__ double exp2_nonpos_f64(double x) {
+  const double n = __builtin_rint(x);
+  const double f = x - n;
+  double p = 4.4558179083360645e-10;
+  p = __builtin_fma(p, f, 7.074194297288521e-09);
+  p = __builtin_fma(p, f, 1.0178057087733941e-07);
+  p = __builtin_fma(p, f, 1.3215432535912375e-06);
+  p = __builtin_fma(p, f, 1.5252733841556773e-05);
+  p = __builtin_fma(p, f, 0.00015403530463724353);
+  p = __builtin_fma(p, f, 0.001333355814640647);
+  p = __builtin_fma(p, f, 0.009618129107587256);
+  p = __builtin_fma(p, f, 0.055504108664821625);
+  p = __builtin_fma(p, f, 0.24022650695910158);
+  p = __builtin_fma(p, f, 0.6931471805599453);
+  p = __builtin_fma(p, f, 1.0);
+  return __builtin_ldexp(p, cvt_i32_sat_f64(n));
+}
+__device__ __forceinline__ double exp_nonpos_f64(double x) {
+  x = x < -800.0 ? -800.0 : x;   // (n ln2_hi is exact for |n| < 2048 only; e^-800 is zero; a compare-select, not v_max: NaN stays NaN)
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double f = __builtin_fma(n, -0x1.62e42fefa3800p-1, x);
+  f = __builtin_fma(n, -5.497923018708371e-14, f);
+  double p = 2.511003761756205e-08;
+  p = __builtin_fma(p, f, 2.763263965412376e-07);
+  p = __builtin_fma(p, f, 2.7557240918547625e-06);
+  p = __builtin_fma(p, f, 2.480148548228773e-05);
+  p = __builtin_fma(p, f, 0.00019841269890047143);
+  p = __builtin_fma(p, f, 0.0013888888952314812);
+  p = __builtin_fma(p, f, 0.008333333333319601);
+  p = __builtin_fma(p, f, 0.04166666666648809);
+  p = __builtin_fma(p, f, 0.1666666666666668);
+  p = __builtin_fma(p, f, 0.5000000000000019);
+  p = __builtin_fma(p, f, 1.0);
+  p = __builtin_fma(p, f, 1.0);
+  return __builtin_ldexp(p, cvt_i32_sat_f64(n));
+}
+__device__ __forceinline__ double sqrt_nonneg_f64(double s) {
+  const double y = __builtin_amdgcn_rsq(s);
+  double g = s * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, s);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, s);
+  g = __builtin_fma(d, h, g);
+  return s > 0.0 ? g : s;          // s = 0: the seed is infinite; NaN stays NaN
+}
+
 template <int KIND>
 __device__ __forceinline__ double cov_from_sq_f64(double s, double p = 0.0) {
   if constexpr (KIND == KIND_RBF) {
-    return exp2(-s);
+    return exp2_nonpos_f64(-s);
   } else if constexpr (KIND == KIND_RQ) {
     return pow(1.0 + s, -p);
   } else {
-    double r = sqrt(s);
-    double e = exp(-r);
+    double r = sqrt_nonneg_f64(s);
+    double e = exp_nonpos_f64(-r);
     if constexpr (KIND == KIND_MATERN12) return e;
     if constexpr (KIND == KIND_MATERN32) return (1.0 + r) * e;
     return (1.0 + r + s * (1.0 / 3.0)) * e;
@@ -103,12 +168,12 @@ __device__ __forceinline__ double cov_from_sq_f64(double s, double p = 0.0) {
 template <int KIND>
 __device__ __forceinline__ double dcov_dsq_f64(double s, double p = 0.0) {
   if constexpr (KIND == KIND_RBF) {
-    return -0.6931471805599453 * exp2(-s);
+    return -0.6931471805599453 * exp2_nonpos_f64(-s);
   } else if constexpr (KIND == KIND_RQ) {
     return -p * pow(1.0 + s, -p - 1.0);
   } else {
-    double r = sqrt(s);
-    double e = exp(-r);
+    double r = sqrt_nonneg_f64(s);
+    double e = exp_nonpos_f64(-r);
     if constexpr (KIND == KIND_MATERN12) return r > 1e-150 ? -0.5 * e / r : 0.0;
     if constexpr (KIND == KIND_MATERN32) return -0.5 * e;
     return -(1.0 + r) * e * (1.0 / 6.0);

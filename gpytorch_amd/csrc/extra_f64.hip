@@ -180,6 +180,25 @@ const void* kv64_ptr_dp(int dp, int ct) {
   }
   return nullptr;
 }
+// t <= 4: the VALU-contraction kernel (kv_f64.hpp kv_f64v_kernel), one or four accumulator columns
+template <int KIND>
+const void* kv64v_ptr_dp(int dp, int tv) {
+#define L(DPV) \
+  case DPV: return tv == 1 ? reinterpret_cast<const void*>(&kv_f64v_kernel<KIND, DPV, 1>) : reinterpret_cast<const void*>(&kv_f64v_kernel<KIND, DPV, 4>);
+  switch (dp) { L(4) L(8) L(12) L(16) }
+#undef L
+  return nullptr;
+}
+const void* kv64v_ptr(int kind, int dp, int tv) {
+  switch (kind) {
+    case GPAMD_RBF: return kv64v_ptr_dp<KIND_RBF>(dp, tv);
+    case GPAMD_MATERN12: return kv64v_ptr_dp<KIND_MATERN12>(dp, tv);
+    case GPAMD_MATERN32: return kv64v_ptr_dp<KIND_MATERN32>(dp, tv);
+    case GPAMD_MATERN52: return kv64v_ptr_dp<KIND_MATERN52>(dp, tv);
+    case GPAMD_RQ: return kv64v_ptr_dp<KIND_RQ>(dp, tv);
+  }
+  return nullptr;
+}
 const void* kv64_ptr(int kind, int dp, int ct) {
   switch (kind) {
     case GPAMD_RBF: return kv64_ptr_dp<KIND_RBF>(dp, ct);
@@ -269,7 +288,7 @@ int gpamd_kv_partials_f64(int kind, double kparam, const double* X1p, int n, con
     a.nrb = (n + kv64_bm(ct, dp) - 1) / kv64_bm(ct, dp);
     a.done = done;
     a.kparam = kparam;
-    const void* fn = kv64_ptr(kind, dp, ct);
+    const void* fn = tg <= 4 ? kv64v_ptr(kind, dp, tg == 1 ? 1 : 4) : kv64_ptr(kind, dp, ct);   // (same row block as ct = 1: the plan does not change)
     if (!fn) return fail64(GPAMD_EUNSUPPORTED, "kv_f64: no kernel variant");
     void* kargs[] = {(void*)&a};
     (void)hipLaunchKernel(fn, dim3((unsigned)a.nrb * (unsigned)S), dim3(256), kargs, 0, (hipStream_t)stream);

@@ -76,6 +76,12 @@ __device__ __forceinline__ void sub_center(float* z, const float* cz) {
   for (int k = 0; k < DP; ++k) z[k] -= cz[k];
 }
 
+// |z_j - c|^2 of a contracted point far from the row block (block-centred mode: up to the extent of the cloud) must stay inside the f16 range of
+// its hi part.  It saturates at 60000: for an output row within the block policy (|z_i - c|^2 <= 32) the expansion then gives
+// S >= 60000 - 2 sqrt(32) |z_j - c| >= 2000 as long as |z_j - c| <= 5000 (the host's extent limit, backend.GRAM_MAX_EXTENT_SQ) -- exp2(-2000) and
+// exp(-sqrt(2000)) poly are zero in f32 like the true values, so the saturation is invisible for RBF / Matern; the heavy-tailed RQ keeps the unsaturated range.
+__device__ __forceinline__ float gram_norm_clamp(float nn) { return __builtin_fminf(nn, 60000.f); }
+
 // A side (contracted points x_j): slot s of a row with coordinates split into zh/zl and |z|^2 into nh/nl
 template <int D>
 __device__ __forceinline__ _Float16 gram_slot_a(int s, const _Float16* zh, const _Float16* zl, _Float16 nh, _Float16 nl,
@@ -128,7 +134,7 @@ __device__ __forceinline__ void gram_pack_a_lane(const float* z, bool valid, int
     nn = __builtin_fmaf(z[k], z[k], nn);
     f16_split(z[k], zh[k], zl[k]);
   }
-  f16_split(nn, nh, nl);
+  f16_split(gram_norm_clamp(nn), nh, nl);
   const _Float16 one = valid ? (_Float16)1.f : (_Float16)0.f;
 #pragma unroll
   for (int kh = 0; kh < KH; ++kh)
@@ -161,7 +167,7 @@ __device__ __forceinline__ void gram_pack_a(const float* z, bool valid, _Float16
     nn = __builtin_fmaf(z[k], z[k], nn);
     f16_split(z[k], zh[k], zl[k]);
   }
-  f16_split(nn, nh, nl);
+  f16_split(gram_norm_clamp(nn), nh, nl);
   const _Float16 one = valid ? (_Float16)1.f : (_Float16)0.f;
 #pragma unroll
   for (int kh = 0; kh < KH; ++kh)

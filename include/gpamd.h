@@ -51,7 +51,11 @@ enum {
    * v_mfma_f32_32x32x16_f16 in place of eight v_mfma_f32_32x32x2_f32 (kv_gramh.hpp).  The f16 planes of V live behind the
    * partial slabs of the workspace: size it with gpamd_kv_plan called with the same flags and pass the plan's jchunk (a multiple of
    * 128); the workspace must be 16-byte aligned and ldo a multiple of 4. */
-  GPAMD_KV_SPLIT = 8
+  GPAMD_KV_SPLIT = 8,
+  /* with GRAM and block centres X1c: the caller bounds the radius of 128-row aligned blocks only (not of the 256 / 512-row blocks the larger
+   * row tilings centre): column groups of 5..65 columns with SPLIT run the split kernels at one row tile per wave (128 rows per workgroup),
+   * every other column group takes the direct-difference kernels. */
+  GPAMD_KV_BLOCK128 = 16
 };
 
 int gpamd_abi_version(void);
@@ -78,8 +82,9 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
  *   then taken relative to the centre of the workgroup's row block (squared distances are translation invariant), so its cancellation
  *   error scales with the BLOCK radius instead of the cloud radius -- the reference's Gram-trick distance has no scale limit
  *   (gpytorch/kernels/kernel.py:26-49).  The caller sorts the rows of X1p along a space-filling curve so that blocks are compact and
- *   asserts: max over 128 / 256 / 512-row aligned blocks of |z - centre|^2 <= 8 and (max |z1| + max |z2|)^2 <= 60000 (f16 range of
- *   the split norms).  With X1c = NULL the GPAMD_KV_GRAM contract is the cloud-centred one (max |z|^2 <= 32). */
+ *   asserts: max over 128 / 256 / 512-row aligned blocks (GPAMD_KV_BLOCK128: 128-row blocks) of |z - centre|^2 <= 32 and
+ *   (max |z1| + max |z2|)^2 <= 2.5e7 (RQ: 60000 -- the split norm of a contracted point saturates at 60000, f16 range; every family but the
+ *   heavy-tailed RQ is zero to f32 precision long before, gram_f16.hpp).  With X1c = NULL the GPAMD_KV_GRAM contract is the cloud-centred one (max |z|^2 <= 32). */
 int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt,
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream);

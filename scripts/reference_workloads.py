@@ -87,7 +87,9 @@ def _path(m, lik):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             mode = B.gram_mode(p1, p1)
-        wide = 0 if mode != 2 else p1.n - p1.sorted_view().n_compact
+        wide = 0 if mode != 2 else p1.n - p1.sorted_view().n_block   # rows on the direct-difference kernels (medium rows -- 128-row blocks -- stay on the Gram form)
+        _path.last_regions = None if mode != 2 else {"compact_rows": p1.sorted_view().n_compact, "medium_rows": p1.sorted_view().n_block - p1.sorted_view().n_compact,
+                                                      "wide_rows": wide}
     return {0: "direct-difference kernels (outside the Gram-form policy)", 1: "Gram form, cloud-centred", 2: "Gram form, block-centred"}[mode], float(p1.zmax2), wide
 
 

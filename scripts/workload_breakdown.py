@@ -21,7 +21,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from scripts.reference_workloads import _model, gaussian_features, road_like  # noqa: E402
+from scripts.reference_workloads import _model, _path, gaussian_features, road_like  # noqa: E402
 
 workload, mode = sys.argv[1], sys.argv[2]
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else (3 if workload == "road3d" else 5)
@@ -74,7 +74,7 @@ if workload == "road3d":
     n = 217_437
     X, y = road_like(n, 0)
     m, lik = _model(g, "matern52", X, y, dev)
-    stages = [("lengthscale 0.05 (start of training: direct-difference kernels)", 0.05), ("lengthscale 0.2 (later iterations: block-centred Gram form)", 0.2)]
+    stages = [("lengthscale 0.05 (start of training)", 0.05), ("lengthscale 0.1", 0.1), ("lengthscale 0.2 (later iterations)", 0.2)]
 else:
     n = 36_584
     X, y = gaussian_features(n, 9, 0)
@@ -123,6 +123,9 @@ with warnings.catch_warnings():
                         e[1] += v_
                         e[2] += 1
         st = {"stage": label, "seconds_per_iteration": walls, "cg_iterations": its}
+        pth = _path(m, lik)
+        m.train(), lik.train()
+        st["kernel_path"], st["max_sq_scaled_radius"], st["rows_by_region"] = pth[0], pth[1], getattr(_path, "last_regions", None)
         if mode == "phases":
             st["phases_exclusive_seconds_per_iteration"] = {k_: v_[0] / iters for k_, v_ in sorted(acc.items(), key=lambda kv: -kv[1][0])}
             st["phases_inclusive_seconds_per_iteration"] = {k_: v_[1] / iters for k_, v_ in acc.items()}

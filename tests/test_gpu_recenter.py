@@ -267,3 +267,80 @@ def test_backward_on_a_heavy_tailed_cloud_sends_the_wide_rows_to_the_direct_path
     tail = sv.perm[sv.n_compact :].cpu()
     assert float(err[tail].max()) < 1e-4, float(err[tail].max())
     assert float((gz.double().cpu() - gzr).norm() / gzr.norm()) < 2e-5
+
+
+def _road_cloud(n, seed=3):
+    """Points along a few smooth planar curves with a slowly varying third coordinate (locally one-dimensional, like a road network)."""
+    g = torch.Generator().manual_seed(seed)
+    roads = 12
+    per = (n + roads - 1) // roads
+    t = torch.linspace(0, 1, per, dtype=torch.float64).unsqueeze(0)
+    p0 = torch.rand(roads, 1, 2, generator=g, dtype=torch.float64) * 3.0
+    ang = torch.rand(roads, 1, generator=g, dtype=torch.float64) * 2 * math.pi
+    curv = (torch.rand(roads, 1, generator=g, dtype=torch.float64) - 0.5) * 5.0
+    th = ang + curv * t
+    step = 1.5 / per
+    xy = p0 + torch.stack([torch.cumsum(torch.cos(th) * step, 1), torch.cumsum(torch.sin(th) * step, 1)], -1)
+    xy = xy.reshape(-1, 2)[:n]
+    X = torch.cat([xy, (torch.sin(0.7 * xy[:, 0]) * torch.cos(0.5 * xy[:, 1])).unsqueeze(-1)], -1)
+    X = X + 1e-3 * torch.randn(X.shape, generator=g, dtype=torch.float64)
+    return X[torch.randperm(n, generator=g)].float().contiguous()
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "split"])
+@pytest.mark.parametrize("kind,ls", [("matern52", 0.04), ("rbf", 0.015)])
+def test_elongated_runs_take_the_128_row_blocks(kind, ls, split, dev, monkeypatch):
+    """Round 5.  Points along curves at a short lengthscale: 512-row runs of the Hilbert order are elongated (radius outside the policy), their
+    128-row chunks are not -- ``SortedView``'s MEDIUM region, served by the kernels that centre 128-row blocks (the split kernel at one row tile per
+    wave, flag GPAMD_KV_BLOCK128; every other column group falls to the direct-difference kernels inside the library).  The cloud's extent
+    (max |z|^2 ~ 24 000) is also beyond the f16 range of the split norms: they saturate (csrc/gram_f16.hpp gram_norm_clamp).  Every column-count
+    kernel against float64 rows, plus the backward (the derivative kernel centres 128-row blocks)."""
+    from gpytorch_amd import backend as B
+
+    monkeypatch.setattr(B, "SPLIT_CONTRACTION", split)
+    n = 30_000
+    X = _road_cloud(n)
+    Xd = X.to(dev)
+    xp = B.prep_points(kind, Xd, torch.tensor([ls]), Xd.mean(0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # no fall-back warning: the product stays on the Gram-form kernels
+        assert B.gram_mode(xp, xp) == 2
+    sv = xp.sorted_view()
+    assert xp.zmax2 > 20_000.0                              # (max |z1| + max |z2|)^2 > 80 000: the old f16-range limit of the split norms was 60 000
+    assert sv.n_block - sv.n_compact > 0.25 * n, (sv.n_compact, sv.n_block)      # there ARE medium rows ...
+    assert sv.n_compact % 512 == 0 and sv.n_block % 128 == 0
+    g = torch.Generator().manual_seed(11)
+    rows = torch.cat([sv.perm[:64].cpu(), sv.perm[sv.n_compact : sv.n_compact + 256].cpu(), sv.perm[sv.n_block - 128 : sv.n_block].cpu(), sv.perm[-64:].cpu(),
+                      torch.randint(0, n, (200,), generator=g)]).unique()
+    Krows = OK.kernel_matrix(kind, X[rows].double(), X.double(), ls, 1.0, x1_eq_x2=False, direct=True)
+    for t in (1, 4, 11, 17, 33, 65, 70):
+        V = torch.randn(n, t, generator=torch.Generator().manual_seed(t))
+        out_t = B.kv(xp, xp, B.to_probe_major(V.to(dev)))
+        got = out_t[:, rows.to(dev)].t().double().cpu()
+        ref = Krows @ V.double()
+        assert rel_err(got, ref) < 2e-5, (kind, t, rel_err(got, ref))
+    # the entries themselves on medium rows
+    cols = rows[:48]
+    E = torch.zeros(n, cols.numel())
+    E[cols, torch.arange(cols.numel())] = 1.0
+    got = B.kv(xp, xp, B.to_probe_major(E.to(dev)))[:, rows.to(dev)].t().double().cpu()
+    assert float((got - Krows[:, cols]).abs().max()) < 2e-5
+    # backward sums against float64 autograd on the prepared coordinates (n small enough for dense float64 on the device)
+    nb, t = 6144, 12
+    Xb = X[:nb].to(dev)
+    xb = B.prep_points(kind, Xb, torch.tensor([ls * 5.0]), Xb.mean(0))          # (a fifth of the points at five times the lengthscale: the same spacing)
+    assert B.gram_mode(xb, xb) == 2 and xb.sorted_view().n_block - xb.sorted_view().n_compact > 0.25 * nb
+    Lv = torch.randn(nb, t, generator=g, dtype=torch.float64).abs()
+    Rv = torch.randn(nb, t, generator=g, dtype=torch.float64).abs()
+    out, _ = B.kv_grad2(xb, xb, B.to_probe_major(Lv.float().to(dev)), B.to_probe_major(Rv.float().to(dev)), iso=True)
+    z = xb.xp[:, :3].double()
+    S = (z.unsqueeze(1) - z.unsqueeze(0)).pow(2).sum(-1)
+    if kind == "rbf":
+        Kd, dK = torch.exp2(-S), -math.log(2.0) * torch.exp2(-S)
+    else:
+        r = S.sqrt()
+        Kd, dK = (1.0 + r + S / 3.0) * torch.exp(-r), -(1.0 + r) * torch.exp(-r) / 6.0
+    W = Lv.to(dev) @ Rv.to(dev).t()
+    tot, gs = float((W * Kd).sum()), float((W * dK * S).sum())
+    assert abs(float(out[0]) - tot) < 2e-5 * abs(tot)
+    assert abs(float(out[1]) - gs) < 5e-5 * abs(gs)          # sum W dk/ds s: the single-lengthscale sum (MODE 0 convention: out[1])

@@ -180,11 +180,32 @@ def test_sorted_view_host_logic():
     xpg[:, :3] = gauss
     svg = B.PreparedPoints(xpg, 100_001, 3, 4, "rbf").sorted_view()
     assert 0 < 100_001 - svg.n_compact < 0.2 * 100_001 and svg.n_compact % 512 == 0
+    # (round 5) three regions: compact 512-row groups | medium 128-row chunks (within the policy against their OWN centre) | wide chunks
+    assert svg.n_compact <= svg.n_block <= 100_001 and svg.n_block % 128 == 0 and 100_001 - svg.n_block < 100_001 - svg.n_compact
     assert sorted(svg.perm.tolist()) == list(range(100_001))
     # compact region: the radius bound, recomputed here for the 512-row blocks with the kernels' centre formula
     blk = svg.xs[: svg.n_compact].reshape(-1, 512, 4)
     cen = svg.centers[: svg.n_compact // 128].reshape(-1, 4, 4).mean(1, keepdim=True)
     assert float((blk - cen).pow(2).sum(-1).max()) <= B.GRAM_MAX_BLOCK_SQRADIUS * (1 + 1e-5)
+    # medium region: every 128-row chunk against its own centre; and it is not empty of chunks whose 512-row run would have failed
+    blk = svg.xs[svg.n_compact : svg.n_block].reshape(-1, 128, 4)
+    cen = svg.centers[svg.n_compact // 128 : svg.n_block // 128].unsqueeze(1)
+    assert float((blk - cen).pow(2).sum(-1).max()) <= B.GRAM_MAX_BLOCK_SQRADIUS * (1 + 1e-5)
+    # wide region: every chunk there fails the 128-row test (nothing admissible was left behind), except possibly the ragged last chunk
+    nw = (100_001 - svg.n_block) // 128
+    blk = svg.xs[svg.n_block : svg.n_block + 128 * nw].reshape(-1, 128, 4)
+    cen = svg.centers[svg.n_block // 128 : svg.n_block // 128 + nw].unsqueeze(1)
+    assert float((blk - cen).pow(2).sum(-1).max(1).values.min()) > B.GRAM_MAX_BLOCK_SQRADIUS
+    # points along a curve (a road network is locally one-dimensional): 512-row runs are elongated, 128-row chunks are not -> medium, not wide
+    tt = torch.linspace(0, 1, 40_000, dtype=torch.float64)
+    curve = torch.stack([800.0 * tt, 20.0 * torch.sin(7.0 * tt), torch.zeros_like(tt)], -1).float()
+    xpc = torch.zeros(40_000, 4)
+    xpc[:, :3] = curve[torch.randperm(40_000, generator=g)]
+    svc = B.PreparedPoints(xpc, 40_000, 3, 4, "matern52").sorted_view()
+    assert svc.n_block - svc.n_compact > 0.4 * 40_000 and svc.n_block > 0.75 * 40_000   # (the Hilbert order does not follow the curve everywhere)
+    with __import__("warnings").catch_warnings():
+        __import__("warnings").simplefilter("error")
+        assert B.gram_mode(B.PreparedPoints(xpc, 40_000, 3, 4, "matern52"), B.PreparedPoints(xpc, 40_000, 3, 4, "matern52")) in (0, 2)
     # Hilbert order: consecutive cells of a full grid are face neighbours (no jumps, unlike the Z-order curve)
     grid = torch.stack(torch.meshgrid(*[torch.arange(8.0)] * 3, indexing="ij"), -1).reshape(-1, 3)
     pg = grid[B.hilbert_order(grid, bits=3)]
@@ -334,7 +355,8 @@ def test_hilbert_order_cache_is_keyed_by_source_and_guarded_by_a_fingerprint():
         # the same cloud at another lengthscale (uniformly rescaled, shifted): the cached permutation is re-used, no second Hilbert transform
         pa2 = B.PreparedPoints(xa * 0.37 + torch.tensor([1.0, -2.0, 0.5, 0.0]), n, 3, 4, "rbf")
         pa2.order_key = key
-        assert torch.equal(pa2.sorted_view().perm, perm_a) and len(calls) == 1
+        # (the region split -- compact | medium | wide -- is re-evaluated on the ACTUAL coordinates, so the final order may differ; the curve order is shared)
+        assert sorted(pa2.sorted_view().perm.tolist()) == list(range(n)) and len(calls) == 1
         # another cloud behind the same key (address re-use): fingerprint mismatch -> its own order, and the entry is replaced
         pb = B.PreparedPoints(xb, n, 3, 4, "rbf")
         pb.order_key = key
