@@ -63,6 +63,7 @@ GRAM_MAX_WIDE_FRACTION = 0.8    # (0.25 until round 5: any row off the direct-di
 # the heavy-tailed RQ keeps the unsaturated range
 GRAM_MAX_EXTENT_SQ = 2.5e7
 GRAM_MAX_EXTENT_SQ_RQ = 60000.0
+DIRECT_SPLIT_MAX_DIM = 10   # csrc/kv_directh.hpp KDH_MAX_DIM
 KV_BLOCK128 = 16         # flag of gpamd_kv_partials_f32: the caller bounds 128-row blocks only (SortedView's medium groups)
 _warned_fallback = set()
 FORCE_GENERIC = False    # tests: send float32 / d <= 16 problems down the generic (row-block + GEMM) path too
@@ -307,10 +308,6 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
         return 0
     if FORCE_KV_FLAGS is not None:
         return FORCE_KV_FLAGS
-    if x1.kind == "matern12":
-        return 0
-    if gram_mode(x1, x2) == 0:
-        return 0
     if SPLIT_CONTRACTION is None:
         # no size rule: the three extra launches of the pre-pass do not make small products slower -- measured, mBCG per iteration
         # with the fp32-MFMA contraction instead: 107 vs 57 us at n = 2000, 231 vs 105 us at n = 5000, 229 vs 144 us at n = 20 000
@@ -318,6 +315,9 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
         split = _split_on()
     else:
         split = SPLIT_CONTRACTION
+    if x1.kind == "matern12" or gram_mode(x1, x2) == 0:
+        # direct differences: the contraction still goes to the f16 matrix pipe (csrc/kv_directh.hpp, 5 .. 32 columns per group, d <= 10)
+        return KV_SPLIT if (split and x1.d <= DIRECT_SPLIT_MAX_DIM) else 0
     return KV_GRAM | (KV_SPLIT if split else 0)
 
 
@@ -441,7 +441,8 @@ def kv_partials_sorted(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor,
     if n_b > n_c:
         _kv_region(x1, x2, X1, Xc, n_c, n_b - n_c, flags | KV_BLOCK128, vt, t, P, ldo, S, jc, done_ptr, st, 1, "medium rows")
     if n_b < x1.n:
-        _kv_region(x1, x2, X1, None, n_b, x1.n - n_b, 0, vt, t, P, ldo, S, jc, done_ptr, st, 2, "wide rows")
+        wflags = KV_SPLIT if ((flags & KV_SPLIT) and x1.d <= DIRECT_SPLIT_MAX_DIM) else 0   # direct differences (+ the split contraction, kv_directh.hpp)
+        _kv_region(x1, x2, X1, None, n_b, x1.n - n_b, wflags, vt, t, P, ldo, S, jc, done_ptr, st, 2, "wide rows")
     return unsort
 
 

@@ -16,6 +16,7 @@
 #include "kv_gram4.hpp"
 #include "kv_gram16.hpp"
 #include "kv_vsplit.hpp"
+#include "kv_directh.hpp"
 #include "misc_kernels.hpp"
 
 using namespace gpamd;
@@ -74,6 +75,7 @@ struct KvVariant {
   bool split;  // kv_gramh: contraction of hi/lo-split operands on the f16 matrix pipe (ct, ex as for mfma)
   int ni;      // kv_gramh: 32-row tiles per wave
   bool gram;   // the selected kernel forms the squared distances by the quadratic expansion (false: direct differences)
+  bool direct; // with split: kv_directh (direct differences + split contraction; one column tile, no extra column)
   int bm;      // rows per workgroup
   int bn;      // j tile
 };
@@ -105,6 +107,16 @@ KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool
     // column, the light generation of the RBF only (the other families would spill 7..15 registers there)
     v.ni = small ? 1 : kgh_ni(v.ct, (v.ex && !light && dk <= 16) ? 16 : dk);
     v.bm = kgh_bm(v.ni);
+    v.bn = KGH_BN;
+  } else if (!gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KDH_COLS && dk <= KDH_MAX_DIM) {
+    // direct differences (clouds / rows outside the policy of the quadratic expansion, Matern nu = 1/2) with the contraction on the f16 matrix pipe
+    // (kv_directh.hpp): the VALU keeps the generation only -- 9.8 instead of ~17 VALU instructions per pair at d = 3, eleven columns
+    v.split = true;
+    v.direct = true;
+    v.ct = 1;
+    v.ex = 0;
+    v.ni = kdh_ni(small);
+    v.bm = kdh_bm(v.ni);
     v.bn = KGH_BN;
   } else if (gram && !wide && t >= 5 && t <= 24 && dk <= 16) {   // (beyond 16 dimensions: no 4-column / 16-column tile kernels -- kv_gramv up to 16 columns, the 32-column tile above)
     if (t <= 8) v.g4 = 2;
@@ -142,14 +154,16 @@ KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool
 constexpr int KV_GROUP = 128;  // columns per launch group (CT = 4); a trailing 129th column rides as EX
 
 bool split_on(int kind, int flags) { return gram_ok(kind, flags) && (flags & GPAMD_KV_SPLIT); }
+// direct differences + split contraction (kv_directh.hpp): SPLIT without an applicable GRAM, up to KDH_MAX_DIM dimensions
+bool dsplit_on(int kind, int flags, int d) { return !gram_ok(kind, flags) && (flags & GPAMD_KV_SPLIT) && kv_kernel_dims(d) <= KDH_MAX_DIM; }
 
 // split [0, t) into launch groups of <= cap (+1) columns: cap = 128, or 64 for the split-operand kernels
 int group_cols(int t, int g0, int cap = KV_GROUP) {
   int rem = t - g0;
-  if (rem <= cap + 1) return rem;  // includes the cap + EX case
+  if (rem <= cap + (cap == KDH_COLS ? 0 : 1)) return rem;  // includes the cap + EX case (the direct-difference split kernel has no extra column)
   return cap;
 }
-int group_cap(int kind, int flags) { return split_on(kind, flags) ? KGH_GROUP : KV_GROUP; }
+int group_cap(int kind, int flags, int d) { return split_on(kind, flags) ? KGH_GROUP : (dsplit_on(kind, flags, d) ? KDH_COLS : KV_GROUP); }
 
 // Split-operand launches keep, behind the S partial slabs of the workspace: column maxima | column multipliers | the two f16
 // planes of every launch group (32 ct rows of ldh positions each).  Offsets in floats, all multiples of 4.
@@ -158,16 +172,16 @@ struct SplitLayout {
   int64_t ldh;
   int rows;                                      // plane rows over all split groups
 };
-SplitLayout split_layout(int kind, int flags, int m, int t, int S, int64_t ldo) {
+SplitLayout split_layout(int kind, int flags, int m, int d, int t, int S, int64_t ldo) {
   SplitLayout L{};
   L.base = ((int64_t)S * t * ldo + 3) / 4 * 4;
   L.ldh = ((int64_t)m + KGH_BN - 1) / KGH_BN * KGH_BN;
-  if (!split_on(kind, flags)) return L;
-  const int cap = group_cap(kind, flags);
+  if (!split_on(kind, flags) && !dsplit_on(kind, flags, d)) return L;
+  const int cap = group_cap(kind, flags, d);
   int rows = 0;
   for (int g0 = 0; g0 < t;) {
     const int tg = group_cols(t, g0, cap);
-    KvVariant v = pick_variant(tg, true, flags, false, false);   // (row tiling does not change the plane rows)
+    KvVariant v = pick_variant(tg, gram_ok(kind, flags), flags, false, false, kv_kernel_dims(d));   // (row tiling does not change the plane rows)
     if (v.split) rows += 32 * v.ct;
     g0 += tg;
   }
@@ -190,6 +204,16 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex, int ni = 0) {
       case GPAMD_MATERN32: return kvh_kernel_ptr_matern32(d, v, ex, ni);
       case GPAMD_MATERN52: return kvh_kernel_ptr_matern52(d, v, ex, ni);
       case GPAMD_RQ: return kvh_kernel_ptr_rq(d, v, ex, ni);
+    }
+    return nullptr;
+  }
+  if (mode == KV_MODE_DIRECTH) {
+    switch (kind) {
+      case GPAMD_RBF: return kvd_kernel_ptr_rbf(d, ni);
+      case GPAMD_MATERN12: return kvd_kernel_ptr_matern12(d, ni);
+      case GPAMD_MATERN32: return kvd_kernel_ptr_matern32(d, ni);
+      case GPAMD_MATERN52: return kvd_kernel_ptr_matern52(d, ni);
+      case GPAMD_RQ: return kvd_kernel_ptr_rq(d, ni);
     }
     return nullptr;
   }
@@ -225,7 +249,7 @@ bool gram_ok(int kind, int flags) { return (flags & GPAMD_KV_GRAM) && kind != GP
 
 int kv_mode(int kind, int flags, int d, const KvVariant& v) {
   const bool gram = v.gram;   // (= gram_ok(kind, flags) unless GPAMD_KV_BLOCK128 sent this column group to the direct-difference kernels)
-  if (v.split) return KV_MODE_GRAMH;
+  if (v.split) return v.direct ? KV_MODE_DIRECTH : KV_MODE_GRAMH;
   if (v.g4) return KV_MODE_GRAM4;
   if (v.valu) return gram ? KV_MODE_GRAMV : KV_MODE_VALU;
   return gram ? KV_MODE_GRAM : KV_MODE_MFMA;
@@ -259,8 +283,8 @@ void plan_split(int kind, int n, int m, int d, int t, int flags, int* S, int* jc
   // runs in ceil(units / slots) rounds of resident workgroups: pick the S whose last round is nearly
   // full (efficiency = units / (rounds * slots)), keeping every chunk >= 16 LDS tiles (per-unit prologue
   // and partial-slab write < 1 %) and preferring the smallest S among near-ties (less slab traffic).
-  const int cap = group_cap(kind, flags);
-  KvVariant v = pick_variant(t > cap + 1 ? cap : t, gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3, n < KGH_SMALL_N, kernel_dims(d));
+  const int cap = group_cap(kind, flags, d);
+  KvVariant v = pick_variant(group_cols(t, 0, cap), gram_ok(kind, flags), flags, kind == GPAMD_RBF && d <= 3, n < KGH_SMALL_N, kernel_dims(d));
   const int mode = kv_mode(kind, flags, d, v);
   variant_geometry(mode, &v);
   const int nrb = (n + v.bm - 1) / v.bm;
@@ -335,7 +359,7 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
   if (S_host) *S_host = S;
   if (jchunk_host) *jchunk_host = jc;
   if (workspace_floats_host) {
-    const SplitLayout L = split_layout(kind, flags, m, t, S, ldo);
+    const SplitLayout L = split_layout(kind, flags, m, d, t, S, ldo);
     *workspace_floats_host = L.total ? L.base + L.total : (int64_t)S * t * ldo;
   }
   return 0;
@@ -354,8 +378,8 @@ int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const
   if (!aligned16(Vt) || !aligned16(X1p) || !aligned16(X2p) || !aligned16(X1c)) return fail(GPAMD_EINVAL, "kv: buffers must be 16-byte aligned");
   if (jchunk % 4 || (int64_t)jchunk * S < m) return fail(GPAMD_EINVAL, "kv: jchunk*S must cover m and jchunk % 4 == 0");
   hipStream_t st = (hipStream_t)stream;
-  const int cap = group_cap(kind, flags);
-  const SplitLayout L = split_layout(kind, flags, m, t, S, ldo);
+  const int cap = group_cap(kind, flags, d);
+  const SplitLayout L = split_layout(kind, flags, m, d, t, S, ldo);
   float* xbase = P + L.base;
   if (L.total) {
     if (!aligned16(P) || ldo % 4) return fail(GPAMD_EINVAL, "kv: the split-operand path needs a 16-byte aligned workspace and ldo % 4 == 0");
@@ -430,7 +454,7 @@ int gpamd_kv_f32(int kind, float kparam, const float* X1p, int n, const float* X
   if (kind < 0 || kind > GPAMD_RQ || n <= 0 || m <= 0 || t <= 0 || d < 1 || d > KV_MAX_DIM) return fail(GPAMD_EINVAL, "kv: bad shape");
   plan_split(kind, n, m, d, t, flags, &S, &jc);
   const int64_t ldp = (n + 3) / 4 * 4;
-  const SplitLayout L = split_layout(kind, flags, m, t, S, ldp);
+  const SplitLayout L = split_layout(kind, flags, m, d, t, S, ldp);
   if (workspace_floats < (L.total ? L.base + L.total : (int64_t)S * t * ldp))
     return fail(GPAMD_EWORKSPACE, "kv: workspace too small (use gpamd_kv_plan with ldo = round_up(n,4) and the same flags)");
   int rc = gpamd_kv_partials_f32(kind, kparam, X1p, n, X2p, m, d, X1c, Vt, ldv, t, workspace, ldp, S, jc, flags, nullptr, stream);

@@ -4,7 +4,7 @@
 
 namespace gpamd {
 
-enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3, KV_MODE_GRAM4 = 4, KV_MODE_GRAMH = 5 };
+enum { KV_MODE_MFMA = 0, KV_MODE_GRAM = 1, KV_MODE_VALU = 2, KV_MODE_GRAMV = 3, KV_MODE_GRAM4 = 4, KV_MODE_GRAMH = 5, KV_MODE_DIRECTH = 6 };
 
 // MFMA / Gram variants: CT 32-column tiles (1..4) + EX extra VALU column; NI row tiles per wave by CT.
 // NI*CT*16 accumulator registers: 64 (CT <= 2) .. 128 (CT = 4)
@@ -34,6 +34,13 @@ const void* kvm_kernel_ptr_rbf(int d, int groups);
 const void* kvm_kernel_ptr_matern32(int d, int groups);
 const void* kvm_kernel_ptr_matern52(int d, int groups);
 const void* kvm_kernel_ptr_rq(int d, int groups);
+
+// direct differences + split contraction (kvd_<family>.hip, kv_directh.hpp): d in {1,2,3,4,5,6,8,10}, ni = 1, 2 row tiles per wave
+const void* kvd_kernel_ptr_rbf(int d, int ni);
+const void* kvd_kernel_ptr_matern12(int d, int ni);
+const void* kvd_kernel_ptr_matern32(int d, int ni);
+const void* kvd_kernel_ptr_matern52(int d, int ni);
+const void* kvd_kernel_ptr_rq(int d, int ni);
 
 // split-operand kernels: generation and contraction on the f16 matrix pipe (kvh_<family>.hip); ct = 1, 2
 const void* kvh_kernel_ptr_rbf(int d, int ct, int ex, int ni);

@@ -154,9 +154,9 @@ def test_kv_gram_policy(dev):
     wide = _prep("rbf", X, 0.5, dev, sh)
     narrow = _prep("rbf", X, 0.02, dev, sh)
     assert B.kv_flags(wide, wide, 65) & B.KV_GRAM
-    assert B.kv_flags(narrow, narrow, 65) == 0
+    assert B.kv_flags(narrow, narrow, 65) & B.KV_GRAM == 0   # (the contraction may still take the f16 matrix pipe: KV_SPLIT alone = direct differences + split contraction)
     assert B.kv_flags(wide, wide, 4) & B.KV_GRAM
-    assert B.kv_flags(_prep("matern12", X, 0.5, dev, sh), _prep("matern12", X, 0.5, dev, sh), 65) == 0
+    assert B.kv_flags(_prep("matern12", X, 0.5, dev, sh), _prep("matern12", X, 0.5, dev, sh), 65) & B.KV_GRAM == 0   # (the contraction may still take the f16 matrix pipe: KV_SPLIT alone = direct differences + split contraction)
     # and the short-lengthscale problem is still accurate (direct path)
     V = torch.randn(500, 33, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
     out = B.from_probe_major(B.kv(narrow, narrow, B.to_probe_major(V.to(dev))), 500)

@@ -161,3 +161,66 @@ def test_split_product_large_row_tiles(split, kind, d, t, dev):
     ref = (_oracle_K(kind, X.float().double()[rows], X.float().double(), ls, 1.7) @ V.float().double().T).T
     err = ((out - ref).abs().amax(1) / ref.abs().amax(1)).max()
     assert float(err) < 2e-5, (kind, float(err))
+
+
+# ---- round 5: direct differences + split contraction (csrc/kv_directh.hpp; flags = GPAMD_KV_SPLIT without GPAMD_KV_GRAM) -----------------------
+def _oracle_any(kind, X1, X2, ls, alpha=1.7):
+    if kind == "matern12":
+        return torch.exp(-OK.sq_dist_direct(X1 / ls, X2 / ls).sqrt())
+    return _oracle_K(kind, X1, X2, ls, alpha)
+
+
+def _check_direct(B, kind, X1, X2, V, ls, dev, tol=2e-5):
+    shift = torch.cat([X1, X2]).mean(0)
+    p1, p2 = _prep(B, kind, X1, ls, dev, shift), _prep(B, kind, X2, ls, dev, shift)
+    t, m = V.shape
+    vt = torch.zeros(t, B.round_up(m, 4), device=dev)
+    vt[:, :m] = V.float().to(dev)
+    out = B.kv(p1, p2, vt)[:, : X1.shape[0]].double().cpu()
+    ref = (_oracle_any(kind, X1.float().double(), X2.float().double(), ls) @ V.float().double().T).T
+    for c in range(t):
+        scale = ref[c].abs().max().clamp_min(1e-300)
+        assert (out[c] - ref[c]).abs().max() <= tol * scale, (kind, c, float((out[c] - ref[c]).abs().max() / scale))
+    return out
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32", "matern52", "rq"])
+@pytest.mark.parametrize("n,m,d,t", [(300, 300, 3, 11), (257, 513, 1, 5), (130, 1000, 10, 32), (1000, 129, 6, 33), (65, 3000, 8, 64), (700, 700, 2, 65),
+                                       (129, 400, 4, 17), (17_000, 600, 3, 11), (16_500, 300, 9, 8), (400, 400, 5, 40)])
+def test_direct_split_product_vs_oracle(split, kind, n, m, d, t, dev, monkeypatch):
+    """Forced onto the direct-difference generation (as for a cloud outside the policy of the quadratic expansion) with the split contraction:
+    groups of <= 32 columns on kv_directh_kernel (two row tiles per wave from 16 384 output rows on, one below), trailing groups of < 5 columns on
+    the VALU kernel, every family incl. Matern nu = 1/2 (which has no Gram form), d up to 10."""
+    monkeypatch.setattr(split, "FORCE_KV_FLAGS", split.KV_SPLIT)
+    g = torch.Generator().manual_seed(n + 7 * m + t)
+    X1 = torch.rand(n, d, generator=g, dtype=torch.float64)
+    X2 = X1 if n == m else torch.rand(m, d, generator=g, dtype=torch.float64)
+    V = torch.randn(t, m, generator=g, dtype=torch.float64)
+    _check_direct(split, kind, X1, X2, V, 0.25 + 0.12 * d, dev)
+
+
+def test_direct_split_is_what_a_short_lengthscale_selects(split, dev):
+    """A cloud outside every Gram-form policy (a few hundred points spread over hundreds of lengthscales) and Matern nu = 1/2: ``kv_flags`` keeps the
+    contraction on the f16 matrix pipe (KV_SPLIT alone), the result matches the float64 oracle and the fp32 direct kernels."""
+    import warnings
+
+    B = split
+    g = torch.Generator().manual_seed(3)
+    X = torch.rand(900, 3, generator=g, dtype=torch.float64)
+    V = torch.randn(11, 900, generator=g, dtype=torch.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p = _prep(B, "rbf", X, 0.003, dev, X.mean(0))
+        assert B.kv_flags(p, p, 11) == B.KV_SPLIT and B.kv_flags(p, p, 3) == B.KV_SPLIT
+        p12 = _prep(B, "matern12", X, 0.4, dev, X.mean(0))
+        assert B.kv_flags(p12, p12, 11) == B.KV_SPLIT
+        a = _check_direct(B, "rbf", X, X, V, 0.003, dev)
+        b = _check_direct(B, "matern12", X, X, V, 0.4, dev)
+        B.SPLIT_CONTRACTION = False
+        try:
+            assert B.kv_flags(p, p, 11) == 0
+            a0 = _check_direct(B, "rbf", X, X, V, 0.003, dev)
+            b0 = _check_direct(B, "matern12", X, X, V, 0.4, dev)
+        finally:
+            B.SPLIT_CONTRACTION = True
+    assert float((a - a0).abs().max() / a0.abs().max()) < 2e-5 and float((b - b0).abs().max() / b0.abs().max()) < 2e-5
