@@ -104,7 +104,9 @@ def test_c3_mll_ingredients_fused_float32_vs_float64_bbmm(dev):
     assert abs(a["inv_quad"] - b["inv_quad"]) < 1e-3 * abs(b["inv_quad"]), log
     # (at a LOOSE tolerance the two runs are different iterates of the same sequence -- 0.2: 113 against 98 iterations, inv_quad 2.7e-3 apart,
     # profiles/r05_s4_c3_at_size_vs_float64_tol0.2.json -- so the comparison is made where both have converged to the level it asserts)
-    assert ysol_err < 2e-3, log
+    # the y column: both runs stop at a mean relative residual of 5 %, 12 % of their iterations apart -- the two iterates differ by 0.95e-3 .. 1.8e-3 (rel. L2, three
+    # runs: profiles/r05_s3_*, r05_s7_*, r05_s8_c3_at_size_*); bounded at 5e-3, the quadratic form y^T K^-1 y above (4e-5) is the converged quantity
+    assert ysol_err < 5e-3, log
     assert abs(a["logdet_precond_part"] - b["logdet_precond_part"]) < 1e-6 * abs(b["logdet_precond_part"]), log
     # the quadrature of the fixed probes: relative to the log-determinant it contributes to (its own scale: n times a per-datum O(1) quantity)
     assert abs(a["logdet_slq_part"] - b["logdet_slq_part"]) < 1e-3 * abs(b["logdet"]), log
