@@ -175,13 +175,15 @@ void kv_gram_kernel(KvArgs a) {
       // so that no MFMA can sink below them -- 8 more idle cycles per 32-row block against the ~2500 of its contraction (the static audit's bar for
       // this kernel is now 20, tests/test_isa_hazard_cpu.py; the on-device stress test compares bitwise with the fully fenced build)
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SAFE) {
+      // (SAFE: 0 = the product; 1 = the full fence; 2 = round 4's form, no explicit wait states; 3 = the product's wait states without the second scheduling
+      // barrier -- 1 .. 3 exist in the tune library only: the stress test's reference and the A/B of what the 8 wait states cost, scripts/kv_gram_fence_ab.py)
+      if constexpr (SAFE == 1) {
         mfma_result_fence(kk);
-      } else {
+      } else if constexpr (SAFE == 0 || SAFE == 3) {
         mfma_tie(kk);
         asm volatile("s_nop 7");   // (+ the toolchain's own 12 behind it: the hazard recogniser does not count wait states inside inline asm)
         mfma_tie(kk);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SAFE == 0) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {

@@ -11,5 +11,6 @@ pmc f64_t65 mfma "python $R/scripts/kv_f64_only.py 100000 3 65 3" SQ_VALU_MFMA_B
 pmc f64_t65 insts "python $R/scripts/kv_f64_only.py 100000 3 65 3" SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY
 pmc f64_t1 mfma "python $R/scripts/kv_f64_only.py 100000 3 1 3" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES
 pmc f64_t1 insts "python $R/scripts/kv_f64_only.py 100000 3 1 3" SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY
+timeout 120 python scripts/kv_gram_fence_ab.py $OUT/kv_gram_fence_ab.json > $OUT/kv_gram_fence_ab.log 2>&1; echo "[fence A/B] rc=$?"; cat $OUT/kv_gram_fence_ab.log | cut -c1-600
 find $OUT -name "*kernel_trace*" -size +5M -delete
 python scripts/pmc_collect_r5.py $OUT $OUT/kv_pmc
