@@ -76,7 +76,7 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
 /* P[s] = k(X1p, X2p[chunk s]) * Vt[:, chunk s]  for s < S -- the matrix-free K @ V of
  * KernelLinearOperator._matmul (gpytorch/kernels/keops/rbf_kernel.py:44-55) and
  * LazyEvaluatedKernelTensor._matmul (gpytorch/lazy/lazy_evaluated_kernel_tensor.py:245-275).
- * d: input dimension (1..16; the prepared clouds have stride dp = 4*ceil(d/4)).
+ * d: input dimension (1..32; the prepared clouds have stride dp = 4*ceil(d/4), 25..32 dimensions stride 32).
  * P: float[S][t][ldo].  done: optional device int; non-zero turns the launch into a no-op.
  * X1c (with GPAMD_KV_GRAM; NULL otherwise): float[ceil(n / 128)][dp], the centre of every 128-row chunk of X1p.  The Gram expansion is
  *   then taken relative to the centre of the workgroup's row block (squared distances are translation invariant), so its cancellation
@@ -294,7 +294,8 @@ int gpamd_kernel_rows_f64(int kind, double kparam, const double* X1p, const int6
                           int dp, const double* scale, double* out, int64_t ldo, void* stream);
 int gpamd_kernel_diag_f64(int kind, double kparam, const double* X1p, const double* X2p, int n, int dp, const double* scale, double* out,
                           void* stream);
-/* Fused float64 K*V (kv_f64.hpp: float64 generation on the VALU, contraction on v_mfma_f64_16x16x4_f64; d <= 8, else
+/* Fused float64 K*V (kv_f64.hpp: float64 generation on the VALU, contraction on v_mfma_f64_16x16x4_f64 -- column groups of <= 4 columns on the
+ * VALU: on gfx950 a float64 MFMA runs at the VALU's float64 rate and a 16-column tile would be mostly empty; d <= 16, else
  * GPAMD_EUNSUPPORTED and the caller uses the row-block path).  Same partial-slab convention as gpamd_kv_partials_f32:
  * P [S][t][ldo], to be summed / scaled by gpamd_kv_reduce_f64 or gpamd_cg64_reduce_q.  Replaces
  * KernelLinearOperator._matmul / LazyEvaluatedKernelTensor._matmul (lazy_evaluated_kernel_tensor.py:245-275) for
