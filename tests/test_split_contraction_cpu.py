@@ -367,3 +367,34 @@ def test_hilbert_order_cache_is_keyed_by_source_and_guarded_by_a_fingerprint():
     finally:
         B.hilbert_order = orig
         B._ORDER_CACHE.pop(key, None)
+
+
+def test_gram_mode_policy_round5():
+    """backend.gram_mode on CPU tensors: the extent limit of the block-centred expansion (saturating split norms: 2.5e7 for the exponentially decaying
+    families, the f16 range 6e4 for the heavy-tailed RQ), the wide-row share it tolerates (80 %), and the cloud-centred rule it falls under first."""
+    import warnings
+
+    from gpytorch_amd import backend as B
+
+    g = torch.Generator().manual_seed(2)
+    n = 20_000
+    base = torch.rand(n, 3, generator=g)
+
+    def pp(scale, kind):
+        xp = torch.zeros(n, 4)
+        xp[:, :3] = (base - base.mean(0)) * scale
+        return B.PreparedPoints(xp, n, 3, 4, kind, 1.5 if kind == "rq" else None)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        B._warned_fallback.clear()
+        assert B.gram_mode(pp(5.0, "rbf"), pp(5.0, "rbf")) == 1                     # max |z|^2 = 18.75: cloud-centred
+        p = pp(150.0, "matern52")                                                    # (max |z1| + max |z2|)^2 ~ 67 500: beyond the old f16-range limit
+        assert 60_000 < (2 * p.zmax2 ** 0.5) ** 2 < B.GRAM_MAX_EXTENT_SQ
+        sv = p.sorted_view()
+        assert B.gram_mode(p, p) == (2 if n - sv.n_block <= B.GRAM_MAX_WIDE_FRACTION * n else 0)
+        assert B.gram_mode(pp(25.0, "matern52"), pp(25.0, "matern52")) == 2         # dense enough at this scale: block-centred
+        q = pp(150.0, "rq")
+        assert B.gram_mode(q, q) == 0                                                # RQ keeps the unsaturated range
+        far = pp(4000.0, "rbf")                                                      # beyond even the saturating limit
+        assert (2 * far.zmax2 ** 0.5) ** 2 > B.GRAM_MAX_EXTENT_SQ and B.gram_mode(far, far) == 0
