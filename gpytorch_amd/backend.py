@@ -162,7 +162,7 @@ class SortedView:
     COMPACT when every 128 / 256 / 512-row block inside it stays within ``GRAM_MAX_BLOCK_SQRADIUS`` of its own centre -- the radius
     the cloud-centred rule accepts for every point, i.e. <= 2e-5 relative error in K.  The sparse tails of a cloud (outlying points many
     lengthscales from everything: Gaussian inputs, short lengthscales) form WIDE groups whatever the order; they are moved behind the
-    compact ones and their rows are produced by the direct-difference kernel in a second launch into the same slabs (2-3x slower per row,
+    compact ones and their rows are produced by the direct-difference kernels in a further launch into the same slabs (1.1-1.6x slower per row,
     a few percent of the rows), so the accuracy bound holds for every entry.
 
     ``perm``: sorted row k is original row perm[k];  ``inv_pad``: [round_up(n, 4)] gather index that takes a probe-major row in sorted
@@ -297,8 +297,8 @@ def gram_mode(x1: PreparedPoints, x2: PreparedPoints) -> int:
         import warnings
 
         _warned_fallback.add(key)
-        warnings.warn("gpytorch_amd: kernel products fall back to the direct-difference kernels (2-3x slower than the Gram-form / "
-                      f"split-contraction kernels): {reason}", RuntimeWarning)
+        warnings.warn("gpytorch_amd: kernel products fall back to the direct-difference kernels (squared distances on the vector pipe: slower than "
+                      f"the Gram-form kernels, 1.1-1.6x per row with the split contraction, 2-3x without): {reason}", RuntimeWarning)
     return 0
 
 
