@@ -3,7 +3,7 @@
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes) for the dominant 65-column kernel on BOTH contraction paths and the small-t kernels.
 # Usage: gpurun -- 'bash scripts/gpu_profile.sh <tag> [round]'   ->  gpurun_out/<tag>/..., summaries in profiles/r<round>_<tag>_*
 set +e
-TAG=${1:-prof}; ROUND=${2:-04}
+TAG=${1:-prof}; ROUND=${2:-05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
