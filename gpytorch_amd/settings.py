@@ -150,9 +150,12 @@ class lanczos_block_size(_value_context):
     one-column products, exp-bound on MI355X: 19 ms each at n = 500 000); b > 1 = block Lanczos (``lanczos.block_lanczos_steps``):
     ``max_root_decomposition_size // b`` products of b columns on the matrix-pipe kernels for a cache of the same rank -- the variance error
     of a LOVE cache follows its rank, not the way its Krylov space was generated (``tests/test_block_lanczos_cpu.py``).
-    "auto" (default): 8 from ``auto_min_size`` rows on (a product then fills the chip) when the rank is at least 32, else 1."""
+    "auto" (default): 8 from ``auto_min_size`` rows on (a product then fills the chip) when the rank is at least ``auto_min_rank`` (200: below it a
+    block cache is measurably less accurate than the single-vector cache of the same rank -- 0.75 against 0.57 of the noise at rank 100 -- so the
+    reference-default rank 100 keeps the reference's recurrence; ``lanczos.block_size_for``), else 1."""
     _global_value = "auto"
     auto_min_size = 16384
+    auto_min_rank = 200
 
 
 class num_trace_samples(_value_context):
