@@ -398,3 +398,69 @@ def test_gram_mode_policy_round5():
         assert B.gram_mode(q, q) == 0                                                # RQ keeps the unsaturated range
         far = pp(4000.0, "rbf")                                                      # beyond even the saturating limit
         assert (2 * far.zmax2 ** 0.5) ** 2 > B.GRAM_MAX_EXTENT_SQ and B.gram_mode(far, far) == 0
+
+
+def test_direct_split_kernel_layout_emulation():
+    """csrc/kv_directh.hpp on the CPU, lane by lane: the layout logic of the kernel restated with numpy index arithmetic and checked against the plain
+    product.  One 32 x 32 block of pairs of one wave:
+      * lane (h, i = l31) owns the 16 pairs (j(r, h), i), j(r, h) = (r & 3) + 8 (r >> 2) + 4 h; half mf = r >> 3 of them are the eight B-operand slots
+        k = 8 h + e of contraction MFMA mf (a 32 x 32 x 16 f16 MFMA: D[m = c][n = i] += sum_k A[c][k] B[k][i]);
+      * the x_j rows are read from the TRANSPOSED LDS image Xf[k][j] one quad at a time: rows 16 mf + 8 q + 4 h .. + 3 = elements e = 4 q .. 4 q + 3;
+      * the V planes hold column c at position 16 g + 8 h + e  ->  j = 16 g + (e & 3) + 8 (e >> 2) + 4 h (kv_vsplit.hpp), so the A operand of lane (m = c, h)
+        for MFMA mf is the 8 consecutive halves at 16 mf + 8 h;
+      * K = hi + lo (hi: f16 toward zero of 2^12 K), V = vh + vl, product = Kh Vh + Kh Vl + Kl Vh in f32, times 2^-12 / scale_c;
+    result: the 32 x 32 block of K^T-contracted columns equals V K within the split's 2^-21."""
+    import numpy as np
+
+    rng = np.random.default_rng(0)
+    D = 3
+    zi = rng.normal(size=(32, D)).astype(np.float32) * 0.7            # the wave's 32 output rows (one row tile)
+    zj = rng.normal(size=(32, D)).astype(np.float32) * 0.7            # one 32-row j block
+    V = rng.normal(size=(32, 32)).astype(np.float32)                  # [c][j] 32 columns
+    # ---- pre-pass: per-column scale, planes in k-slot order
+    scale = np.array([2.0 ** (14 - (np.frexp(np.abs(V[c]).max())[1])) for c in range(32)], dtype=np.float32)
+    planes_h = np.zeros((32, 32), dtype=np.float16)
+    planes_l = np.zeros((32, 32), dtype=np.float16)
+    for c in range(32):
+        for g in range(2):
+            for hh in range(2):
+                for e in range(8):
+                    j = 16 * g + (e & 3) + 8 * (e >> 2) + 4 * hh
+                    v = np.float32(V[c, j] * scale[c])
+                    hi = np.float16(v)
+                    planes_h[c, 16 * g + 8 * hh + e] = hi
+                    planes_l[c, 16 * g + 8 * hh + e] = np.float16(v - np.float32(hi))
+    Xf = zj.T.copy()                                                   # transposed LDS image [k][j]
+    acc = np.zeros((32, 32), dtype=np.float64)                         # acc[c][i]: what the MFMA accumulators hold (all lanes together)
+    for h in range(2):
+        for i in range(32):                                            # lane (h, l31 = i)
+            for mf in range(2):
+                b_hi = np.zeros(8, dtype=np.float16)
+                b_lo = np.zeros(8, dtype=np.float16)
+                for q in range(2):
+                    row0 = 16 * mf + 8 * q + 4 * h
+                    quad = Xf[:, row0 : row0 + 4]                      # one ds_read_b128 per dimension
+                    for el in range(4):
+                        e = 4 * q + el
+                        s = np.float32(((zi[i] - quad[:, el]) ** 2).sum())
+                        k = np.float32(np.exp2(np.float32(12.0) - s))  # RBF, 2^KSHIFT K
+                        hi = np.float32(k).view(np.uint32)             # cvt_pkrtz: toward zero
+                        hv = np.float16(k)
+                        if np.float32(hv) > k:                         # round-to-nearest overshot: step down one f16 ulp
+                            hv = np.nextafter(hv, np.float16(0))
+                        b_hi[e] = hv
+                        b_lo[e] = np.float16(k - np.float32(hv))
+                        # the j this slot stands for must be the j of the V plane slot the MFMA pairs it with
+                        r = 8 * mf + e
+                        assert (r & 3) + 8 * (r >> 2) + 4 * h == row0 + el
+                # MFMA mf: D[c][i] += sum_{k = 8 h + e} A[c][k] B[k][i];  A of lane (c, h) = planes[c][16 mf + 8 h .. + 7]
+                for c in range(32):
+                    a_hi = planes_h[c, 16 * mf + 8 * h : 16 * mf + 8 * h + 8].astype(np.float32)
+                    a_lo = planes_l[c, 16 * mf + 8 * h : 16 * mf + 8 * h + 8].astype(np.float32)
+                    bh, bl = b_hi.astype(np.float32), b_lo.astype(np.float32)
+                    acc[c, i] += float((a_lo * bh).sum()) + float((a_hi * bl).sum()) + float((a_hi * bh).sum())
+    got = acc * (2.0 ** -12 / scale.astype(np.float64))[:, None]
+    S = ((zi[None, :, :].astype(np.float64) - zj[:, None, :].astype(np.float64)) ** 2).sum(-1)    # [j][i]
+    ref = V.astype(np.float64) @ np.exp2(-S)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-6, err
