@@ -32,10 +32,10 @@ def build_preconditioner(x: B.PreparedPoints, scale, sigma2: torch.Tensor, rank=
     with two rounds of Cholesky-QR (GEMM + k x k Cholesky in float64 + triangular solve), which
     keeps the n x k work on rocBLAS GEMMs.  Q1 Q1^T and |diag R| -- the only quantities used -- are
     identical up to rounding."""
-    rank = settings.max_preconditioner_size.value() if rank is None else rank
+    n = x.n
+    rank = settings.max_preconditioner_size.resolve(n) if rank is None else rank
     tol = settings.preconditioner_tolerance.value() if tol is None else tol
     min_size = settings.min_preconditioning_size.value() if min_size is None else min_size
-    n = x.n
     if rank == 0 or n < min_size:
         return None
     s2v = float(sigma2.detach().reshape(-1)[0])
@@ -152,10 +152,10 @@ def build_preconditioner_rows(row_fn, kdiag: torch.Tensor, noise: torch.Tensor, 
     """The pivoted-Cholesky preconditioner of a structured operator K + D (``pivoted_cholesky_rows`` + ``preconditioner_from_factor``).
     The reference preconditions every ``AddedDiagLinearOperator`` this way, whatever its first summand (``settings.py:6-31``
     ``max_preconditioner_size``, ``kernels/multitask_kernel.py:46-54``); ``None`` when disabled."""
-    rank = settings.max_preconditioner_size.value() if rank is None else rank
+    n = kdiag.numel()
+    rank = settings.max_preconditioner_size.resolve(n) if rank is None else rank
     tol = settings.preconditioner_tolerance.value() if tol is None else tol
     min_size = settings.min_preconditioning_size.value() if min_size is None else min_size
-    n = kdiag.numel()
     if rank == 0 or n < min_size or not bool((noise.detach() > 0).all()):
         return None
     lt = pivoted_cholesky_rows(row_fn, kdiag.detach(), rank, tol)

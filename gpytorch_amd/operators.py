@@ -66,7 +66,25 @@ def psd_safe_cholesky(A: torch.Tensor, jitter=None, max_tries=None, model_dtype=
 
 
 class LinearOperator:
-    """Minimal protocol base (2-D, no batch dimensions: the fused kernels are non-batched)."""
+    """Minimal protocol base (2-D, no batch dimensions: the fused kernels are non-batched).
+
+    Subclasses written against ``linear_operator``'s own protocol (``gpytorch_amd.dropin``: every tensor goes to ``super().__init__`` so that
+    ``representation()`` can list it; ``_getitem(row_index, col_index, *batch_indices)`` and ``_diagonal()`` instead of ``__getitem__`` /
+    ``diagonal``) work on this base as they do on the real one: ``__init__`` keeps its arguments, ``__getitem__`` / ``diagonal`` route to the
+    underscore methods where a subclass defines them."""
+
+    def __init__(self, *args, **kwargs):
+        self._args, self._kwargs = args, kwargs
+
+    def representation(self):
+        """The tensors this operator was built from (``LinearOperator.representation``: operators among the arguments contribute theirs)."""
+        out = []
+        for a in getattr(self, "_args", ()):
+            if torch.is_tensor(a):
+                out.append(a)
+            elif isinstance(a, LinearOperator):
+                out.extend(a.representation())
+        return tuple(out)
 
     def _size(self) -> torch.Size:
         raise NotImplementedError
@@ -124,6 +142,8 @@ class LinearOperator:
         return self._matmul(torch.eye(n, device=self.device, dtype=self.dtype))
 
     def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        if type(self)._diagonal is not LinearOperator._diagonal:    # a subclass on linear_operator's protocol
+            return self._diagonal()
         return self.to_dense().diagonal()
 
     def _diagonal(self):
@@ -160,6 +180,12 @@ class LinearOperator:
         return DenseLinearOperator(self.to_dense() * c.reshape(()))
 
     def __getitem__(self, index):
+        if hasattr(self, "_getitem"):    # a subclass on linear_operator's protocol: (row index, column index), both always present
+            index = _strip_ellipsis(index)
+            if not isinstance(index, tuple):
+                index = (index, slice(None))
+            if len(index) == 2:
+                return self._getitem(index[0], index[1])
         return DenseLinearOperator(self.to_dense()[_strip_ellipsis(index)])
 
     def detach(self):

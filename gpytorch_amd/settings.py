@@ -129,7 +129,27 @@ class max_lanczos_quadrature_iterations(_value_context):
 
 
 class max_preconditioner_size(_value_context):
+    """Rank of the pivoted-Cholesky preconditioner (``linear_operator.settings.max_preconditioner_size``, re-exported at
+    ``gpytorch/settings.py:6-31``; default 15 = the reference's).  ``"auto"`` (no counterpart in the reference) picks the rank from the
+    number of points: on MI355X the k pivot steps cost O(n k^2) memory traffic -- 42 ms at n = 500 000, k = 100 -- against O(n^2 t) per
+    mBCG iteration (91 ms there), and the iteration count falls steeply with the rank (metric shape, n = 500 000, RBF d = 3, ``cg_tolerance``
+    1: rank 0 / 15 / 50 / 100: 93 / 42 / 21 / 21 iterations, 8.7 / 3.9 / 2.0 / 2.0 s per MLL evaluation, y^T K^-1 y within 3e-2 / 1.9e-1 /
+    8e-2 / 1.3e-3 of the converged value; ``eval_cg_tolerance`` 1e-3: rank 100 / 128: 74 / 44 iterations --
+    ``profiles/r06_s1_mll_precond_timing_n500000.json``).  The rule keeps the build below roughly ten products of the solve it serves:
+    n >= 40 000 -> 128 (the widest factor ``gpamd_pivoted_cholesky_f32`` builds), n >= 6 000 -> 50, else the reference's 15; the
+    ``preconditioner_tolerance`` early stop applies as always, so a fast-decaying spectrum ends the factor earlier."""
     _global_value = 15
+    auto_ranks = ((40_000, 128), (6_000, 50), (0, 15))
+
+    @classmethod
+    def resolve(cls, n: int) -> int:
+        """The rank in force for a system of ``n`` points (the integer setting itself, or the ``"auto"`` rule above)."""
+        v = cls.value()
+        if v == "auto":
+            for floor, rank in cls.auto_ranks:
+                if n >= floor:
+                    return rank
+        return int(v)
 
 
 class min_preconditioning_size(_value_context):
