@@ -514,6 +514,43 @@ class SumLinearOperator(LinearOperator):
     def _transpose_nonbatch(self):
         return SumLinearOperator(*[o._transpose_nonbatch() for o in self.ops])
 
+    def evaluate_kernel(self):
+        """A member that is a deferred kernel call (the reference's ``LazyEvaluatedKernelTensor``, ``lazy/lazy_evaluated_kernel_tensor.py:342-372``)
+        is evaluated and the sum is re-formed with ``+``, so that a fused kernel operator takes its noise term into its own epilogue -- what
+        ``AddedDiagLinearOperator.evaluate_kernel`` does in linear_operator (evaluated operator + diagonal)."""
+        ev = [o.evaluate_kernel() for o in self.ops]
+        if all(a is b for a, b in zip(ev, self.ops)):
+            return self
+        out = ev[0]
+        for o in ev[1:]:
+            out = out + o
+        return out
+
+    def _evaluated(self):
+        """``self.evaluate_kernel()`` when that changes anything (a deferred kernel call among the members), else None."""
+        ev = self.evaluate_kernel()
+        return None if ev is self else ev
+
+    # solves / decompositions of a sum with a deferred kernel member go to the EVALUATED sum (the fused operator with its noise), not to the
+    # dense defaults of the base class
+    def solve(self, rhs, lhs=None):
+        ev = self._evaluated()
+        return super().solve(rhs, lhs) if ev is None else ev.solve(rhs, lhs)
+
+    def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+        ev = self._evaluated()
+        return super().inv_quad_logdet(inv_quad_rhs, logdet, reduce_inv_quad) if ev is None else ev.inv_quad_logdet(inv_quad_rhs, logdet, reduce_inv_quad)
+
+    def root_decomposition(self, method=None):
+        ev = self._evaluated()
+        return super().root_decomposition(method) if ev is None else ev.root_decomposition(method)
+
+    def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
+        ev = self._evaluated()
+        if ev is None:
+            return super().root_inv_decomposition(initial_vectors, test_vectors, method)
+        return ev.root_inv_decomposition(initial_vectors, test_vectors, method)
+
     def to_dense(self):
         out = self.ops[0].to_dense()
         for o in self.ops[1:]:

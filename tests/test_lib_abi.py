@@ -135,6 +135,8 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+                # ... nor the test-only linear_operator shim / CPU double of tests/shim (tests/test_reference_layers_cpu.py)
+                assert not re.search(r"^\s*(from|import)\s+tests\b", src, flags=re.M) and "cpu_backend" not in src, f"{f} imports test infrastructure"
 
 
 def test_integration_stub_matches_the_abi():
