@@ -23,10 +23,14 @@ configs[1] itself.  Inputs are resident in HBM before the timed region.
 is inside the timed step, as in a real MLL evaluation); `--config c5` = BASELINE configs[4] (multitask, 4 tasks, RBF (x) index kernel,
 n = 200 000, d = 6: mBCG over the Kronecker MVM -- ONE fused launch with 4 x columns -- 64 probes IN TOTAL split over the ranks).
 
-N > 1: one process per GPU.  Default (`--config metric`): each rank owns 64 probes of a 64*N global probe set (WEAK scaling;
-the y column is solved on rank 0 only).  `--config c4` = BASELINE configs[3]: n = 1 000 000, 256 probes in total split over
-the N ranks (32 + y on rank 0 at N = 8; STRONG scaling over the probe set).  The only data-path collectives are the 2-float
-stopping-rule all-reduce per CG iteration (stream-ordered RCCL), one scalar SLQ all-reduce and one broadcast of the y solve.
+N > 1: one process per GPU.  Default (`--scaling strong`): the workload BASELINE names -- ONE MLL evaluation, 64 probes in total + y -- split over
+the N GPUs on the P x R grid (probe shares x row blocks) `gpytorch_amd.distributed.choose_grid` picks from the measured column ladder of the
+fused K*V and the cost of one all-gather of the search directions per iteration: 1 x N for `metric` (every rank keeps all 65 columns on 1/N of
+the rows; probe sharding alone would leave 8 + 1 columns per GPU, where kernel generation no longer hides under the contraction: 2x, not 8x).
+`--scaling weak` = rounds 1-5's default (64 probes PER GPU, probes only).  `--config c4` = BASELINE configs[3]: n = 1 000 000, 256 probes in
+total (2 x 4 on 8 GPUs).  `--grid PxR` overrides the layout.  Data-path collectives: the 2-float stopping-rule all-reduce per CG iteration over the
+probe group (stream-ordered RCCL), one scalar SLQ all-reduce, one broadcast of the y solve; with row blocks one all-gather of the search
+directions (4 n cols bytes) + two small all-reduces of the inner products per iteration over the row group.
 """
 from __future__ import annotations
 
@@ -339,12 +343,36 @@ def self_launch(n_ranks: int) -> int:
 
 def make_grid_groups(world: int, rank: int, P: int, R: int):
     """--grid PxR: P probe shares x R row blocks, rank = p * R + r.  Returns (probe group of this rank = the P ranks with its r -- stopping rule,
-    SLQ sums --, row group = the R ranks with its p -- all-gather of the search directions, inner products).  ``new_group`` is collective:
-    every rank creates every group, in the same order."""
+    SLQ sums --, row group = the R ranks with its p -- all-gather of the search directions, inner products); ``None`` for a dimension of
+    extent 1 (``gpytorch_amd.distributed.grid_groups``: collective, every rank creates every group in the same order)."""
+    from gpytorch_amd.distributed import grid_groups
+
     assert P * R == world, f"--grid {P}x{R} needs {P * R} ranks, have {world}"
-    pgs = [torch.distributed.new_group([p * R + r for p in range(P)]) for r in range(R)]
-    rgs = [torch.distributed.new_group([p * R + r for r in range(R)]) for p in range(P)]
-    return pgs[rank % R], rgs[rank // R]
+    return grid_groups(P, R)
+
+
+# nominal (n, probes in total) of every configuration: the layout of a multi-GPU run is chosen for THESE, so that a --size smoke run exercises
+# the layout of the real one
+NOMINAL = {"metric": (500_000, 64), "c2": (100_000, 64), "c3": (500_000, 64), "c4": (1_000_000, 256), "c5": (200_000, 64)}
+
+
+def scaling_of(args) -> str:
+    return "strong" if (args.config in ("c4", "c5") or args.scaling == "strong") else "weak"
+
+
+def pick_grid(args, world: int):
+    """(P probe shares, R row blocks) of this run: --grid, else probes only for c5 (structured operator: rows cannot be sharded) and for weak
+    scaling, else the cost model's choice for the configuration's nominal size and the timed contraction."""
+    if args.grid:
+        P, R = (int(v) for v in args.grid.lower().split("x"))
+        assert P * R == world, f"--grid {args.grid} needs {P * R} ranks, have {world}"
+        return P, R
+    if world == 1 or args.config == "c5" or scaling_of(args) == "weak":
+        return world, 1
+    from gpytorch_amd.distributed import choose_grid
+
+    n_nom, t_nom = NOMINAL[args.config]
+    return choose_grid(world, n_nom, args.probes if args.probes is not None else t_nom, args.contraction)
 
 
 def main():
@@ -353,7 +381,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=["metric", "c2", "c3", "c4", "c5", "road3d", "protein"], default="metric",
-                    help="metric: n=500k, 64 probes/GPU + y (weak scaling; the configuration BASELINE.json's metric is quoted on); "
+                    help="metric: n=500k, 64 probes + y (the configuration BASELINE.json's metric is quoted on; N > 1: see --scaling); "
                          "c2: configs[1] (n=100k); c3: configs[2] (Matern-5/2, n=500k, d=10, rank-100 preconditioner); "
                          "c4: configs[3], n=1e6 with 256 probes IN TOTAL split over the ranks (strong scaling); "
                          "c5: configs[4], 4-task Kronecker multitask GP, n=200k, d=6, 64 probes IN TOTAL split over the ranks")
@@ -369,8 +397,13 @@ def main():
     ap.add_argument("--skip-parity", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="skip the untimed API-level MLL fwd+bwd / posterior timings")
-    ap.add_argument("--grid", default=None, help="PxR (c4 / metric with N = P * R ranks): two-dimensional split -- P probe groups x R row blocks "
-                                                 "(bbmm.inv_quad_logdet_forward(group, row_group)); default: probes only (P = N, R = 1)")
+    ap.add_argument("--grid", default=None, help="PxR (N = P * R ranks): two-dimensional split -- P probe shares x R row blocks "
+                                                 "(bbmm.inv_quad_logdet_forward(group, row_group)).  Default for metric / c2 / c3 / c4: chosen by the cost model of "
+                                                 "gpytorch_amd.distributed.choose_grid at the configuration's nominal size (metric on 8 GPUs: 1x8); c5 and "
+                                                 "--scaling weak: probes only (P = N, R = 1)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1, metric / c2 / c3: strong (default) = the workload BASELINE names -- ONE MLL evaluation with 64 probes in total -- split "
+                         "over the N GPUs; weak = 64 probes PER GPU (the default of rounds 1-5).  c4 / c5 are strong by definition")
     args = ap.parse_args()
 
     if args.config in ("road3d", "protein"):
@@ -402,12 +435,14 @@ def main():
             torch.distributed.all_reduce(tt)
             tot = float(tt.item())
             grid = None
-            if args.grid:   # the subgroups of the 2-D split, exercised over gloo: sums of (rank + 1) over this rank's probe group and row group
-                P_, R_ = (int(v) for v in args.grid.lower().split("x"))
+            P_, R_ = pick_grid(args, world)
+            if R_ > 1:   # the subgroups of the split, exercised over gloo: sums of (rank + 1) over this rank's probe group and row group
                 pg, rg = make_grid_groups(world, rank, P_, R_)
                 a, b = torch.tensor([float(rank + 1)]), torch.tensor([float(rank + 1)])
-                torch.distributed.all_reduce(a, group=pg)
-                torch.distributed.all_reduce(b, group=rg)
+                if pg is not None:
+                    torch.distributed.all_reduce(a, group=pg)
+                if rg is not None:
+                    torch.distributed.all_reduce(b, group=rg)
                 allv = [None] * world
                 torch.distributed.all_gather_object(allv, (rank, float(a.item()), float(b.item())))
                 grid = sorted(allv)
@@ -415,7 +450,7 @@ def main():
         else:
             tot, grid = 1.0, None
         if rank == 0:
-            rec = {"launched": world, "rank_sum": tot, "n_gpus": args.gpus}
+            rec = {"launched": world, "rank_sum": tot, "n_gpus": args.gpus, "grid": list(pick_grid(args, world)), "scaling": scaling_of(args)}
             if grid is not None:
                 rec["grid_sums"] = grid
             print(json.dumps(rec), flush=True)
@@ -435,14 +470,10 @@ def main():
     # --grid PxR: P probe groups x R row blocks, rank = p * R + r.  The probe group of a rank = the P ranks with its r (stopping rule, SLQ sums),
     # its row group = the R ranks with its p (all-gather of the search directions, inner products).  new_group is collective: every rank
     # creates every group in the same order.
-    P_, R_ = world, 1
+    P_, R_ = pick_grid(args, world)
     row_group = None
-    if args.grid:
-        P_, R_ = (int(v) for v in args.grid.lower().split("x"))
-        assert P_ * R_ == world, f"--grid {args.grid} needs {P_ * R_} ranks, have {world}"
-        if R_ > 1:
-            pg, row_group = make_grid_groups(world, rank, P_, R_)
-            group = pg if P_ > 1 else None
+    if R_ > 1:
+        group, row_group = make_grid_groups(world, rank, P_, R_)
     p_idx = rank // R_          # index of this rank's probe share
 
     from gpytorch_amd import backend as B
@@ -452,7 +483,7 @@ def main():
 
     gsettings.split_contraction._set_state(args.contraction == "split")
 
-    strong = args.config in ("c4", "c5")
+    strong = scaling_of(args) == "strong"
     n = args.size if args.size is not None else {"metric": 500_000, "c2": 100_000, "c3": 500_000, "c4": 1_000_000, "c5": 200_000}[args.config]
     d = args.dims if args.dims is not None else {"c3": 10, "c5": 6}.get(args.config, 3)
     kind = "matern52" if args.config == "c3" else "rbf"
@@ -461,7 +492,7 @@ def main():
     if strong:
         from gpytorch_amd.distributed import probe_shard
 
-        t_total = args.probes if args.probes is not None else (256 if args.config == "c4" else 64)
+        t_total = args.probes if args.probes is not None else NOMINAL[args.config][1]
         a_, b_ = probe_shard(t_total, P_, p_idx)
         t = b_ - a_
     else:
@@ -508,7 +539,7 @@ def main():
         return mll, res.info.iterations
 
     def barrier():
-        if group is not None:
+        if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
@@ -528,7 +559,7 @@ def main():
         iters_all.append(it)          # (the stopping iteration varies with the probe draw: 93 .. 109 on the metric configuration)
     barrier()
     elapsed = time.perf_counter() - t0
-    if group is not None:
+    if world > 1:
         et = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(et, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(et.item())
@@ -680,7 +711,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if strong else "weak",
+            "scaling": "strong" if strong else "weak",   # (N = 1: the same workload either way)
             "vs_baseline": None,
             "dtype": "f32" if args.contraction == "f32" else "f32 emulated on f16 MFMA (hi/lo-split operands, 21-22 bits, f32 accumulate)",
             "data": "synthetic",
@@ -696,7 +727,9 @@ def main():
                 "cg_iterations_per_step": iters_total / args.steps,
                 "cg_iterations_all": iters_all,
                 "parallelism": (f"probe-sharded x{world}, y column on rank 0" if R_ == 1 else
-                                f"2-D split: {P_} probe shares x {R_} row blocks, y column on the first share"),
+                                f"{P_} probe share(s) x {R_} row blocks (layout {'from --grid' if args.grid else 'chosen by distributed.choose_grid'}), "
+                                "y column on the first share"),
+                "grid": [P_, R_],
             },
             "mll": float(mll),
             "roofline": roofline,
@@ -710,7 +743,7 @@ def main():
         if not args.skip_cpu_baseline and world == 1:  # timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(n, d, cols * T, ls, kind=kind)
         print(json.dumps(out))
-    if group is not None:
+    if world > 1:
         torch.distributed.barrier()   # rank 0 may still be in the (untimed) parity check
         torch.distributed.destroy_process_group()
 

@@ -682,7 +682,7 @@ int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream) {
 int gpamd_pivoted_cholesky_f32(int kind, float kparam, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
                                float* L, int64_t ldl, int64_t* pivots, float* fwork, int* iwork, void* stream) {
   if (n <= 0 || rank <= 0 || ldl < n) return fail(GPAMD_EINVAL, "pivoted_cholesky: bad shape");
-  if (rank > 128) return fail(GPAMD_EUNSUPPORTED, "pivoted_cholesky: rank > 128");
+  if (rank > PC_MAX_RANK) return fail(GPAMD_EUNSUPPORTED, "pivoted_cholesky: rank > 512");
   if (rank > n) rank = n;
   hipStream_t st = (hipStream_t)stream;
   PcState s;
@@ -696,6 +696,23 @@ int gpamd_pivoted_cholesky_f32(int kind, float kparam, const float* Xp, int n, i
   s.tol = tol;
   s.kparam = kparam;
   (void)hipMemsetAsync(iwork, 0, 2 * sizeof(int), st);
+  const int nb = (n + 255) / 256;
+  if (n >= 8) {
+    // one launch per pivot step: the update of step m and the arg-max for step m + 1 in one kernel (misc_kernels.hpp, "last block decides");
+    // the partials live in the former permutation region of iwork (4 nb + 1 <= n words for n >= 8)
+    PcPartials pp;
+    pp.nb = nb;
+    pp.ppos = s.perm;
+    pp.pidx = s.perm + nb;
+    pp.pval = reinterpret_cast<float*>(s.perm + 2 * nb);
+    pp.psum = reinterpret_cast<float*>(s.perm + 3 * nb);
+    pp.counter = reinterpret_cast<unsigned*>(s.perm + 4 * nb);
+    (void)hipMemsetAsync(pp.counter, 0, sizeof(unsigned), st);
+    KIND_SWITCH(kind, hipLaunchKernelGGL((pc_first_kernel<KK>), dim3(nb), dim3(256), 0, st, s, pp, Xp, dp, scale));
+    for (int m = 0; m < rank; ++m)
+      KIND_SWITCH(kind, hipLaunchKernelGGL((pc_step_kernel<KK>), dim3(nb), dim3(256), 0, st, s, pp, m, Xp, dp, scale));
+    return check_launch("pivoted_cholesky");
+  }
   hipLaunchKernelGGL(pc_init_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.perm, s.pos, n);
   // diagonal of the noise-free kernel matrix: scale * k(0)
   KIND_SWITCH(kind, hipLaunchKernelGGL((kernel_diag_kernel<KK>), dim3((n + 255) / 256), dim3(256), 0, st, Xp, Xp, n, dp,

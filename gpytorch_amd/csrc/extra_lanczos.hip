@@ -92,7 +92,7 @@ int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* 
       hipLaunchKernelGGL((pc_coef_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
     else
       hipLaunchKernelGGL((pc_coef_kernel<5>), dim3((unsigned)nb), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
-    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((tg * k + 255) / 256), dim3(256), 0, st, (const double*)part, (int)nb, tg * k, W + (int64_t)c0 * k);
+    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((4 * tg * k + 255) / 256), dim3(256), 0, st, (const double*)part, (int)nb, tg * k, W + (int64_t)c0 * k);
   }
   return lz_check("precond_coef");
 }
@@ -124,7 +124,7 @@ int block_project(const TQ* Q, int64_t ldq, int k, const TR* R, int64_t ldr, int
     const int tg = b - c0 < 16 ? b - c0 : 16;
     hipLaunchKernelGGL((pc_coef_kernel<1, TQ, TR>), dim3((unsigned)nb, (unsigned)((k + 16 * PC_MT - 1) / (16 * PC_MT))), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg,
                        Q, ldq, k, n, slice, workspace);
-    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((tg * k + 255) / 256), dim3(256), 0, st, (const double*)workspace, (int)nb, tg * k, W + (int64_t)c0 * k);
+    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((4 * tg * k + 255) / 256), dim3(256), 0, st, (const double*)workspace, (int)nb, tg * k, W + (int64_t)c0 * k);
   }
   return lz_check("block_project");
 }

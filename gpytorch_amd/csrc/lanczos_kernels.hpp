@@ -171,13 +171,22 @@ __global__ __launch_bounds__(256) void pc_coef_kernel(const TR* __restrict__ R, 
     }
 }
 
-// W[e] = sum_b part[b][e]     (e < t * k)
+// W[e] = sum_b part[b][e]     (e < t * k).  Four consecutive lanes share an element: lane q takes the partials b = q, q + 4, .. in order and the four
+// running sums are combined in a fixed order (bitwise reproducible); the loads of a wave still cover 16 consecutive elements per b (128 contiguous
+// bytes).  Round 6: with one thread walking all nb <= 256 partials of its element the kernel took 35 us whatever the size -- 1.3 ms of a
+// protein-shaped closure's 23 preconditioner applies (profiles/r05_s6_workload_protein_kernel_stats.csv); a quarter of the dependent loads now.
 __global__ void pc_coef_sum_kernel(const double* __restrict__ part, int nb, int tk, double* __restrict__ W) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= tk) return;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = gid >> 2, q = gid & 3;
   double s = 0.0;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * tk + e];
-  W[e] = s;
+  if (e < tk)
+    for (int b = q; b < nb; b += 4) s += part[(int64_t)b * tk + e];
+  // (all 64 lanes take part in the shuffles; lanes of elements past the end carry zeros)
+  double o = __shfl_xor(s, 1, 64);
+  s = (q & 1) ? o + s : s + o;        // both lanes of a pair form the same sum: lower lane's value first
+  o = __shfl_xor(s, 2, 64);
+  s = (q & 2) ? o + s : s + o;
+  if (e < tk && q == 0) W[e] = s;
 }
 
 // Second half of the preconditioner apply, fused:  Out[c][i] = (R[c][i] - sum_m W[c][m] Q1[m][i]) / sigma2  with the subtraction and

@@ -140,11 +140,13 @@ __global__ void pc_init_perm_kernel(int* perm, int* pos, int n) {
   if (i < n) { perm[i] = i; pos[i] = i; }
 }
 
+constexpr int PC_MAX_RANK = 512;   // LDS copy of L[q][p], q < m
+
 // L[m][i] = (K[p][i] - sum_{q<m} L[q][p] L[q][i]) / sqrt(d_p) for live i; L[m][p] = sqrt(d_p); d[i] -= L[m][i]^2
 template <int KIND>
 __global__ __launch_bounds__(256) void pc_update_kernel(PcState st, int m, const float* __restrict__ Xp, int DP,
                                                         const float* __restrict__ scale) {
-  __shared__ float lp[128];  // L[q][p], q < m  (rank <= 128 per launch design)
+  __shared__ float lp[PC_MAX_RANK];  // L[q][p], q < m
   if (st.ctl[1] || st.ctl[0] != m + 1) return;
   const int64_t p = st.pivots[m];
   for (int q = threadIdx.x; q < m; q += blockDim.x) lp[q] = st.L[(int64_t)q * st.ldl + p];
@@ -165,6 +167,155 @@ __global__ __launch_bounds__(256) void pc_update_kernel(PcState st, int m, const
     st.dwork[i] = d - v * v;
   }
   st.L[(int64_t)m * st.ldl + i] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ONE launch per pivot step (round 6; n >= 8).  The two-kernel form above spends most of a step in pc_pivot_kernel -- one workgroup scanning all n
+// diagonal entries (n = 500 000: ~0.3 ms of a 0.42 ms step; 200 launches of ~4 us kernels per factor at n = 36 584, DESIGN 8 viii).  Here the
+// update of step m and the arg-max that chooses pivot m + 1 share a kernel: every block updates its 256 entries, reduces (value, position,
+// index, l1 sum) over them, publishes the partial, and the LAST block to arrive (ticket from an atomic counter, __threadfence on both sides)
+// reduces the partials of all blocks IN BLOCK ORDER (deterministic) and writes the next decision.  The position bookkeeping needs no
+// permutation array any more: the swap "pi_m <-> pi_bi" of the reference only changes the positions of the two indices involved, and each is
+// updated by the thread that owns the index (pos[i] == m -> bi; i == p -> m) before that thread's own partial reads it.
+// Workspace (inside the iwork / fwork sizes of the ABI): the former perm[n] region holds ppos[nb] | pidx[nb] | pval[nb] | psum[nb] | counter.
+struct PcPartials {
+  int* ppos;
+  int* pidx;
+  float* pval;
+  float* psum;
+  unsigned* counter;
+  int nb;
+};
+
+// decision for step `mnext` from the per-block partials; called by every thread of the LAST block.  scal[3] carries the POSITION of the chosen pivot.
+__device__ __forceinline__ void pc_decide(const PcState& st, const PcPartials& pp, int mnext) {
+  __shared__ float sval[4];
+  __shared__ int spos[4], sidx[4];
+  __shared__ float ssum[4];
+  const int tid = threadIdx.x;
+  float best = -INFINITY, sum = 0.f;
+  int bpos = 0x7fffffff, bidx = -1;
+  // fixed assignment of partials to threads and a fixed combination order: bitwise reproducible from run to run
+  for (int b = tid; b < pp.nb; b += 256) {
+    const float v = pp.pval[b];
+    const int ps = pp.ppos[b];
+    sum += pp.psum[b];
+    if (v > best || (v == best && ps < bpos)) { best = v; bpos = ps; bidx = pp.pidx[b]; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int op = __shfl_xor(bpos, o, 64), oi = __shfl_xor(bidx, o, 64);
+    if (ov > best || (ov == best && op < bpos)) { best = ov; bpos = op; bidx = oi; }
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) { sval[tid >> 6] = best; spos[tid >> 6] = bpos; sidx[tid >> 6] = bidx; ssum[tid >> 6] = sum; }
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      tot += ssum[w];
+      if (sval[w] > best || (sval[w] == best && spos[w] < bpos)) { best = sval[w]; bpos = spos[w]; bidx = sidx[w]; }
+    }
+    if (mnext == 0) st.scal[0] = best;  // orig_error = max diag
+    const float err = tot / st.scal[0];
+    st.scal[1] = err;
+    // reference loop condition: m == 0 or (m < max_iter and max(errors) > tol)
+    if (mnext >= st.rank || (mnext > 0 && !(err > st.tol)) || bidx < 0) {
+      st.ctl[1] = 1;
+    } else {
+      st.pivots[mnext] = bidx;
+      st.scal[2] = best;
+      st.scal[3] = __int_as_float(bpos);
+      st.ctl[0] = mnext + 1;
+    }
+    *pp.counter = 0u;   // ready for the next launch
+  }
+}
+
+// block-level partial of (largest live diagonal entry, its position, its index, l1 sum of the live entries) + the "last block decides" tail
+__device__ __forceinline__ void pc_partial_and_decide(const PcState& st, const PcPartials& pp, float v, int ps, int idx, int mnext) {
+  __shared__ float bval[4];
+  __shared__ int bps[4], bix[4];
+  __shared__ float bsum[4];
+  __shared__ bool last;
+  const int tid = threadIdx.x;
+  float best = v > -INFINITY ? v : -INFINITY, sum = v > -INFINITY ? fabsf(v) : 0.f;
+  int bpos = v > -INFINITY ? ps : 0x7fffffff, bidx = v > -INFINITY ? idx : -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int op = __shfl_xor(bpos, o, 64), oi = __shfl_xor(bidx, o, 64);
+    if (ov > best || (ov == best && op < bpos)) { best = ov; bpos = op; bidx = oi; }
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) { bval[tid >> 6] = best; bps[tid >> 6] = bpos; bix[tid >> 6] = bidx; bsum[tid >> 6] = sum; }
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      tot += bsum[w];
+      if (bval[w] > best || (bval[w] == best && bps[w] < bpos)) { best = bval[w]; bpos = bps[w]; bidx = bix[w]; }
+    }
+    pp.pval[blockIdx.x] = best; pp.ppos[blockIdx.x] = bpos; pp.pidx[blockIdx.x] = bidx; pp.psum[blockIdx.x] = tot;
+    __threadfence();
+    last = (atomicAdd(pp.counter, 1u) == (unsigned)(pp.nb - 1));
+  }
+  __syncthreads();
+  if (last) {
+    __threadfence();
+    pc_decide(st, pp, mnext);
+  }
+}
+
+// first launch: diagonal of the noise-free kernel matrix (scale * k(0)), identity positions, decision for step 0
+template <int KIND>
+__global__ __launch_bounds__(256) void pc_first_kernel(PcState st, PcPartials pp, const float* __restrict__ Xp, int DP, const float* __restrict__ scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float v = -INFINITY;
+  if (i < st.n) {
+    v = (scale ? *scale : 1.f) * cov_pair<KIND>(Xp + (int64_t)i * DP, Xp + (int64_t)i * DP, DP, st.kparam);
+    st.dwork[i] = v;
+    st.pos[i] = i;
+  }
+  pc_partial_and_decide(st, pp, v, i, i, 0);
+}
+
+// step m: row m of L^T and the Schur-complement diagonal (as pc_update_kernel), then the decision for step m + 1
+template <int KIND>
+__global__ __launch_bounds__(256) void pc_step_kernel(PcState st, PcPartials pp, int m, const float* __restrict__ Xp, int DP, const float* __restrict__ scale) {
+  __shared__ float lp[PC_MAX_RANK];  // L[q][p], q < m
+  if (st.ctl[1] || st.ctl[0] != m + 1) return;     // (uniform over the grid: written by the previous launch)
+  const int64_t p = st.pivots[m];
+  const int bi = __float_as_int(st.scal[3]);       // position the pivot was found at
+  for (int q = threadIdx.x; q < m; q += 256) lp[q] = st.L[(int64_t)q * st.ldl + p];
+  __syncthreads();
+  const float piv = sqrtf(st.scal[2]);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float dnew = -INFINITY;
+  int ps = 0x7fffffff;
+  if (i < st.n) {
+    // the reference's swap pi_m <-> pi_bi, seen from the two indices it moves
+    ps = st.pos[i];
+    if (ps == m) ps = bi;
+    if (i == p) ps = m;
+    st.pos[i] = ps;
+    const float d = st.dwork[i];
+    float out = 0.f;
+    if (i == p) {
+      out = piv;
+      st.dwork[i] = -INFINITY;
+    } else if (d > -INFINITY) {
+      float v = (scale ? *scale : 1.f) * cov_pair<KIND>(Xp + p * DP, Xp + (int64_t)i * DP, DP, st.kparam);
+      for (int q = 0; q < m; ++q) v -= lp[q] * st.L[(int64_t)q * st.ldl + i];
+      v = v / piv;
+      out = v;
+      dnew = d - v * v;
+      st.dwork[i] = dnew;
+    }
+    st.L[(int64_t)m * st.ldl + i] = out;
+  }
+  pc_partial_and_decide(st, pp, dnew, ps, i, m + 1);
 }
 
 }  // namespace gpamd

@@ -165,6 +165,7 @@ void kv_gramh_ablate_kernel(KvhArgs ka) {
   // the extra column's two multiply-adds ride in gen_a as one v_pk_fma_f32.
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 eacc2[NI];
+  uint32_t sink = 0;   // ABL == 2 only (see the step loop)
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) eacc2[ni] = (f32x2)(0.f);
   auto gen_a = [&](const f32x16& kk, int mf, int p, const f32x4* ev, int ni, f32x2& kv, u32x4& bh) {
@@ -352,6 +353,14 @@ void kv_gramh_ablate_kernel(KvhArgs ka) {
           }
         }
         if (ABL != 1) { bh[0] = bhn[0]; bh[1] = bhn[1]; bl[0] = bln[0]; bl[1] = bln[1]; }
+        if constexpr (ABL == 2) {
+          // live sink of the "no contraction MFMAs" build: with the MFMAs gone nothing read the generated B operands and the whole generation
+          // was dead code (round 5 recorded 2.1 us per launch for this case: it measured nothing).  Eight v_xor3 per step (~ 8 % on top of the
+          // ~ 100 generation instructions) fold every packed hi / lo word into one register that reaches the output.
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf)
+            sink ^= (bhn[mf][0] ^ bhn[mf][1] ^ bhn[mf][2]) ^ (bhn[mf][3] ^ bln[mf][0] ^ bln[mf][1]) ^ (bln[mf][2] ^ bln[mf][3]);
+        }
         if constexpr (DEEP) kk_pend = kk_new;
       }
 #pragma unroll
@@ -377,7 +386,7 @@ void kv_gramh_ablate_kernel(KvhArgs ka) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (c < a.t) Pout[(int64_t)c * a.ldo + i] = acc[ni][ct][r] * ka.colmul[c];
+          if (c < a.t) Pout[(int64_t)c * a.ldo + i] = acc[ni][ct][r] * ka.colmul[c] + (ABL == 2 ? (float)(sink & 1u) : 0.f);
         }
     }
     if constexpr (EX) {

@@ -23,7 +23,7 @@ extern "C" int gpamd_tune_kv_gramh_rbf3(int abl, int ni, int ex, const float* X1
   const dim3 grid((unsigned)a.nrb * S), block(64 * nw);
 #define L(A, N) if (abl == A && ni == N && !ex) hipLaunchKernelGGL((kv_gramh_ablate_kernel<KIND_RBF, 3, 2, N, 0, A>), grid, block, 0, (hipStream_t)stream, ka);
 #define LX(A, N) if (abl == A && ni == N && ex) hipLaunchKernelGGL((kv_gramh_ablate_kernel<KIND_RBF, 3, 2, N, 1, A>), grid, block, 0, (hipStream_t)stream, ka);
-  L(0, 2) L(1, 2) L(3, 2) L(4, 2) L(6, 2) L(7, 2) L(8, 2) L(10, 2) L(0, 4) LX(0, 2) LX(0, 4)
+  L(0, 2) L(1, 2) L(2, 2) L(3, 2) L(4, 2) L(5, 2) L(6, 2) L(7, 2) L(8, 2) L(10, 2) L(0, 4) LX(0, 2) LX(0, 4)
 #define G(A, N, E, NWV, OCCV) if (abl == A && ni == N && ex == E) hipLaunchKernelGGL((kv_gramh_ablate_kernel<KIND_RBF, 3, 2, N, E, 0, NWV, OCCV>), grid, block, 0, (hipStream_t)stream, ka);
   G(110, 2, 0, 8, 2) G(110, 2, 1, 8, 2) G(120, 1, 0, 4, 3) G(120, 1, 1, 4, 3) G(130, 4, 0, 8, 2) G(130, 4, 1, 8, 2) G(110, 1, 0, 8, 2) G(110, 1, 1, 8, 2)
 #undef G

@@ -14,7 +14,7 @@
 using namespace gpamd_hz;
 
 // which: 0 = kv_gram_kernel (fp32 contraction; Vh / Vl / colmul unused), 1 = kv_gramh_kernel (split contraction)
-// variant: index into the lists below;  safe: 0 = the product's code path, 1 = fully fenced; kv_gram only: 2 = round 4's form (no explicit wait states), 3 = the
+// variant: index into the lists below;  safe: 0 = the product's code path, 1 = fully fenced, 2 = the toolchain's table only (kv_gram: round 4's form, kv_gramh: round 5's); kv_gram only: 3 = the
 // product's wait states without the second scheduling barrier (timing A/B, scripts/kv_gram_fence_ab.py)
 extern "C" int gpamd_tune_hazard_launch(int which, int variant, int safe, const float* X1p, int n, const float* X2p, int m, const float* Vt, int64_t ldv, int t,
                                         const void* Vh, const void* Vl, int64_t ldh, const float* colmul, float* P, int64_t ldo, int S, int jchunk, void* stream) {
@@ -37,7 +37,8 @@ extern "C" int gpamd_tune_hazard_launch(int which, int variant, int safe, const 
 #define GRAMH(V, K, D, CT, NI, EX)                                                                                            \
   if (which == 1 && variant == V) {                                                                                            \
     ni = NI; a.nrb = (n + 128 * NI - 1) / (128 * NI);                                                                          \
-    if (safe) hipLaunchKernelGGL((kv_gramh_kernel<K, D, CT, NI, EX, 1>), dim3((unsigned)a.nrb * S), dim3(256), 0, st, ka);     \
+    if (safe == 1) hipLaunchKernelGGL((kv_gramh_kernel<K, D, CT, NI, EX, 1>), dim3((unsigned)a.nrb * S), dim3(256), 0, st, ka);     \
+    else if (safe == 2) hipLaunchKernelGGL((kv_gramh_kernel<K, D, CT, NI, EX, 2>), dim3((unsigned)a.nrb * S), dim3(256), 0, st, ka); \
     else hipLaunchKernelGGL((kv_gramh_kernel<K, D, CT, NI, EX, 0>), dim3((unsigned)a.nrb * S), dim3(256), 0, st, ka);          \
   }
   // the instantiations the round-4 audit named (D = 1: ONE Gram MFMA per block, the shortest distance), the headline / default kernels, one Matern

@@ -177,3 +177,90 @@ class RowShard:
         else:
             dist.broadcast(x, src=src, group=self.group)
         return x
+
+
+# ======================================================================================================================================
+# Layout policy: how many probe shares x row blocks for one MLL evaluation on G ranks (replaces the "which devices" argument of the
+# reference's MultiDeviceKernel(base_kernel, device_ids), kernels/multi_device_kernel.py:24-47 -- the user names no layout there either).
+#
+# Measured column ladder of the fused K*V on ONE MI355X, per 2.5e11 pairs (n = m = 500 000; profiles/r05_s8_bench_kernel_stats.csv,
+# r02_s38_scale_check_split_default.json): kernel generation is replicated on every probe share, so a launch costs
+# max(generation, 32-column contraction tiles) and is linear in rows x columns-of-K:
+KV_LADDER_MS = {
+    # contraction: (<= 4 columns: first + each further, one 32-column tile, each further tile, extra column riding on the VALU: beside ONE tile / beside more)
+    "split": (18.6, 5.2, 45.0, 44.0, 13.5, 2.0),     # hi/lo-split f16 operands (library default): 1: 18.6, 2: 23.8, 9: 45, 33: 58.5, 65: 91
+    "f32": (18.6, 5.2, 121.0, 118.0, 10.0, 3.0),     # fp32 MFMA (bench.py --contraction f32): 33: 131 (C4 share 519.8 / 4), 65: 242
+}
+XGMI_LINK_GBS = 100.0     # effective bytes/s of one ring step over one xGMI link (153 GB/s peak per link; ring collectives are per-link bound)
+ALLREDUCE_SMALL_MS = 0.05  # one stream-ordered all-reduce of a few floats
+
+
+def kv_cost_ms(cols: int, rows: int, m: int, contraction: str = "split") -> float:
+    """Modelled time of ONE fused K*V launch with ``cols`` right-hand sides on ``rows`` x ``m`` kernel entries (the ladder above, scaled by pairs)."""
+    first, nxt, tile, more, extra1, extra = KV_LADDER_MS[contraction]
+    if cols <= 4:
+        base = first + nxt * (cols - 1)
+    else:
+        ex = 1 if cols % 32 == 1 and cols > 32 else 0
+        tiles = (cols - ex + 31) // 32
+        base = tile + more * (tiles - 1) + (extra1 if tiles == 1 else extra) * ex
+    return base * (float(rows) * float(m)) / 2.5e11
+
+
+def grid_cost_ms(P: int, R: int, n: int, t_total: int, contraction: str = "split", rhs_cols: int = 1) -> float:
+    """Modelled time of one mBCG iteration of the MLL solve on a P x R grid: the widest probe share's launch on its row block + (R > 1) one
+    all-gather of the search directions over the row group (ring: (R - 1) / R of 4 n cols bytes through one link) and the two small
+    all-reduces of the solver's inner products."""
+    cols = -(-t_total // P) + rhs_cols            # the first share also carries the rhs column(s)
+    rows = -(-n // R)
+    ms = kv_cost_ms(cols, rows, n, contraction) + ALLREDUCE_SMALL_MS
+    if R > 1:
+        ms += 4.0 * n * cols * (R - 1) / R / (XGMI_LINK_GBS * 1e9) * 1e3 + 2 * ALLREDUCE_SMALL_MS
+    return ms
+
+
+def choose_grid(world: int, n: int, t_total: int, contraction: str = "split", rhs_cols: int = 1, allow_rows: bool = True) -> tuple[int, int]:
+    """(P probe shares, R row blocks), P * R == world, minimising :func:`grid_cost_ms`; ties go to the layout with fewer row blocks (no
+    all-gather).  ``allow_rows=False``: operators whose rows cannot be sharded (structured operators) -> (world, 1).  Every share needs at
+    least one probe and every row block at least one 512-row group of the Gram-form kernels."""
+    best = (world, 1)
+    if not allow_rows:
+        return best
+    best_ms = None
+    for R in range(1, world + 1):
+        if world % R:
+            continue
+        P = world // R
+        if P > max(t_total, 1) or (R > 1 and n // R < 512):
+            continue
+        ms = grid_cost_ms(P, R, n, t_total, contraction, rhs_cols)
+        if best_ms is None or ms < best_ms * (1.0 - 1e-9):
+            best, best_ms = (P, R), ms
+    return best
+
+
+_GRID_GROUPS: dict = {}
+
+
+def grid_groups(P: int, R: int, base=None):
+    """The two subgroups of THIS rank on a P x R grid of the ranks of ``base`` (default WORLD), rank = p * R + r: (probe group = the P ranks with
+    its r -- stopping rule, SLQ sums --, row group = the R ranks with its p -- all-gather of the search directions, inner products); ``None``
+    for a dimension of extent 1.  ``new_group`` is collective: every rank creates every group, in the same order; the result is cached per
+    (base, P, R), so repeated evaluations create nothing."""
+    world = dist.get_world_size(base)
+    if P * R != world:
+        raise ValueError(f"grid {P}x{R} needs {P * R} ranks, the group has {world}")
+    key = (id(base) if base is not None else 0, P, R)
+    if key not in _GRID_GROUPS:
+        rank = dist.get_rank(base)
+        ranks = list(range(world)) if base is None or base is dist.group.WORLD else dist.get_process_group_ranks(base)
+        pgs = [dist.new_group([ranks[p * R + r] for p in range(P)]) for r in range(R)] if (P > 1 and R > 1) else None
+        rgs = [dist.new_group([ranks[p * R + r] for r in range(R)]) for p in range(P)] if (P > 1 and R > 1) else None
+        whole = base if base is not None else dist.group.WORLD
+        if R == 1:
+            _GRID_GROUPS[key] = (whole if P > 1 else None, None)
+        elif P == 1:
+            _GRID_GROUPS[key] = (None, whole)
+        else:
+            _GRID_GROUPS[key] = (pgs[rank % R], rgs[rank // R])
+    return _GRID_GROUPS[key]

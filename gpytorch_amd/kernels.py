@@ -315,8 +315,9 @@ class MultiDeviceKernel(Kernel):
     (``torchrun``; RCCL): the wrapped kernel returns the same fused operator as without the wrapper, and the operator shards its
     work at solve time -- probe columns of the MLL over ``settings.sharding.probe_group``, the few-column posterior solves by rows
     over ``settings.sharding.row_group`` (``distributed.py``).  Constructing this kernel in a process group of more than one rank
-    installs the WORLD group for both (unless groups are already set), which is the closest equivalent of "allocate the covariance
-    on these devices"; in a single process with several ``device_ids`` it warns once and runs on the inputs' device.
+    installs the automatic layout policy over WORLD (``settings.sharding("auto")``, unless a sharding scope is already set): the closest
+    equivalent of "allocate the covariance on these devices" -- the user names devices, never a probe-share x row-block grid; in a single
+    process with several ``device_ids`` it warns once and runs on the inputs' device.
     The wrapped kernel is registered as ``module`` (the name ``DataParallel`` uses), so state-dict keys match the reference's."""
 
     def __init__(self, base_kernel, device_ids, output_device=None, create_cuda_context=True, **kwargs):
@@ -329,20 +330,19 @@ class MultiDeviceKernel(Kernel):
         from . import settings
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # process-global, like every setting here (and like the reference's settings): said out loud once, undone by `release()`
+            # process-global, like every setting here (and like the reference's settings): said out loud once, undone by `release()`.  The user of
+            # the reference's MultiDeviceKernel names devices, not a layout: the "auto" policy of settings.sharding takes that role -- every MLL
+            # evaluation picks its probe-share x row-block grid from (n, probes) (distributed.choose_grid), the posterior solves are row-sharded over WORLD
             import warnings
 
-            installed = []
-            if settings.sharding._probe_group is None:
-                settings.sharding._probe_group = dist.group.WORLD
-                installed.append("probe_group")
-            if settings.sharding._row_group is None:
-                settings.sharding._row_group = dist.group.WORLD
-                installed.append("row_group")
-            self._installed = installed
-            if installed:
-                warnings.warn(f"gpytorch_amd.kernels.MultiDeviceKernel installed the WORLD process group as settings.sharding {' / '.join(installed)} "
-                              "for EVERY model of this process; MultiDeviceKernel.release() (or a settings.sharding(...) scope) undoes it.", RuntimeWarning)
+            self._installed = []
+            if not settings.sharding._auto and settings.sharding._probe_group is None and settings.sharding._row_group is None \
+                    and settings.sharding._mll_row_group is None:
+                settings.sharding._auto = True
+                self._installed = ["auto"]
+                warnings.warn("gpytorch_amd.kernels.MultiDeviceKernel installed the WORLD process group with the automatic layout policy "
+                              "(settings.sharding('auto')) for EVERY model of this process; MultiDeviceKernel.release() (or a settings.sharding(...) "
+                              "scope) undoes it.", RuntimeWarning)
         elif len(self.device_ids) > 1:
             import warnings
 
@@ -353,8 +353,8 @@ class MultiDeviceKernel(Kernel):
         """Take back the process groups this constructor installed in ``settings.sharding`` (no-op if it installed none)."""
         from . import settings
 
-        for name in getattr(self, "_installed", []):
-            setattr(settings.sharding, "_" + name, None)
+        if getattr(self, "_installed", []):
+            settings.sharding._auto = False
         self._installed = []
 
     @property

@@ -114,11 +114,28 @@ class DefaultPredictionStrategy:
                 from .operators import BatchLinearOperator
 
                 train_train_covar = BatchLinearOperator.replicate(train_train_covar, rhs_in.shape[:-2])
+            if (settings.rhs_refinement.on() and ttc.dtype == torch.float32 and rhs_in.dim() == 2 and rhs_in.shape[-1] <= 4096
+                    and hasattr(train_train_covar, "float64_product_available")):
+                # K_** - K_*X K_hat^-1 K_X* is 1 - 0.9998.. at a well-determined test point: the variance of f needs the quadratic form to ~1e-6,
+                # the float32 solve delivers 3e-4.  Round 5 refined the n_test solves (a second solve + a float64 product: 3.7 x the time); the
+                # quadratic form is what is wanted, and X^T (2 B - K_hat X) with K_hat X in float64 has it to SECOND order in the solve error --
+                # one float64 product, no second solve (bbmm.variational_inv_quad)
+                from .bbmm import variational_inv_quad
+
+                if train_train_covar.float64_product_available():
+                    with settings.rhs_refinement(False):
+                        rhs = train_train_covar.solve(rhs_in)
+                    quad = variational_inv_quad(train_train_covar.matmul_float64, rhs_in, rhs)
+                    if torch.is_tensor(test_test_covar):
+                        return to_linear_operator((test_test_covar.to(torch.float64) - quad).to(ttc.dtype))
+                    # (K_** is an operator above max_eager_kernel_size: its own diagonal / products stay matrix-free; the n_test x n_test
+                    # correction is dense, kept in float64 so that diag(K_**) - diag(quad) loses nothing before the final rounding)
+                    return _VarianceDifference(test_test_covar, quad)
             rhs = train_train_covar.solve(rhs_in)
             if torch.is_tensor(test_test_covar):
                 if settings.rhs_refinement.on() and ttc.dtype == torch.float32:
-                    # K_** - K_*X K_hat^-1 K_X* is 1 - 0.9998.. at a well-determined test point: with the solves refined to float64 accuracy
-                    # (settings.rhs_refinement) the LAST contraction must not throw the digits away again -- float64 GEMM, float32 result
+                    # (operators without a fused float64 product: the solves were refined inside solve(); the LAST contraction must not throw
+                    # the digits away again -- float64 GEMM, float32 result)
                     return to_linear_operator((test_test_covar.to(torch.float64) - ttc.to(torch.float64) @ rhs.to(torch.float64)).to(ttc.dtype))
                 return to_linear_operator(test_test_covar - ttc @ rhs)
             return test_test_covar + MatmulLinearOperator(DenseLinearOperator(ttc), DenseLinearOperator(rhs.mul(-1)))
@@ -126,6 +143,18 @@ class DefaultPredictionStrategy:
         if torch.is_tensor(test_test_covar):
             return to_linear_operator(torch.add(test_test_covar, root @ root.mT, alpha=-1))
         return SumLinearOperator(test_test_covar, MatmulLinearOperator(DenseLinearOperator(root), DenseLinearOperator(root.mT.mul(-1))))
+
+
+class _VarianceDifference(SumLinearOperator):
+    """K_** - Q with K_** a (matrix-free) operator and Q a dense float64 [m, m] matrix (``bbmm.variational_inv_quad``): behaves like the sum, but
+    the diagonal is formed in float64 (the predictive variance of f is a difference of nearly equal numbers)."""
+
+    def __init__(self, kss, quad64: torch.Tensor):
+        super().__init__(kss, DenseLinearOperator((-quad64).to(kss.dtype)))
+        self._kss, self._quad64 = kss, quad64
+
+    def diagonal(self, offset=0, dim1=-2, dim2=-1):
+        return (self._kss.diagonal().to(torch.float64) - self._quad64.diagonal()).to(self._kss.dtype)
 
 
 def prediction_strategy(train_inputs, train_prior_dist, train_labels, likelihood):

@@ -184,14 +184,56 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
         return linear_cg(None, None, None, rhs_t, n_tridiag=n_tridiag, tolerance=tolerance, kv_partials=partials,
                          dvec=self._dvec(), nvec=N, group=self.bbmm_opts.get("group"), preconditioner=self._precond())
 
+    # ---- float64 product on the prepared points of the float32 path (mixed-precision corrections: settings.rhs_refinement) ----
+    def float64_product_available(self) -> bool:
+        p1, _ = self.kron.kx.prepared()
+        return bool(p1.fused and p1.dp <= B.FUSED_F64_MAX_DP)
+
+    def _matvec64(self):
+        """a64 [c, ld_{nT}] (probe-major, interleaved, float64) -> (K_XX (x) K_TT + I (x) diag(task noise)) a in float64: the Kronecker MVM of
+        ``kron_matvec`` on the prepared points widened to float64 (one fused float64 launch with T x columns, ``csrc/kv_f64.hpp``), groups of 20 columns."""
+        p1, _ = self.kron.kx.prepared()
+        x64 = B.PreparedPoints(p1.xp.to(torch.float64), p1.n, p1.d, p1.dp, p1.kind, p1.param)
+        ktt = self.kron.ktt.detach().to(torch.float64)
+        os_ = self.kron.kx._os()
+        os64 = None if os_ is None else os_.to(torch.float64)
+        dv = self._dvec().to(torch.float64)
+        grp = max(1, 80 // self.kron.T)
+
+        def mv(a64):
+            out = torch.empty_like(a64)
+            for c0 in range(0, a64.shape[0], grp):
+                blk = a64[c0 : c0 + grp].contiguous()
+                out[c0 : c0 + grp] = kron_matvec(x64, x64, ktt, blk, os64)[:, : blk.shape[1]] + dv.unsqueeze(0)[:, : blk.shape[1]] * blk
+            return out
+
+        return mv
+
+    def matmul_float64(self, rhs: torch.Tensor) -> torch.Tensor:
+        """K_hat @ rhs ([nT, c] -> [nT, c]) in float64 (see ``FusedKernelAddedDiagLinearOperator.matmul_float64``)."""
+        if not self.float64_product_available():
+            return None
+        return B.from_probe_major(self._matvec64()(B.to_probe_major(rhs.detach(), torch.float64)), self.shape[-1])
+
     def solve(self, rhs, lhs=None):
         squeeze = rhs.dim() == 1
         r = rhs.unsqueeze(-1) if squeeze else rhs
         if self._use_cholesky(settings.fast_computations.solves):
             sol = torch.cholesky_solve(r.detach().double(), psd_safe_cholesky(self.to_dense().detach().double(), model_dtype=self.dtype)).to(rhs.dtype)
         else:
-            sol_t, info = self._cg(B.to_probe_major(r.detach(), B.work_dtype(self.kron.kx.x1)), tolerance=settings.cg_tolerance.value())
+            rhs_t = B.to_probe_major(r.detach(), B.work_dtype(self.kron.kx.x1))
+            sol_t, info = self._cg(rhs_t, tolerance=settings.cg_tolerance.value())
             self._cache["last_cg_info"] = info
+            if settings.rhs_refinement.on() and sol_t.dtype == torch.float32 and self.bbmm_opts.get("group") is None and self.float64_product_available():
+                # mixed-precision refinement of the float32 solves (round 6: the structured operators too): float64 residual through the Kronecker
+                # MVM on the same prepared points, one more float32 solve of it (bbmm.refine_with_)
+                from .bbmm import refine_with_
+
+                def solve32(res):
+                    d, inf = self._cg(res, tolerance=settings.cg_tolerance.value())
+                    return d, inf.iterations
+
+                refine_with_(rhs_t.to(torch.float64), sol_t, self._matvec64(), solve32, settings.rhs_refinement.steps)
             sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
         if lhs is not None:
             sol = lhs @ sol

@@ -808,10 +808,14 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         """Solver options of this evaluation: ``bbmm_opts`` completed with the ``settings.sharding`` probe group
         (each rank then draws its share of ``num_trace_samples`` from a rank-specific generator)."""
         opts = self.bbmm_opts
-        rg = settings.sharding.mll_row_group()
+        # the probe group and the row group of THIS evaluation: the explicit groups of the settings.sharding scope, or -- sharding("auto") -- the
+        # P x R grid the cost model picks from (n, probes); rows can be sharded for the single fused float32 kernel with a constant diagonal only
+        rows_ok = self.noise_vec is None and self.kernel_op.prepared()[0].fused
+        # (an EXPLICIT mll_row_group on an operator whose rows cannot be sharded still raises in bbmm.inv_quad_logdet_forward: never silently replicated)
+        pg_auto, rg = settings.sharding.mll_groups(self.shape[-1], settings.num_trace_samples.value(), allow_rows=rows_ok or not settings.sharding.is_auto())
         if rg is not None and "row_group" not in opts and torch.distributed.get_world_size(rg) > 1:
             opts = dict(opts, row_group=rg)   # two-dimensional split (probe groups x row blocks), bbmm.inv_quad_logdet_forward
-        group = opts.get("group", settings.sharding.probe_group())
+        group = opts.get("group", pg_auto)
         if group is None or "group" in opts or torch.distributed.get_world_size(group) == 1:
             return opts
         from .distributed import probe_shard
@@ -880,6 +884,23 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         if lhs is not None:
             sol = lhs @ sol
         return sol.squeeze(-1) if squeeze else sol
+
+    def float64_product_available(self) -> bool:
+        """A fused float64 product exists for this operator (float32 model, d <= 16: ``csrc/kv_f64.hpp``)."""
+        p1, _ = self.kernel_op.prepared()
+        return bool(p1.fused and p1.dp <= B.FUSED_F64_MAX_DP)
+
+    def matmul_float64(self, rhs: torch.Tensor) -> torch.Tensor:
+        """K_hat @ rhs ([n, c] -> [n, c]) with the kernel entries, the contraction and the result in FLOAT64 on the prepared points of the float32
+        path (``bbmm.matvec64``): the residual / ``A X`` product of the mixed-precision corrections (``settings.rhs_refinement``,
+        ``bbmm.variational_inv_quad``).  ``None`` where no fused float64 kernel applies (d > 16)."""
+        from .bbmm import matvec64
+
+        p1, _ = self.kernel_op.prepared()
+        if not self.float64_product_available():
+            return None
+        mv = matvec64(p1, self.kernel_op._os(), self._nz(), self._dvec())
+        return B.from_probe_major(mv(B.to_probe_major(rhs.detach(), torch.float64)), self.shape[-1])
 
     # ---- row-sharded small-t solves (SURVEY.md 8e.2; settings.sharding(row_group=...) or bbmm_opts["row_group"]) ----
     def _row_shard(self):

@@ -400,16 +400,49 @@ class sharding:
         two-dimensional split of ``bbmm.inv_quad_logdet_forward`` -- probe groups x row blocks; the two groups must be orthogonal, i.e. a
         P x R grid of ranks).  For many GPUs and few probes per GPU (C4: 256 probes on 8 GPUs -> 4 x 2 keeps 64 + 1 columns per rank).
 
+    ``sharding("auto")`` (or ``sharding(auto=True)``) asks for no layout at all -- what ``MultiDeviceKernel(base_kernel, device_ids)`` asks of its
+    user (``kernels/multi_device_kernel.py:24-47``): the posterior's few-column solves are row-sharded over WORLD, and every MLL evaluation picks
+    its P x R grid (probe shares x row blocks, P R = world size) from the number of points and probes with the cost model of
+    ``distributed.choose_grid`` (measured column ladder of the fused K*V + one all-gather of the search directions per iteration over a row
+    group) and builds the subgroups on first use (``distributed.grid_groups``: collective, cached).  The metric workload (n = 500 000, 64
+    probes) on 8 GPUs: 1 x 8 -- 65 columns on an eighth of the rows each; C4 (n = 10^6, 256 probes): 2 x 4.
+
     Replaces ``gpytorch.kernels.MultiDeviceKernel`` (``multi_device_kernel.py:49-92``).  Not thread-safe, like every
     other setting here (``gpytorch/settings.py:84-144`` are process-global class attributes)."""
 
     _probe_group = None
     _row_group = None
     _mll_row_group = None
+    _auto = False
     _generators: dict = {}
 
-    def __init__(self, probe_group=None, row_group=None, mll_row_group=None):
-        self._new = (probe_group, row_group, mll_row_group)
+    def __init__(self, probe_group=None, row_group=None, mll_row_group=None, auto=False):
+        if isinstance(probe_group, str):
+            if probe_group != "auto":
+                raise ValueError(f"settings.sharding: unknown policy {probe_group!r} (process groups, or \"auto\")")
+            probe_group, auto = None, True
+        if auto and (probe_group is not None or row_group is not None or mll_row_group is not None):
+            raise ValueError("settings.sharding: 'auto' chooses the groups itself; pass either groups or auto")
+        self._new = (probe_group, row_group, mll_row_group, bool(auto))
+
+    @classmethod
+    def is_auto(cls) -> bool:
+        import torch.distributed as dist
+
+        return bool(cls._auto) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    @classmethod
+    def mll_groups(cls, n: int, t_total: int, allow_rows: bool = True):
+        """(probe group, row group) of one MLL evaluation with ``t_total`` probes on ``n`` points: the explicit groups of the scope, or -- under
+        ``"auto"`` -- the grid ``distributed.choose_grid`` picks (same arguments on every rank -> same grid, same collective group creation)."""
+        if not cls.is_auto():
+            return cls._probe_group, (cls._mll_row_group if allow_rows else None)
+        import torch.distributed as dist
+
+        from .distributed import choose_grid, grid_groups
+
+        P, R = choose_grid(dist.get_world_size(), int(n), int(t_total), "split" if split_contraction.on() else "f32", allow_rows=allow_rows)
+        return grid_groups(P, R)
 
     @classmethod
     def mll_row_group(cls):
@@ -421,6 +454,10 @@ class sharding:
 
     @classmethod
     def row_group(cls):
+        if cls._row_group is None and cls.is_auto():
+            import torch.distributed as dist
+
+            return dist.group.WORLD
         return cls._row_group
 
     @classmethod
@@ -441,10 +478,10 @@ class sharding:
         cls._generators.clear()
 
     def __enter__(self):
-        self._old = (sharding._probe_group, sharding._row_group, sharding._mll_row_group)
-        sharding._probe_group, sharding._row_group, sharding._mll_row_group = self._new
+        self._old = (sharding._probe_group, sharding._row_group, sharding._mll_row_group, sharding._auto)
+        sharding._probe_group, sharding._row_group, sharding._mll_row_group, sharding._auto = self._new
         return self
 
     def __exit__(self, *args):
-        sharding._probe_group, sharding._row_group, sharding._mll_row_group = self._old
+        sharding._probe_group, sharding._row_group, sharding._mll_row_group, sharding._auto = self._old
         return False

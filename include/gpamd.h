@@ -178,7 +178,7 @@ int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream);
 
 /* ---- pivoted Cholesky of the NOISE-FREE kernel matrix (LinearOperator.pivoted_cholesky; wrapper
  * gpytorch/__init__.py:146-173; consumer AddedDiagLinearOperator._preconditioner). L: float[rank][ldl]
- * (zero-filled by the caller), rank <= 128; fwork: float[n + 4]; iwork: int[2 + 2n]; pivots: int64[rank].
+ * (zero-filled by the caller), rank <= 512 (the preconditioner applies ranks <= 128 through its fused kernels); fwork: float[n + 4]; iwork: int[2 + 2n]; pivots: int64[rank].
  * Runs `rank` (pivot, update) steps without host synchronisation; steps after the error tolerance is
  * met are no-ops.  On completion iwork[0] = number of columns produced. ---- */
 int gpamd_pivoted_cholesky_f32(int kind, float kparam, const float* Xp, int n, int dp, const float* scale, int rank, float tol,

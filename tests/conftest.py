@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the slowest tests go into every log (the driver's -m gpu run has a wall-clock limit: what eats it must be visible in the log it pulls)
+    if getattr(config.option, "durations", None) is None:
+        config.option.durations = 15
+        config.option.durations_min = 1.0
 
 
 def pytest_collection_modifyitems(config, items):

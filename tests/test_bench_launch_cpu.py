@@ -21,12 +21,28 @@ def _run(n, extra=()):
 
 
 def test_bench_starts_its_own_ranks_when_no_launcher_is_present():
+    """... and the default multi-GPU line is STRONG scaling of the metric workload (64 probes in total) on the layout the cost model picks for the
+    nominal size: every rank keeps all the columns on a third of the rows."""
     rec = _run(3)
-    assert rec == {"launched": 3, "rank_sum": 6.0, "n_gpus": 3}
+    assert rec["launched"] == 3 and rec["rank_sum"] == 6.0 and rec["n_gpus"] == 3
+    assert rec["scaling"] == "strong" and rec["grid"] == [1, 3]
+    assert [list(x) for x in rec["grid_sums"]] == [[0, 1.0, 6.0], [1, 2.0, 6.0], [2, 3.0, 6.0]]     # row group = all three ranks, no probe group
 
 
 def test_bench_single_rank_needs_no_launcher():
-    assert _run(1)["launched"] == 1
+    rec = _run(1)
+    assert rec["launched"] == 1 and rec["grid"] == [1, 1]
+
+
+def test_metric_smoke_run_takes_the_layout_of_the_full_configuration():
+    """`--gpus 4 --config metric --size 4096`: the layout is chosen for the configuration's NOMINAL size (n = 500 000, 64 probes -> 1 x 4), so
+    that a shrunken smoke run exercises the collectives of the real one; `--scaling weak` keeps rounds 1-5's probes-only line."""
+    rec = _run(4, ("--config", "metric", "--size", "4096"))
+    assert rec["grid"] == [1, 4] and rec["scaling"] == "strong"
+    rec = _run(4, ("--config", "metric", "--size", "4096", "--scaling", "weak"))
+    assert rec["grid"] == [4, 1] and rec["scaling"] == "weak"
+    rec = _run(8, ("--config", "c4"))
+    assert rec["grid"] == [2, 4] and rec["scaling"] == "strong"
 
 
 def test_grid_subgroups_of_the_two_dimensional_split():

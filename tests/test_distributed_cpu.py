@@ -38,9 +38,11 @@ def _worker(rank, world, port, q):
         _w.simplefilter("always")
         mdk = g.kernels.MultiDeviceKernel(g.kernels.RBFKernel(), device_ids=[torch.device("cpu")] * world)
     assert any("installed the WORLD process group" in str(c.message) for c in caught)     # process-global state is announced ...
-    assert S0.sharding.probe_group() is dist.group.WORLD and S0.sharding.row_group() is dist.group.WORLD and mdk.base_kernel.has_lengthscale
+    # the automatic layout policy: posterior solves row-sharded over WORLD, MLL grid chosen per evaluation (2 ranks, 300 points, 6 probes: 2 x 1)
+    assert S0.sharding.is_auto() and S0.sharding.row_group() is dist.group.WORLD and mdk.base_kernel.has_lengthscale
+    assert S0.sharding.mll_groups(300, 6) == (dist.group.WORLD, None)
     mdk.release()                                                                          # ... and can be taken back
-    assert S0.sharding.probe_group() is None and S0.sharding.row_group() is None
+    assert not S0.sharding.is_auto() and S0.sharding.probe_group() is None and S0.sharding.row_group() is None
     n, t_total = 300, 6
     X, y = make_data(n, 3)
     Z = torch.randn(n, t_total, generator=torch.Generator().manual_seed(1234), dtype=torch.float64)
@@ -440,3 +442,82 @@ def test_two_dimensional_split_probe_groups_times_row_halves_matches_single_proc
         if p == 0:
             assert torch.allclose(s_loc[:, -1], sol[r0:r1, t_total], rtol=0, atol=3e-5 * scale)
         assert abs(ldr - ld) < 1e-6 * abs(ld), (rank, ldr, ld)
+
+
+def test_layout_policy_cost_model():
+    """distributed.choose_grid: the measured column ladder of the fused K*V (kernel generation replicated on every probe share) + one
+    all-gather of the search directions per iteration over a row group.  The metric workload (64 probes) goes 1 x N -- probe sharding alone
+    would leave 8 + 1 columns per GPU at N = 8: 45 ms against 91 / 8 + all-gather --, C4 (256 probes) keeps >= 2 probe shares, operators
+    whose rows cannot be sharded stay probes-only, and nobody gets fewer than one probe or less than one 512-row group."""
+    from gpytorch_amd import distributed as D
+
+    # the ladder reproduces the measured launches (ms at n = 500 000): profiles/r05_s8_bench_kernel_stats.csv, DESIGN 3.2 / 6
+    for cols, ms, c in ((1, 18.6, "split"), (2, 23.8, "split"), (9, 45.0, "split"), (33, 58.5, "split"), (65, 91.0, "split"), (65, 242.0, "f32"), (33, 131.0, "f32")):
+        assert abs(D.kv_cost_ms(cols, 500_000, 500_000, c) - ms) < 0.02 * ms, (cols, c)
+    for c in ("split", "f32"):
+        assert [D.choose_grid(N, 500_000, 64, c) for N in (1, 2, 4, 8)] == [(1, 1), (1, 2), (1, 4), (1, 8)]
+        P, R = D.choose_grid(8, 1_000_000, 256, c)
+        assert P * R == 8 and P >= 2
+    assert D.grid_cost_ms(1, 8, 500_000, 64) < 0.35 * D.grid_cost_ms(8, 1, 500_000, 64)          # 12.7 against 45 ms per iteration
+    assert D.choose_grid(8, 500_000, 64, allow_rows=False) == (8, 1)
+    assert D.choose_grid(8, 500_000, 4) == (1, 8)                                                  # fewer probes than ranks: rows only
+    assert D.choose_grid(8, 2_000, 64)[1] <= 2                                                     # 2000 points: at most 3 row groups of 512
+    P, R = D.choose_grid(6, 100_000, 10)
+    assert P * R == 6
+
+
+def _auto_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from gpytorch_amd import distributed as D
+    from gpytorch_amd import settings as S
+
+    D.init_from_env("gloo")
+    out = {}
+    assert S.sharding.mll_groups(500_000, 64) == (None, None) and not S.sharding.is_auto()
+    with S.sharding("auto"):
+        assert S.sharding.is_auto() and S.sharding.row_group() is dist.group.WORLD
+        for name, (n, t) in (("metric", (500_000, 64)), ("c4", (1_000_000, 256)), ("probes_only", (3_000, 64))):
+            pg, rg = S.sharding.mll_groups(n, t)
+            a, b = torch.tensor([float(rank + 1)]), torch.tensor([float(rank + 1)])
+            if pg is not None:
+                dist.all_reduce(a, group=pg)
+            if rg is not None:
+                dist.all_reduce(b, group=rg)
+            out[name] = (None if pg is None else dist.get_world_size(pg), None if rg is None else dist.get_world_size(rg), float(a), float(b))
+            assert S.sharding.mll_groups(n, t) == (pg, rg)            # cached: a second evaluation creates no group
+        pg, rg = S.sharding.mll_groups(500_000, 64, allow_rows=False)   # structured operators: probe columns only
+        out["structured"] = (dist.get_world_size(pg), rg)
+    assert not S.sharding.is_auto() and S.sharding.row_group() is None
+    with pytest.raises(ValueError):
+        S.sharding("auto", row_group=dist.group.WORLD)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharding_auto_builds_the_groups_of_the_chosen_grid():
+    """settings.sharding("auto") on 4 gloo ranks: every MLL evaluation gets the subgroups of the grid the cost model picks for its (n, probes) --
+    metric 1 x 4 (row group = WORLD, no probe group), C4 2 x 2 (rank = p * 2 + r), a small system probes-only -- built collectively on first
+    use and cached."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_auto_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from gpytorch_amd.distributed import choose_grid
+
+    assert choose_grid(4, 500_000, 64) == (1, 4) and choose_grid(4, 1_000_000, 256) == (2, 2) and choose_grid(4, 3_000, 64) == (4, 1)
+    for r in range(4):
+        assert got[r]["metric"] == (None, 4, float(r + 1), 10.0)
+        p, rr = divmod(r, 2)
+        assert got[r]["c4"] == (2, 2, float((rr + 1) + (2 + rr + 1)), float((2 * p + 1) + (2 * p + 2)))
+        assert got[r]["probes_only"] == (4, None, 10.0, float(r + 1))
+        assert got[r]["structured"] == (4, None)

@@ -115,3 +115,25 @@ def test_multitask_posterior(fast, dev):
     assert ((var.double().cpu() - var_ref).abs() / var_ref).max() < (0.05 if fast else 5e-3)
     # reference's own criterion: MAE < 0.05 per task against the noiseless truth is data dependent; here: vs dense posterior
     assert float((mu.double().cpu() - mu_ref).abs().mean()) < 0.05
+
+
+def test_multitask_posterior_with_rhs_refinement(dev):
+    """Round 6: ``settings.rhs_refinement`` on the STRUCTURED operator -- the mean-cache solve refined through the float64 Kronecker MVM
+    (``KroneckerFusedAddedDiagLinearOperator._matvec64``) and the exact predictive covariance from ``bbmm.variational_inv_quad`` (one float64
+    product, no second solve): the variance of F (without the task noise) against dense float64, which the unrefined float32 path misses."""
+    n, ns = 900, 40
+    X, Y = _data(n, 2)
+    Xs, _ = _data(ns, 2, seed=5)
+    g, m, lik = _model(X, Y, dev, **PARAMS)
+    S = g.settings
+    mu_ref, fvar_ref = OM.dense_posterior("rbf", X, Y, Xs, 0.35, 1.0, PARAMS["Bf"], PARAMS["v"], PARAMS["tn"], noise=False)
+    out = {}
+    for refine in (False, True):
+        m.train(); m.eval(); lik.eval()
+        with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.fast_pred_var(False), S.rhs_refinement(refine):
+            pred = m(Xs.float().to(dev))
+            out[refine] = (pred.mean.double().cpu(), pred.variance.double().cpu())
+    err = {r: float(((out[r][1] - fvar_ref).abs() / (2e-3 * fvar_ref + 2e-6)).max()) for r in out}
+    assert rel_err(out[True][0], mu_ref) < 2e-4 and rel_err(out[True][0], mu_ref) <= rel_err(out[False][0], mu_ref) + 1e-6
+    assert err[True] < 1.0, err                       # the variance of f to rtol 2e-3 (+ the float32-input floor 2e-6)
+    assert err[True] < err[False], err

@@ -7,8 +7,9 @@ before the first non-matrix instruction reads one of them:
     at least the fence's 32 wait states -- i.e. no MFMA has been moved below its fence by the optimiser (which round 3's fence, lacking
     data dependencies, allowed: two MFMAs of kv_grad2_kernel<.., WSPLIT> were emitted after the s_nops);
   * kv_gram_kernel (the headline fp32-contraction kernel): at least 20 -- 8 explicit wait states behind its Gram MFMAs on top of the table (round 5);
-  * every other kernel: never closer than the toolchain's own hazard table for an 8-pass XDL write (12 wait states); kv_gramh_kernel, which sits
-    on that table plus one intervening MFMA, is stress-tested on the device against its fully fenced build (tests/test_gpu_hazard_stress.py).
+  * kv_gramh_kernel (the library-default split kernel): at least 20 as well since round 6 (8 tied wait states behind every Gram MFMA + one intervening
+    contraction MFMA); still stress-tested on the device against its fully fenced build (tests/test_gpu_hazard_stress.py);
+  * every other kernel: never closer than the toolchain's own hazard table for an 8-pass XDL write (12 wait states).
 A compiler or flag change that breaks either shows up here, at build time, without a GPU."""
 import os
 import sys
@@ -42,6 +43,8 @@ def test_every_vgpr_destination_mfma_is_read_behind_its_fence():
     assert not bad, bad[:5]
     gram = [r["min_wait_states"] for r in rows if A.family(r["kernel"]) == "kv_gram_kernel" and "32x32x16_f16" in r["mfma"]]
     assert gram and min(gram) >= 20, min(gram)
+    gramh = [r["min_wait_states"] for r in rows if A.family(r["kernel"]) == "kv_gramh_kernel"]
+    assert gramh and min(gramh) >= 20, min(gramh)
 
 
 def test_audit_measures_a_synthetic_hazard():

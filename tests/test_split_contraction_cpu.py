@@ -331,6 +331,46 @@ def test_rhs_refinement_loop_squares_the_accuracy_of_a_float32_solve():
     assert e1 < 0.05 * e0, (e0, e1)        # one refinement step: more than an order of magnitude
 
 
+def test_variational_quadratic_form_is_second_order_in_the_solve_error():
+    """``bbmm.variational_inv_quad`` (the predictive variance of f under ``settings.rhs_refinement``, round 6): B^T A^-1 B from float32-accurate
+    solves X to SECOND order in their error with ONE float64 product A X and no second solve -- X^T (2 B - A X) -- against the plain
+    contraction B^T X, on an ill-conditioned kernel system (kappa ~ 1e6) whose diagonal 1 - b^T A^-1 b sits at 1e-4 .. 1e-2."""
+    import pytest
+
+    try:
+        from gpytorch_amd.bbmm import variational_inv_quad
+    except Exception as exc:
+        pytest.skip(f"gpytorch_amd not importable here: {exc}")
+    g = torch.Generator().manual_seed(3)
+    n, m = 700, 37
+    X = torch.rand(n, 2, generator=g, dtype=torch.float64)
+    Xs = torch.rand(m, 2, generator=g, dtype=torch.float64)
+    k = lambda a, c: torch.exp(-0.5 * torch.cdist(a, c).pow(2) / 0.3 ** 2)     # noqa: E731
+    A = k(X, X) + 1e-4 * torch.eye(n, dtype=torch.float64)
+    Bm = k(X, Xs)                                                               # [n, m] = K_X*
+    exact = Bm.t() @ torch.linalg.solve(A, Bm)
+    # a float32-accurate solve: the exact one with a relative perturbation of 3e-4 (what float32 mBCG attains at this conditioning), float32 storage
+    Xsol = torch.linalg.solve(A, Bm)
+    Xsol = (Xsol + 3e-4 * Xsol.norm(dim=0) / n ** 0.5 * torch.randn(n, m, generator=g, dtype=torch.float64)).float()
+    calls = []
+
+    def matmul64(v):
+        calls.append(v.shape[1])
+        assert v.dtype == torch.float64
+        return A @ v
+
+    quad = variational_inv_quad(matmul64, Bm.float(), Xsol, cols=16, rows=256)
+    plain = Bm.t() @ Xsol.double()
+    e_plain = float((plain - exact).diagonal().abs().max())
+    e_var = float((quad - exact).diagonal().abs().max())
+    assert calls == [16, 16, 5]                       # one float64 product per column group, nothing else
+    assert torch.allclose(quad, quad.t())
+    # (the float32 STORAGE of B itself leaves ~1e-7 relative in the form: the floor of any float32-input path)
+    assert e_var < 2e-6 and e_var < 0.02 * e_plain, (e_plain, e_var)
+    var_f = 1.0 - exact.diagonal()
+    assert float(var_f.min()) < 1e-2 and float(((1.0 - quad.diagonal()) - var_f).abs().max()) < 2e-3 * float(var_f.min()) + 2e-6
+
+
 def test_hilbert_order_cache_is_keyed_by_source_and_guarded_by_a_fingerprint():
     """``backend._ORDER_CACHE`` (round 4): one Hilbert permutation per SOURCE cloud across the evaluations of a training run (a new lengthscale
     rescales the prepared points uniformly: same order), and never across different clouds that happen to re-use an address."""
