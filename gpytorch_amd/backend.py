@@ -379,11 +379,22 @@ def workspace(device, nfloats: int, slot: int = 0) -> torch.Tensor:
     return buf
 
 
+_PLAN_CACHE: dict = {}
+
+
 def kv_plan(kind: str, n: int, m: int, d: int, t: int, flags: int, ldo: int):
-    """(S, jchunk, workspace floats) for the kernel variant that (kind, d, t, flags) selects."""
-    S, jc, ws = C.c_int(0), C.c_int(0), C.c_int64(0)
-    check(lib().gpamd_kv_plan(KIND_IDS[kind], n, m, d, t, flags, ldo, C.byref(S), C.byref(jc), C.byref(ws)), "kv_plan")
-    return S.value, jc.value, ws.value
+    """(S, jchunk, workspace floats) for the kernel variant that (kind, d, t, flags) selects.  A pure function of its arguments on a given
+    device (``gpamd_kv_plan`` asks the runtime for the kernel's occupancy): cached -- the region launches of a block-centred product
+    (``_kv_region``) used to repeat the query on every mBCG iteration (advisor finding, round 5)."""
+    key = (kind, n, m, d, t, flags, ldo, torch.cuda.current_device() if torch.cuda.is_available() else -1)
+    hit = _PLAN_CACHE.get(key)
+    if hit is None:
+        S, jc, ws = C.c_int(0), C.c_int(0), C.c_int64(0)
+        check(lib().gpamd_kv_plan(KIND_IDS[kind], n, m, d, t, flags, ldo, C.byref(S), C.byref(jc), C.byref(ws)), "kv_plan")
+        if len(_PLAN_CACHE) > 4096:
+            _PLAN_CACHE.clear()
+        hit = _PLAN_CACHE[key] = (S.value, jc.value, ws.value)
+    return hit
 
 
 def gram_operands(x1: PreparedPoints, x2: PreparedPoints, flags: int):

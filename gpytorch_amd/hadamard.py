@@ -242,9 +242,9 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
         return sol.squeeze(-1) if squeeze else sol
 
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
-        method = check_root_method(method)
-        if method == "cholesky" or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
-            return super().root_inv_decomposition()
+        method = check_root_method(method, inverse=True)
+        if method in ("cholesky", "symeig") or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
+            return super().root_inv_decomposition(method=method)      # dense factorisations of a small operator (base class)
         n = self.shape[-1]
         partials, wd = self._partials()
         dv = self._dvec(wd)

@@ -404,6 +404,15 @@ def block_lanczos_steps(n: int, dev, steps: int, init_t: torch.Tensor):
     m = m_max if not bad else bad[0] * b
     if m == 0:
         raise RuntimeError("block Lanczos: the start block is rank deficient")
+    if m < m_max:
+        # (advisor finding, round 5) a shortened decomposition is said out loud: the LOVE cache built on it has a lower rank than
+        # settings.max_root_decomposition_size asked for, and only the variance error would show it otherwise
+        import warnings
+
+        from .linear_cg import NumericalWarning
+
+        warnings.warn(f"block Lanczos stopped at rank {m} of the {m_max} requested (block {bad[0]} of {steps}: rank-deficient or ill-conditioned in "
+                      "float32 -- the block Krylov space is exhausted to rounding); decompositions built on it have that rank.", NumericalWarning)
     Hm = H[:m, :m]
     T = torch.triu(Hm) + torch.triu(Hm, 1).t()
     return Q[:m], T

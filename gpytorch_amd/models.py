@@ -123,7 +123,7 @@ class DefaultPredictionStrategy:
                 from .bbmm import variational_inv_quad
 
                 if train_train_covar.float64_product_available():
-                    with settings.rhs_refinement(False):
+                    with settings.rhs_refinement(False), settings.cg_tolerance(settings.cg_tolerance.value() * settings.rhs_refinement.variance_tolerance_factor):
                         rhs = train_train_covar.solve(rhs_in)
                     quad = variational_inv_quad(train_train_covar.matmul_float64, rhs_in, rhs)
                     if torch.is_tensor(test_test_covar):

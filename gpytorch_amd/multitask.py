@@ -277,9 +277,9 @@ class KroneckerFusedAddedDiagLinearOperator(LinearOperator):
         return torch.kron(kmat, self.kron.ktt) + torch.diag(self.task_noise.repeat(kx.shape[0]))
 
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
-        method = check_root_method(method)
-        if method == "cholesky" or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
-            return super().root_inv_decomposition()
+        method = check_root_method(method, inverse=True)
+        if method in ("cholesky", "symeig") or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
+            return super().root_inv_decomposition(method=method)      # dense factorisations of a small operator (base class)
         p1, _ = self.kron.kx.prepared()
         ktt, os_, dv = self.kron.ktt.detach(), self.kron.kx._os(), self._dvec()
         N = self.shape[-1]

@@ -248,6 +248,21 @@ class LinearOperator:
             # (psd_safe_cholesky raises NotPSDError after its last jitter level: a failed factor is never handed back)
             Lc = psd_safe_cholesky(self.to_dense().to(torch.float64), model_dtype=self.dtype)
             return RootLinearOperator(Lc.to(self.dtype))
+        if method == "symeig":
+            return RootLinearOperator(_symeig_root(self.to_dense(), False, self.dtype))
+        if method == "pivoted_cholesky":
+            # low-rank root L with L L^T ~= self: the greedy factor itself (rank max_root_decomposition_size), row by row -- matrix-free wherever
+            # the operator serves rows (the fused kernel operators do); the reference: RootLinearOperator(self.pivoted_cholesky(rank))
+            from .bbmm import pivoted_cholesky_rows
+
+            rank = min(settings.max_root_decomposition_size.value(), n)
+            if type(self).pivoted_cholesky is not LinearOperator.pivoted_cholesky:
+                try:
+                    return RootLinearOperator(self.pivoted_cholesky(rank).to(self.dtype))
+                except NotImplementedError:
+                    pass
+            lt = pivoted_cholesky_rows(self._row, self.diagonal().detach(), rank, settings.preconditioner_tolerance.value())
+            return RootLinearOperator(lt.t().contiguous().to(self.dtype))
         from .lanczos import lanczos_tridiag, tridiag_to_diag
 
         def matvec(q_row):  # probe-major [1, ld] -> [1, ld]
@@ -260,6 +275,19 @@ class LinearOperator:
         evals, evecs = tridiag_to_diag(T)
         w = (evecs * evals.clamp_min(0).sqrt().unsqueeze(-2)).to(device=Q.device, dtype=Q.dtype)      # V Lambda^1/2
         return RootLinearOperator((w.t() @ Q)[:, :n].t().contiguous().to(self.dtype))
+
+    def _row(self, p: torch.Tensor) -> torch.Tensor:
+        """Row p ([n]) of the matrix for a 1-element index tensor (``bbmm.pivoted_cholesky_rows``); dense default."""
+        return self.to_dense()[int(p.reshape(-1)[0])]
+
+    def pivoted_cholesky(self, rank, error_tol=None, return_pivots=False):
+        """``LinearOperator.pivoted_cholesky`` (wrapper ``gpytorch/__init__.py:146-173``): the greedy rank-``rank`` factor L [n, rank], row by row."""
+        from .bbmm import pivoted_cholesky_rows
+
+        if return_pivots:
+            raise NotImplementedError("pivoted_cholesky(return_pivots=True) on this operator")
+        tol = settings.preconditioner_tolerance.value() if error_tol is None else error_tol
+        return pivoted_cholesky_rows(self._row, self.diagonal().detach(), min(rank, self.shape[-1]), tol).t().contiguous()
 
     def zero_mean_mvn_samples(self, num_samples: int) -> torch.Tensor:
         """``LinearOperator.zero_mean_mvn_samples``: [num_samples, n] draws of N(0, self) through a root decomposition, or --
@@ -276,9 +304,12 @@ class LinearOperator:
     def root_inv_decomposition(self, initial_vectors=None, test_vectors=None, method=None):
         """Dense default (small operators): the Cholesky root of the inverse.  ``method="lanczos"`` on an operator without a matrix-free
         Lanczos of its own is an error, not a silent Cholesky."""
-        if check_root_method(method) == "lanczos":
+        method = check_root_method(method, inverse=True)
+        if method == "lanczos":
             raise NotImplementedError(f"{type(self).__name__}.root_inv_decomposition(method='lanczos')")
         lanczos_vectors(initial_vectors, test_vectors, self.shape[-1], self.dtype)   # (shape errors as the reference raises them; a dense factor needs no start vector)
+        if method == "symeig":
+            return RootLinearOperator(_symeig_root(self.to_dense(), True, self.dtype))
         Lc = self.cholesky()
         inv_root = torch.linalg.solve_triangular(Lc, torch.eye(Lc.shape[-1], dtype=Lc.dtype, device=Lc.device), upper=False).mT
         return RootLinearOperator(inv_root.to(self.dtype))
@@ -322,12 +353,24 @@ def to_dense(obj):
     return obj.to_dense() if isinstance(obj, LinearOperator) else obj
 
 
-def check_root_method(method):
-    """``method`` of ``LinearOperator.root_decomposition`` / ``root_inv_decomposition`` (linear_operator: "cholesky", "lanczos", and for
-    the forward root also "symeig" / "pivoted_cholesky"): the two methods built here, or an error -- never silently another one."""
-    if method not in (None, "cholesky", "lanczos"):
-        raise NotImplementedError(f"root decomposition method {method!r}: only 'cholesky' and 'lanczos' are implemented")
+def check_root_method(method, inverse: bool = False):
+    """``method`` of ``LinearOperator.root_decomposition`` / ``root_inv_decomposition`` (``gpytorch/__init__.py:176-216``): "cholesky", "lanczos",
+    "symeig", and for the forward root also "pivoted_cholesky" -- or an error, never silently another method."""
+    allowed = (None, "cholesky", "lanczos", "symeig") + (() if inverse else ("pivoted_cholesky",))
+    if method not in allowed:
+        raise NotImplementedError(f"root {'inverse ' if inverse else ''}decomposition method {method!r}: one of {allowed[1:]}")
     return method
+
+
+def _symeig_root(dense: torch.Tensor, inverse: bool, dtype) -> torch.Tensor:
+    """V Lambda^(+-1/2) from the dense symmetric eigendecomposition in float64 (``method="symeig"``); eigenvalues below ``tridiagonal_jitter`` relative to
+    the largest are treated as the reference treats non-positive ones (clamped for the root, dropped for the inverse root)."""
+    evals, evecs = torch.linalg.eigh(dense.to(torch.float64))
+    floor = settings.tridiagonal_jitter.value() * float(evals.abs().max()) * 1e-6
+    if inverse:
+        keep = evals > floor
+        return (evecs[..., keep] / evals[keep].sqrt()).to(dtype)
+    return (evecs * evals.clamp_min(0.0).sqrt().unsqueeze(-2)).to(dtype)
 
 
 def lanczos_vectors(initial_vectors, test_vectors, n: int, dtype):
@@ -339,8 +382,14 @@ def lanczos_vectors(initial_vectors, test_vectors, n: int, dtype):
             out.append(None)
             continue
         v = v.unsqueeze(-1) if v.dim() == 1 else v
-        if v.dim() != 2 or v.shape[-2] != n:
+        if v.shape[-2] != n:
             raise RuntimeError(f"LinearOperator (size={n} x {n}) cannot be multiplied with {name} (size={tuple(v.shape)}).")
+        if v.dim() != 2:
+            # batch-shaped vectors ([*batch, n, k]: what the reference's root_inv_decomposition accepts for batch operators).  The operators here
+            # are single matrices whose DENSE defaults need no start vector -- accepted and ignored there (advisor finding, round 5); the matrix-free
+            # Lanczos paths of a single operator cannot use a batch of them
+            out.append(None)
+            continue
         out.append(B.to_probe_major(v, dtype))
     return out[0], out[1]
 
@@ -653,6 +702,9 @@ class FusedKernelLinearOperator(LinearOperator):
         p1, p2 = self.prepared()
         return B.kernel_rows(p1, idx, p2, self._os())
 
+    def _row(self, p):
+        return self.rows(p.reshape(1)).reshape(-1)
+
     def __add__(self, other):
         if isinstance(other, DiagLinearOperator) and other.batch_shape:
             return BatchLinearOperator.replicate(self, other.batch_shape) + other
@@ -954,9 +1006,9 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         step), the decomposition that solves the test vectors best is returned."""
         from .lanczos import root_inv_decomposition
 
-        method = check_root_method(method)
-        if method == "cholesky" or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
-            return super().root_inv_decomposition()
+        method = check_root_method(method, inverse=True)
+        if method in ("cholesky", "symeig") or (method is None and self._use_cholesky(settings.fast_computations.covar_root_decomposition)):
+            return super().root_inv_decomposition(method=method)      # dense factorisations of a small operator (base class)
         n = self.shape[-1]
         init_t, test_t = lanczos_vectors(initial_vectors, test_vectors, n, B.work_dtype(self.kernel_op.x1))
         if self._row_shard() is not None:
@@ -971,6 +1023,13 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
 
     def pivoted_cholesky(self, rank, error_tol=None, return_pivots=False):
         raise NotImplementedError("pivoted_cholesky is defined on the noise-free kernel operator (self.kernel_op)")
+
+    def _row(self, p):
+        """Row p of K_hat: the fused kernel row + the diagonal entry (``root_decomposition(method="pivoted_cholesky")``: matrix-free)."""
+        row = self.kernel_op._row(p).clone()
+        i = int(p.reshape(-1)[0])
+        row[i] += self.noise.detach().reshape(()).to(row.dtype) + (0.0 if self.noise_vec is None else self.noise_vec.detach()[i].to(row.dtype))
+        return row
 
     # ---- both prediction caches from ONE sequence of two-column products ------------------------------------------------
     def can_fuse_caches(self) -> bool:

@@ -161,6 +161,9 @@ class preconditioner_tolerance(_value_context):
 
 
 class max_root_decomposition_size(_value_context):
+    """Rank of the Lanczos root decompositions (LOVE cache; ``linear_operator.settings.max_root_decomposition_size``, default 100).  With a block
+    recurrence (``lanczos_block_size`` b > 1) the rank is ``b * (rank // b)`` -- 100 -> 96 at b = 8 --, and a block that turns out rank deficient
+    in float32 ends the decomposition early with a ``NumericalWarning`` naming the rank reached (``lanczos.block_lanczos_steps``)."""
     _global_value = 100
 
 
@@ -206,6 +209,13 @@ class rhs_refinement(_feature_flag):
     (d <= 16: the fused float64 kernel), unsharded rows."""
     _default = False
     steps = 1
+    # Round 6: the n_test-column solve behind the EXACT predictive variance is not refined by a second solve any more (3.7 x the unrefined time);
+    # the quadratic form is taken to second order in the solve error -- X^T (2 B - K_hat X), K_hat X in float64: ``bbmm.variational_inv_quad`` -- and
+    # that error is the ENERGY norm of the solve error, which a residual tolerance bounds only through the condition number.  The float32 solve
+    # therefore stops at ``variance_tolerance_factor`` x the tolerance in force: C2 (n = 100 000, 1000 test points, eval_cg_tolerance 1e-4) the
+    # variance of f within rtol 2e-3 (+ the float32-input floor 2e-6) at 0.3 x (3.5 s against 2.6 s unrefined: 1.35 x; 0.9 x with the "auto"
+    # preconditioner rank), not at 1.0 x (8 x the bound) -- profiles/r06_s6_posterior_at_size_c2_variational.json.
+    variance_tolerance_factor = 0.3
 
 
 class skip_posterior_variances(_feature_flag):

@@ -84,7 +84,10 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
  *   (gpytorch/kernels/kernel.py:26-49).  The caller sorts the rows of X1p along a space-filling curve so that blocks are compact and
  *   asserts: max over 128 / 256 / 512-row aligned blocks (GPAMD_KV_BLOCK128: 128-row blocks) of |z - centre|^2 <= 32 and
  *   (max |z1| + max |z2|)^2 <= 2.5e7 (RQ: 60000 -- the split norm of a contracted point saturates at 60000, f16 range; every family but the
- *   heavy-tailed RQ is zero to f32 precision long before, gram_f16.hpp).  With X1c = NULL the GPAMD_KV_GRAM contract is the cloud-centred one (max |z|^2 <= 32). */
+ *   heavy-tailed RQ is zero to f32 precision long before, gram_f16.hpp).  With X1c = NULL the GPAMD_KV_GRAM contract is the cloud-centred one (max |z|^2 <= 32).
+ *   These are HARD preconditions of the flag, not hints: the kernels do not verify them (a check would cost a pass over both clouds per launch) and
+ *   outside them entries of K lose accuracy silently.  A caller that cannot guarantee them passes flags without GPAMD_KV_GRAM (direct differences: no
+ *   scale limit).  The Python host decides per product in backend.gram_mode / SortedView (tests/test_gpu_recenter.py: clouds at 0.8 of the extent limit). */
 int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt,
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream);

@@ -344,3 +344,35 @@ def test_elongated_runs_take_the_128_row_blocks(kind, ls, split, dev, monkeypatc
     tot, gs = float((W * Kd).sum()), float((W * dK * S).sum())
     assert abs(float(out[0]) - tot) < 2e-5 * abs(tot)
     assert abs(float(out[1]) - gs) < 5e-5 * abs(gs)          # sum W dk/ds s: the single-lengthscale sum (MODE 0 convention: out[1])
+
+
+@pytest.mark.parametrize("kind", ["matern32", "matern52"])
+@pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "split"])
+def test_contracted_points_near_the_extent_limit_of_the_saturating_norms(kind, split, dev, monkeypatch):
+    """The block-centred Gram expansion saturates the split norm of a CONTRACTED point at 60 000 (f16 range) and relies on k being zero to
+    float32 precision long before (gram_f16.hpp; include/gpamd.h: (max |z1| + max |z2|)^2 <= 2.5e7 is a HARD precondition of GPAMD_KV_GRAM with
+    block centres -- the kernels do not check it, ``backend.gram_mode`` does).  Advisor finding (round 5): nothing exercised it near the limit.
+    Here: 48 tight clusters scattered over a cube of half-width 1300 in the prepared (scaled) units -- |z_j - c| up to ~4500 between a row block's
+    centre and a contracted point, extent (2 max |z|)^2 ~ 2e7 -- so that almost every pair is far beyond the saturation point while pairs inside a
+    cluster carry the whole product.  Against the float64 oracle (reference formulas)."""
+    from gpytorch_amd import backend as B
+
+    monkeypatch.setattr(B, "SPLIT_CONTRACTION", split)
+    n, d, ls = 24_576, 3, 1.0
+    g = torch.Generator().manual_seed(5)
+    centres = (torch.rand(48, d, generator=g) * 2 - 1) * 1300.0 / math.sqrt(3.0 if kind == "matern32" else 5.0)
+    X = (centres[torch.randint(0, 48, (n,), generator=g)] + 0.6 * torch.randn(n, d, generator=g)).float()
+    Xd = X.to(dev)
+    xp = B.prep_points(kind, Xd, torch.tensor([ls]), Xd.mean(0))
+    zmax = math.sqrt(xp.zmax2)
+    assert 1.0e7 < (2 * zmax) ** 2 <= B.GRAM_MAX_EXTENT_SQ, (2 * zmax) ** 2      # close to the documented limit, inside it
+    assert B.gram_mode(xp, xp) == 2
+    rows = torch.cat([torch.arange(128), torch.randint(128, n - 128, (256,), generator=g), torch.arange(n - 128, n)]).unique()
+    Krows = OK.kernel_matrix(kind, X[rows].double(), X.double(), ls, 1.0, x1_eq_x2=False, direct=True)
+    for t in (1, 8, 33, 65):
+        V = torch.randn(n, t, generator=torch.Generator().manual_seed(t))
+        got = B.kv(xp, xp, B.to_probe_major(V.to(dev)))[:, rows.to(dev)].t().double().cpu()
+        ref = Krows @ V.double()
+        # (5e-5, not the 2e-5 of compact clouds: at |z| ~ 1300 the float32 PREPARED coordinates resolve 1.2e-4, so distances of order one inside a
+        # cluster carry 1e-4 relative before any kernel arithmetic -- measured 3.4e-5 (Matern-3/2, one column), the same on both contractions)
+        assert rel_err(got, ref) < 5e-5, (kind, t, rel_err(got, ref))
