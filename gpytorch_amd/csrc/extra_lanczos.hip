@@ -78,7 +78,8 @@ int64_t gpamd_precond_coef_workspace_doubles(int n, int t, int k) {
 int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* Q, int64_t ldq, int k, int n, double* W,
                               double* workspace, int64_t workspace_doubles, void* stream) {
   if (!R || !Q || !W || !workspace || n <= 0 || t <= 0 || k <= 0 || ldr < n || ldq < n) return lz_fail("precond_coef: bad arguments");
-  if (k > 16 * PC_MT) return lz_fail("precond_coef: rank > 128");
+  if (k > 512) return lz_fail("precond_coef: rank > 512");
+  const unsigned ktiles = (unsigned)((k + 16 * PC_MT - 1) / (16 * PC_MT));   // 128 basis rows per blockIdx.y
   long nb = ((long)n + 255) / 256;   // >= 256 elements per workgroup: small n still spreads over several CUs
   if (nb > 256) nb = 256;
   if (workspace_doubles < (int64_t)nb * t * k) return GPAMD_EWORKSPACE;
@@ -89,9 +90,9 @@ int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* 
     const int tg = t - c0 < 80 ? t - c0 : 80;
     double* part = workspace;             // reused per group: the sum kernel of a group runs before the next group's partials
     if (tg <= 16)
-      hipLaunchKernelGGL((pc_coef_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
+      hipLaunchKernelGGL((pc_coef_kernel<1>), dim3((unsigned)nb, ktiles), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
     else
-      hipLaunchKernelGGL((pc_coef_kernel<5>), dim3((unsigned)nb), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
+      hipLaunchKernelGGL((pc_coef_kernel<5>), dim3((unsigned)nb, ktiles), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
     hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((4 * tg * k + 255) / 256), dim3(256), 0, st, (const double*)part, (int)nb, tg * k, W + (int64_t)c0 * k);
   }
   return lz_check("precond_coef");
@@ -101,7 +102,7 @@ int gpamd_precond_apply_f32f64(const float* R, int64_t ldr, int t, const double*
                                const float* sigma2, float* Out, int64_t ldo, void* stream) {
   if (!R || !Q || !W || !sigma2 || !Out || n <= 0 || t <= 0 || k <= 0 || ldr < n || ldq < n || ldo < n)
     return lz_fail("precond_apply: bad arguments");
-  if (k > 16 * PC_MT) return lz_fail("precond_apply: rank > 128");
+  if (k > 512) return lz_fail("precond_apply: rank > 512");
   hipLaunchKernelGGL(pc_apply_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)((t + PA_CT - 1) / PA_CT)), dim3(256), 0, (hipStream_t)stream,
                      R, ldr, t, Q, ldq, k, n, W, sigma2, Out, ldo);
   return lz_check("precond_apply");
@@ -144,13 +145,13 @@ int gpamd_block_project_f64(const double* Q, int64_t ldq, int k, const double* R
 }
 
 int gpamd_block_subtract_f32(const float* Q, int64_t ldq, int k, const double* W, float* R, int64_t ldr, int b, int n, void* stream) {
-  if (!Q || !R || !W || n <= 0 || b <= 0 || b > LZB_MAXB || k <= 0 || ldq < n || ldr < n) return lz_fail("block_subtract: bad arguments (b <= 16)");
+  if (!Q || !R || !W || n <= 0 || b <= 0 || b > LZB_MAXB || k <= 0 || ldq < n || ldr < n) return lz_fail("block_subtract: bad arguments (b <= 32)");
   hipLaunchKernelGGL(lzb_subtract_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Q, ldq, k, W, R, ldr, b, n);
   return lz_check("block_subtract");
 }
 
 int gpamd_block_transform_f32(const double* M, float* R, int64_t ldr, int b, int n, void* stream) {
-  if (!M || !R || n <= 0 || b <= 0 || b > LZB_MAXB || ldr < n) return lz_fail("block_transform: bad arguments (b <= 16)");
+  if (!M || !R || n <= 0 || b <= 0 || b > LZB_MAXB || ldr < n) return lz_fail("block_transform: bad arguments (b <= 32)");
   hipLaunchKernelGGL(lzb_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, R, ldr, b, n);
   return lz_check("block_transform");
 }

@@ -119,7 +119,7 @@ namespace gpamd {
 // Work split: block b owns a slice of i; threads form a 16 x 16 grid over (column, basis vector) with a CT x MT register tile each;
 // 32-element chunks of R and Q1 are staged in LDS.  Partials [b][t][k] are summed in a fixed order by pc_coef_sum_kernel.
 constexpr int PC_CHUNK = 32;
-constexpr int PC_MT = 8;      // k <= 128
+constexpr int PC_MT = 8;      // 128 basis rows per tile (blockIdx.y of pc_coef_kernel / the tile loop of pc_apply_kernel)
 
 // TQ / TR: types of the basis rows and of the projected rows (double / float: the preconditioner's Q1 against float32 residuals; float / float: the Lanczos
 // basis of the block recurrences below and the Gram matrix of the pivoted-Cholesky factor; double / double: the second Cholesky-QR pass of the preconditioner).  blockIdx.y selects a
@@ -198,32 +198,38 @@ constexpr int PA_CT = 16;
 __global__ __launch_bounds__(256) void pc_apply_kernel(const float* __restrict__ R, int64_t ldr, int t, const double* __restrict__ Q,
                                                        int64_t ldq, int k, int n, const double* __restrict__ W,
                                                        const float* __restrict__ sigma2, float* __restrict__ Out, int64_t ldo) {
-  __shared__ double Ws[PA_CT * 16 * PC_MT];   // [c][m], k <= 128
+  __shared__ double Ws[PA_CT * 16 * PC_MT];   // [c][m] of the current 128-row tile of Q1 (round 6: any k, tile by tile; was k <= 128)
   const int c0 = blockIdx.y * PA_CT;
   const int nc = min(PA_CT, t - c0);
-  for (int e = threadIdx.x; e < nc * k; e += 256) Ws[(e / k) * (16 * PC_MT) + (e % k)] = W[(int64_t)(c0 + e / k) * k + (e % k)];
-  __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   double acc[PA_CT];
 #pragma unroll
   for (int c = 0; c < PA_CT; ++c) acc[c] = 0.0;
-  for (int m = 0; m < k; ++m) {
-    const double q = Q[(int64_t)m * ldq + i];
+  for (int m0 = 0; m0 < k; m0 += 16 * PC_MT) {
+    const int kt = min(16 * PC_MT, k - m0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nc * kt; e += 256) Ws[(e / kt) * (16 * PC_MT) + (e % kt)] = W[(int64_t)(c0 + e / kt) * k + m0 + (e % kt)];
+    __syncthreads();
+    if (i < n) {
+      for (int m = 0; m < kt; ++m) {
+        const double q = Q[(int64_t)(m0 + m) * ldq + i];
 #pragma unroll
-    for (int c = 0; c < PA_CT; ++c) acc[c] = fma(Ws[c * (16 * PC_MT) + m], q, acc[c]);
+        for (int c = 0; c < PA_CT; ++c) acc[c] = fma(Ws[c * (16 * PC_MT) + m], q, acc[c]);
+      }
+    }
   }
+  if (i >= n) return;
   const double inv = 1.0 / (double)sigma2[0];
 #pragma unroll
   for (int c = 0; c < PA_CT; ++c)
     if (c < nc) Out[(int64_t)(c0 + c) * ldo + i] = (float)(((double)R[(int64_t)(c0 + c) * ldr + i] - acc[c]) * inv);
 }
 
-// ---- BLOCK Lanczos (lanczos.py block_lanczos_steps: the LOVE cache on a block Krylov space; b <= 16 rows per block, any number k of basis rows) ----
+// ---- BLOCK Lanczos (lanczos.py block_lanczos_steps: the LOVE cache on a block Krylov space; b <= 32 rows per block, any number k of basis rows) ----
 // project : W[c][m] = <R[c], Q[m]>      = pc_coef_kernel<1, float> over k tiles of 128 (double accumulation, partials summed in a fixed order)
 // subtract: R[c][i] -= sum_m W[c][m] Q[m][i]      (in place, double arithmetic; W of a 128-row tile of the basis in LDS, every Q element read once)
 // transform: R[r][i] = sum_c M[r][c] R[c][i]      (in place; M: b x b double -- the inverse Cholesky factor of the block's Gram matrix: Cholesky-QR)
-constexpr int LZB_MAXB = 16;
+constexpr int LZB_MAXB = 32;   // (16 until round 6: the auto block size at n >= 262 144 is 32)
 __global__ __launch_bounds__(256) void lzb_subtract_kernel(const float* __restrict__ Q, int64_t ldq, int k, const double* __restrict__ W, float* R,
                                                           int64_t ldr, int b, int n) {
   __shared__ double Ws[LZB_MAXB * 128];   // [c][m] of the current basis tile

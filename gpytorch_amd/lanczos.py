@@ -324,7 +324,7 @@ def block_lanczos_steps(n: int, dev, steps: int, init_t: torch.Tensor):
     H = torch.zeros(m_max, m_max, device=dev, dtype=torch.float64)
     infos = []
     defl = (100.0 * torch.finfo(wd).eps) ** 2
-    native = wd == torch.float32 and torch.device(dev).type == "cuda" and b <= 16 and not FORCE_TORCH
+    native = wd == torch.float32 and torch.device(dev).type == "cuda" and b <= 32 and not FORCE_TORCH
     if native:
         # vector work on the gpamd_block_* kernels (csrc/lanczos_kernels.hpp): float32 rows, float64 accumulation, every basis element read once per
         # pass (rocBLAS' tall-skinny float64 GEMMs -- the b x n x b Gram matrix -- cost tens of ms per call: profiles/r05_s1_love_block_timing_c2_torch.json,
@@ -439,7 +439,9 @@ def block_size_for(n: int, rank: int) -> int:
     from 200 on the two are indistinguishable and the block form is 3-5 x faster."""
     v = settings.lanczos_block_size.value()
     if v == "auto":
-        return 8 if (n >= settings.lanczos_block_size.auto_min_size and rank >= settings.lanczos_block_size.auto_min_rank) else 1
+        if n < settings.lanczos_block_size.auto_min_size or rank < settings.lanczos_block_size.auto_min_rank:
+            return 1
+        return 32 if n >= settings.lanczos_block_size.auto_wide_size else 8     # (round 6: <= 32 columns cost one generation-bound launch at large n)
     return max(1, min(int(v), rank))
 
 

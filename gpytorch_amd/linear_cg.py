@@ -99,7 +99,7 @@ class Preconditioner:
 
     def row_sharded(self, row_shard) -> "Preconditioner":
         """The same preconditioner acting on vectors of which every rank holds a block of rows: Q1 is sliced to the local
-        rows and the k x t inner products R Q1 are all-reduced per apply (k <= 128, t small: a few KB over xGMI)."""
+        rows and the k x t inner products R Q1 are all-reduced per apply (k <= 512, t small: a few KB over xGMI)."""
         di = None if self.dinv_sqrt is None else row_shard.local(self.dinv_sqrt.unsqueeze(0))[0]
         return Preconditioner(row_shard.local(self.q1t), self.sigma2, self.logdet, row_shard.local(self.lt), reduce=row_shard.allreduce, dinv_sqrt=di)
 
@@ -120,7 +120,7 @@ class Preconditioner:
     def _apply_core(self, rt: torch.Tensor, out: torch.Tensor):
         q1t = self.q1t if self.q1t.dtype == torch.float64 else self.q1t.to(torch.float64)
         k = q1t.shape[0]
-        fast = rt.dtype == torch.float32 and rt.is_cuda and k <= 128 and rt.stride(1) == 1 and q1t.stride(1) == 1
+        fast = rt.dtype == torch.float32 and rt.is_cuda and k <= 512 and rt.stride(1) == 1 and q1t.stride(1) == 1
         if fast:
             # W = R Q1^T: own mixed-precision reduction kernel (rocBLAS' float64 GEMM takes 80 ms for some tall-skinny shapes)
             t, n = rt.shape[0], min(rt.shape[1], q1t.shape[1])

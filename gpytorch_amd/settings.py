@@ -131,15 +131,16 @@ class max_lanczos_quadrature_iterations(_value_context):
 class max_preconditioner_size(_value_context):
     """Rank of the pivoted-Cholesky preconditioner (``linear_operator.settings.max_preconditioner_size``, re-exported at
     ``gpytorch/settings.py:6-31``; default 15 = the reference's).  ``"auto"`` (no counterpart in the reference) picks the rank from the
-    number of points: on MI355X the k pivot steps cost O(n k^2) memory traffic -- 42 ms at n = 500 000, k = 100 -- against O(n^2 t) per
-    mBCG iteration (91 ms there), and the iteration count falls steeply with the rank (metric shape, n = 500 000, RBF d = 3, ``cg_tolerance``
-    1: rank 0 / 15 / 50 / 100: 93 / 42 / 21 / 21 iterations, 8.7 / 3.9 / 2.0 / 2.0 s per MLL evaluation, y^T K^-1 y within 3e-2 / 1.9e-1 /
-    8e-2 / 1.3e-3 of the converged value; ``eval_cg_tolerance`` 1e-3: rank 100 / 128: 74 / 44 iterations --
-    ``profiles/r06_s1_mll_precond_timing_n500000.json``).  The rule keeps the build below roughly ten products of the solve it serves:
-    n >= 40 000 -> 128 (the widest factor ``gpamd_pivoted_cholesky_f32`` builds), n >= 6 000 -> 50, else the reference's 15; the
-    ``preconditioner_tolerance`` early stop applies as always, so a fast-decaying spectrum ends the factor earlier."""
+    number of points: on MI355X the k pivot steps cost O(n k^2) memory traffic -- 17 ms at n = 500 000, k = 100; 57 ms at k = 256 -- against
+    O(n^2 t) per mBCG iteration (91 ms there for 65 columns, 18.6 ms for one), and the iteration count falls steeply with the rank.  Metric shape
+    (n = 500 000, RBF d = 3; ``profiles/r06_s9_*``): MLL at ``cg_tolerance`` 1, rank 0 / 15 / 100 / 128: 94 / 42 / 21 / 21 iterations (21 = the floor
+    ``max_lanczos_quadrature_iterations`` sets), 8.6 / 4.0 / 2.08 / 2.10 s forward + backward, y^T K^-1 y within 3e-2 / 1.6e-1 / 1.3e-3 / 9e-5 of the
+    converged value; mean-cache solve at ``eval_cg_tolerance`` 1e-4, rank 100 / 128 / 192 / 256 / 384: 121 / 70 / 28 / 13 / 11 iterations, cold
+    posterior 3.1 / 2.1 / 1.35 / 1.29 / 1.33 s.  The rule keeps the build below a few products of the solve it serves: n >= 200 000 -> 256,
+    n >= 40 000 -> 128, n >= 6 000 -> 50, else the reference's 15; the ``preconditioner_tolerance`` early stop applies as always, so a fast-decaying
+    spectrum ends the factor earlier.  (Ranks up to 512 run on the fused kernels since round 6.)"""
     _global_value = 15
-    auto_ranks = ((40_000, 128), (6_000, 50), (0, 15))
+    auto_ranks = ((200_000, 256), (40_000, 128), (6_000, 50), (0, 15))
 
     @classmethod
     def resolve(cls, n: int) -> int:
@@ -175,10 +176,14 @@ class lanczos_block_size(_value_context):
     of a LOVE cache follows its rank, not the way its Krylov space was generated (``tests/test_block_lanczos_cpu.py``).
     "auto" (default): 8 from ``auto_min_size`` rows on (a product then fills the chip) when the rank is at least ``auto_min_rank`` (200: below it a
     block cache is measurably less accurate than the single-vector cache of the same rank -- 0.75 against 0.57 of the noise at rank 100 -- so the
-    reference-default rank 100 keeps the reference's recurrence; ``lanczos.block_size_for``), else 1."""
+    reference-default rank 100 keeps the reference's recurrence; ``lanczos.block_size_for``), else 1.  Round 6: 32 from ``auto_wide_size`` rows on --
+    there a product of up to 32 columns costs what one of 5 does (kernel generation bounds it: 45 ms at n = 500 000), so a rank-384 cache from 12
+    products of 32 columns beats a rank-400 cache from 25 of 16: cold posterior 0.85 against 1.29 s, variance error 3.9e-4 against 5.0e-4 of the noise
+    (``profiles/r06_s9_posterior_by_preconditioner_rank.json``)."""
     _global_value = "auto"
     auto_min_size = 16384
     auto_min_rank = 200
+    auto_wide_size = 262144
 
 
 class num_trace_samples(_value_context):

@@ -181,7 +181,7 @@ int gpamd_cg_finish_f32(gpamd_cg_t* h, void* stream);
 
 /* ---- pivoted Cholesky of the NOISE-FREE kernel matrix (LinearOperator.pivoted_cholesky; wrapper
  * gpytorch/__init__.py:146-173; consumer AddedDiagLinearOperator._preconditioner). L: float[rank][ldl]
- * (zero-filled by the caller), rank <= 512 (the preconditioner applies ranks <= 128 through its fused kernels); fwork: float[n + 4]; iwork: int[2 + 2n]; pivots: int64[rank].
+ * (zero-filled by the caller), rank <= 512; fwork: float[n + 4]; iwork: int[2 + 2n]; pivots: int64[rank].
  * Runs `rank` (pivot, update) steps without host synchronisation; steps after the error tolerance is
  * met are no-ops.  On completion iwork[0] = number of columns produced. ---- */
 int gpamd_pivoted_cholesky_f32(int kind, float kparam, const float* Xp, int n, int dp, const float* scale, int rank, float tol,
@@ -206,7 +206,7 @@ int gpamd_lanczos_coef_f32(const float* part, int k, int nb, float tol, float* c
 int gpamd_lanczos_subtract_f32(const float* Q, int64_t ldq, int k, const float* coef, float* r, int n, float* part_rr, void* stream);
 int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* out, float* norm_out, float tiny, int* stop, void* stream);
 
-/* ---- BLOCK Lanczos with full re-orthogonalisation: the vector work of one step for a block of b <= 16 probe-major rows R [b][ldr] against a basis
+/* ---- BLOCK Lanczos with full re-orthogonalisation: the vector work of one step for a block of b <= 32 probe-major rows R [b][ldr] against a basis
  * Q [k][ldq] of ANY length k (float32 vectors, float64 accumulation).  Behind LinearOperator.root_inv_decomposition (the LOVE covar_cache,
  * gpytorch/models/exact_prediction_strategies.py:267-272) and the multi-vector form of gpytorch.root_inv_decomposition (gpytorch/__init__.py:190-216): the b
  * vectors ride through ONE b-column gpamd_kv_partials_f32 per step instead of b single-column products.
@@ -231,7 +231,7 @@ int gpamd_msminres_update_f32(const float* v, const float* d1, float* d2, float*
                               void* stream);
 
 /* ---- pivoted-Cholesky preconditioner apply, first half:  W[c][m] = sum_i R[c][i] * Q1[m][i]  with R float32 [t][ldr] (the CG
- * residuals), Q1 float64 [k][ldq] (k <= 128), W float64 [t][k], float64 accumulation -- the k x t coefficients of
+ * residuals), Q1 float64 [k][ldq] (k <= 512), W float64 [t][k], float64 accumulation -- the k x t coefficients of
  * AddedDiagLinearOperator._preconditioner's closure  P^-1 R = (R - Q1 Q1^T R) / sigma^2, whose cancellation float32 cannot carry
  * (gpytorch_amd/linear_cg.py).  workspace: double[gpamd_precond_coef_workspace_doubles(n, t, k)]. ---- */
 int64_t gpamd_precond_coef_workspace_doubles(int n, int t, int k);

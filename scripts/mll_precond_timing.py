@@ -60,7 +60,7 @@ if what in ("mll", "both"):
     out["tight_reference"] = {"what": "rank-100 preconditioner, cg_tolerance 1e-3, 64 probes", "inv_quad": iq_ref, "logdet": ld_ref, "cg_iterations": it_ref, "seconds": sec_ref}
     print(out["tight_reference"], flush=True)
     rows = []
-    for rank in (0, 15, 50, 100, 128):   # (gpamd_pivoted_cholesky_f32: rank <= 128)
+    for rank in (0, 15, 100, 128, 256):   # (gpamd_pivoted_cholesky_f32 / the fused preconditioner apply: rank <= 512 since round 6)
         m.train(), lik.train()
         rec = {"max_preconditioner_size": rank}
         with S.max_cholesky_size(0), S.num_trace_samples(t_probes), S.max_preconditioner_size(rank):
@@ -120,8 +120,8 @@ if what in ("posterior", "both"):
     rows = []
     cases = [
         # (preconditioner rank, eval_cg_tolerance, LOVE rank, block)
-        (15, 1e-2, 100, 1), (100, 1e-2, 100, 1), (100, 1e-2, 400, 16), (100, 1e-3, 400, 16), (100, 1e-4, 400, 16),
-        (128, 1e-3, 400, 16), (128, 1e-3, 384, 32), (128, 1e-3, 256, 16), (128, 1e-3, 320, 16),
+        (15, 1e-2, 100, 1), (100, 1e-2, 100, 1), (100, 1e-4, 400, 16), (128, 1e-4, 400, 16),
+        (192, 1e-4, 400, 16), (256, 1e-4, 400, 16), (384, 1e-4, 400, 16), (256, 1e-3, 400, 16), (256, 1e-4, 384, 32),
     ]
     for rank, tol, love, blk in cases:
         best = None

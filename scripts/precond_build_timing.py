@@ -12,7 +12,7 @@ from gpytorch_amd.bbmm import build_preconditioner  # noqa: E402
 
 dev = torch.device("cuda:0")
 rows = []
-for n, d, kind, ls, ranks in ((500_000, 3, "rbf", 0.25, (15, 100, 128)), (36_584, 9, "rbf", 1.2, (15, 100)), (217_437, 3, "matern52", 0.2, (15, 100)), (2_000, 3, "rbf", 0.25, (15,))):
+for n, d, kind, ls, ranks in ((500_000, 3, "rbf", 0.25, (15, 100, 128, 256, 384)), (36_584, 9, "rbf", 1.2, (15, 100)), (217_437, 3, "matern52", 0.2, (15, 100)), (2_000, 3, "rbf", 0.25, (15,))):
     g = torch.Generator().manual_seed(0)
     X = torch.rand(n, d, generator=g).to(dev)
     xp = B.prep_points(kind, X, torch.tensor([ls], device=dev), X.mean(0))

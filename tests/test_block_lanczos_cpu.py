@@ -134,7 +134,9 @@ def test_love_variance_error_follows_the_rank_not_the_block_size():
 
 def test_block_size_setting():
     # (the reference-default rank 100 keeps the reference's single-vector recurrence: a block cache of that rank is 1.3-1.6 x less accurate)
-    assert LZ.block_size_for(500_000, 400) == 8 and LZ.block_size_for(500_000, 200) == 8 and LZ.block_size_for(500_000, 100) == 1
+    # (round 6: 32 rows per product from 262 144 points on -- up to 32 columns cost one generation-bound launch there)
+    assert LZ.block_size_for(500_000, 400) == 32 and LZ.block_size_for(500_000, 200) == 32 and LZ.block_size_for(500_000, 100) == 1
+    assert LZ.block_size_for(100_000, 400) == 8 and LZ.block_size_for(100_000, 200) == 8 and LZ.block_size_for(100_000, 100) == 1
     assert LZ.block_size_for(2000, 400) == 1 and LZ.block_size_for(500_000, 16) == 1
     with settings.lanczos_block_size(1):
         assert LZ.block_size_for(500_000, 400) == 1
