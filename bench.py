@@ -397,6 +397,7 @@ def main():
     ap.add_argument("--skip-parity", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="skip the untimed API-level MLL fwd+bwd / posterior timings")
+    ap.add_argument("--far-cutoff", type=float, default=None, help="--config road3d: run under settings.far_pair_cutoff(eps) (opt-in far-pair tile culling; default: every pair)")
     ap.add_argument("--grid", default=None, help="PxR (N = P * R ranks): two-dimensional split -- P probe shares x R row blocks "
                                                  "(bbmm.inv_quad_logdet_forward(group, row_group)).  Default for metric / c2 / c3 / c4: chosen by the cost model of "
                                                  "gpytorch_amd.distributed.choose_grid at the configuration's nominal size (metric on 8 GPUs: 1x8); c5 and "
@@ -412,7 +413,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import reference_workloads
 
-        return reference_workloads.main(args.config, gpus=args.gpus, size=args.size, steps=args.steps if "--steps" in sys.argv else None)
+        return reference_workloads.main(args.config, gpus=args.gpus, size=args.size, steps=args.steps if "--steps" in sys.argv else None,
+                                        far_eps=args.far_cutoff)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher (the shape of the N = 1 command): start the N ranks ourselves, exactly as the driver's
         # multi-GPU line does -- one process per GPU under torch.distributed.run on the loopback address; rank 0 prints the one JSON line

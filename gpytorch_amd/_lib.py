@@ -26,6 +26,8 @@ SIGNATURES = {
     "gpamd_prep_points_f32": (_i, [_i, _f, _p, _i, _i, _i64, _p, _i, _p, _p, _i, _p]),
     "gpamd_kv_plan": (_i, [_i, _i, _i, _i, _i, _i, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
     "gpamd_kv_partials_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _p]),
+    "gpamd_kv_partials_far_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _i64]),
+    "gpamd_kv_far_workspace_ints": (_i64, [_i, _i, _i]),
     "gpamd_kv_reduce_f32": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "gpamd_kv_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p]),
     "gpamd_kernel_rows_f32": (_i, [_i, _f, _p, _p, _i, _p, _i, _i, _p, _p, _i64, _p]),
@@ -118,7 +120,7 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if h.gpamd_abi_version() != 4:
+        if h.gpamd_abi_version() != 5:
             raise GpamdError("libgpamd.so ABI version mismatch")
         _lib = h
     return _lib

@@ -231,6 +231,18 @@ class SortedView:
         pad = nch * 128 - n
         xs_pad = torch.cat([self.xs, self.xs[-1:].expand(pad, -1)], 0) if pad else self.xs
         self.centers = xs_pad.reshape(nch, 128, dp).mean(1).contiguous()
+        # bounding sphere of every 128-row chunk about its centre (far-pair tile culling, settings.far_pair_cutoff): a hair of slack for the rounding
+        # of the norm, so that the sphere CONTAINS the chunk
+        self.radii = ((xs_pad.reshape(nch, 128, dp) - self.centers.unsqueeze(1)).pow(2).sum(-1).max(1).values.sqrt() * (1.0 + 1e-6) + 1e-30).contiguous()
+        self._perm_pad = None
+
+    @property
+    def perm_pad(self):
+        """[round_up(n, 4)] gather index that takes a probe-major row in the ORIGINAL order to the sorted order (padding: the last row again)."""
+        if self._perm_pad is None:
+            ld = self.inv_pad.numel()
+            self._perm_pad = torch.cat([self.perm, self.perm[-1:].expand(ld - self.perm.numel())]) if ld > self.perm.numel() else self.perm
+        return self._perm_pad
 
 
     @staticmethod
@@ -253,6 +265,59 @@ class SortedView:
             per_chunk.append((xc - cb.unsqueeze(1)).pow(2).sum(-1).max(1).values)          # [nch]
         worst = torch.maximum(per_chunk[0], torch.maximum(per_chunk[1], per_chunk[2]))
         return per_chunk[0], torch.nn.functional.pad(worst, (0, ng * 4 - nch)).reshape(ng, 4).max(1).values
+
+
+FAR_MIN_POINTS = 1024   # far-pair culling: smaller clouds are launch-bound, the two extra gathers per product would cost more than any tile saves
+
+
+def far_sq_cutoff(kind: str, eps: float, param=None) -> float:
+    """Squared distance in PREPARED coordinates (csrc/common.hpp: RBF k = 2^-s, Matern k = poly(r) e^-r with r = sqrt(s), RQ k = (1 + s)^-alpha)
+    at which the family's covariance falls to ``eps``: beyond it every entry of K is <= eps."""
+    if kind == "rbf":
+        return math.log2(1.0 / eps)
+    if kind == "rq":
+        return eps ** (-1.0 / float(param)) - 1.0
+    poly = {"matern12": lambda r: 1.0, "matern32": lambda r: 1.0 + r, "matern52": lambda r: 1.0 + r + r * r / 3.0}[kind]
+    lo, hi = 0.0, 200.0
+    for _ in range(80):                      # k is decreasing in r: bisection
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if poly(mid) * math.exp(-mid) > eps else (lo, mid)
+    return hi * hi
+
+
+def far_cull(x1: PreparedPoints, x2: PreparedPoints):
+    """The squared cutoff of a product k(x1, x2) V under ``settings.far_pair_cutoff``, or None when culling is off or cannot drop anything (small
+    clouds; a cloud narrower than the cutoff)."""
+    from . import settings
+
+    eps = settings.far_pair_cutoff.value()
+    if eps is None or FORCE_KV_FLAGS is not None or not (x1.fused and x2.fused) or min(x1.n, x2.n) < FAR_MIN_POINTS:
+        return None
+    sq = far_sq_cutoff(x1.kind, float(eps), x1.param)
+    z1 = x1.zmax2
+    z2 = x2.zmax2 if x2 is not x1 else z1
+    if not sq < (math.sqrt(z1) + math.sqrt(z2)) ** 2:
+        return None
+    return sq
+
+
+def far_kept_fraction(x1: PreparedPoints, x2: PreparedPoints, sq: float, bm: int = 512) -> float:
+    """Share of the (bm-row block, 128-point tile) pairs of k(x1, x2) that survive a squared cutoff ``sq`` -- the test of csrc/kv_cull.hpp
+    restated with torch on the sorted views (reporting only: scripts/far_cull_timing.py, the reference-workload record)."""
+    sv1, sv2 = x1.sorted_view(), x2.sorted_view()
+    m = bm // 128
+    nch = sv1.centers.shape[0]
+    nb = (nch + m - 1) // m
+    idx = (torch.arange(nb, device=sv1.centers.device).unsqueeze(1) * m + torch.arange(m, device=sv1.centers.device).unsqueeze(0)).clamp_max(nch - 1)
+    bc = sv1.centers[idx].mean(1)
+    br = ((sv1.centers[idx] - bc.unsqueeze(1)).norm(dim=-1) + sv1.radii[idx]).max(1).values
+    gap = torch.cdist(bc, sv2.centers) - br.unsqueeze(1) - sv2.radii.unsqueeze(0)
+    return float((~((gap > 0) & (gap * gap > sq))).float().mean().item())
+
+
+def rows_sorted(x1: PreparedPoints, x2: PreparedPoints, flags: int) -> bool:
+    """True when :func:`kv_partials_sorted` returns the output rows of k(x1, x2) V in x1's Hilbert order (the caller then un-sorts them)."""
+    return far_cull(x1, x2) is not None or gram_operands(x1, x2, flags)[2] is not None
 
 
 def kind_id(xp: PreparedPoints) -> int:
@@ -407,7 +472,31 @@ def gram_operands(x1: PreparedPoints, x2: PreparedPoints, flags: int):
     return x1.xp, None, None, x1.n, x1.n
 
 
-def _kv_region(x1, x2, X1, Xc, row0: int, n_r: int, flags_r: int, vt, t: int, P, ldo: int, S: int, jc: int, done_ptr, st, slot: int, what: str):
+_far_ws: dict = {}   # per device: the tile-list workspace of the far-pair launches (stream-ordered re-use, like the partial slabs)
+
+
+def _kv_launch(x1, x2, X1ptr, n_r: int, X2, Xcptr, vt, t: int, Pptr, ldo: int, S: int, jc: int, flags: int, done_ptr, st, cull, row0: int, what: str):
+    """One ``gpamd_kv_partials_f32`` launch group; with ``cull`` = (sq, sv1, sv2) the far-pair variant with the bounding spheres of the rows from
+    ``row0`` (a multiple of 128) on."""
+    L = lib()
+    if cull is None:
+        check(L.gpamd_kv_partials_f32(*kind_args(x1), X1ptr, n_r, _ptr(X2), x2.n, x1.d, Xcptr, _ptr(vt), vt.stride(0), t, Pptr, ldo, S, jc, flags,
+                                      done_ptr, st), what)
+        return
+    sq, sv1, sv2 = cull
+    assert row0 % 128 == 0
+    rc = C.c_void_p(sv1.centers.data_ptr() + 4 * x1.dp * (row0 // 128))
+    rr = C.c_void_p(sv1.radii.data_ptr() + 4 * (row0 // 128))
+    nws = int(L.gpamd_kv_far_workspace_ints(n_r, S, jc))
+    tws = _far_ws.get(vt.device)
+    if tws is None or tws.numel() < nws:
+        tws = _far_ws[vt.device] = torch.empty(max(nws, 1 << 18), device=vt.device, dtype=torch.int32)
+    check(L.gpamd_kv_partials_far_f32(*kind_args(x1), X1ptr, n_r, _ptr(X2), x2.n, x1.d, Xcptr, _ptr(vt), vt.stride(0), t, Pptr, ldo, S, jc, flags,
+                                      done_ptr, st, rc, rr, _ptr(sv2.centers), _ptr(sv2.radii), float(sq), _ptr(tws), tws.numel()), what)
+
+
+def _kv_region(x1, x2, X1, Xc, row0: int, n_r: int, flags_r: int, vt, t: int, P, ldo: int, S: int, jc: int, done_ptr, st, slot: int, what: str,
+               X2=None, cull=None):
     """Rows [row0, row0 + n_r) of a block-centred product (row0 a multiple of 512) on the kernels ``flags_r`` selects, into the shared slabs P.
     A region is a SMALLER product than the compact launch, possibly on another kernel: with that launch's split count it would leave most of the
     chip idle -- measured on the reference's own workloads (profiles/r05_s1_workload_*_kernel_stats.csv): 11.3 ms for 10 % of the rows against
@@ -416,17 +505,17 @@ def _kv_region(x1, x2, X1, Xc, row0: int, n_r: int, flags_r: int, vt, t: int, P,
     layout, the other slabs' rows are zeroed."""
     L = lib()
     assert row0 % 4 == 0
+    X2 = x2.xp if X2 is None else X2
     x1r = C.c_void_p(X1.data_ptr() + 4 * x1.dp * row0)
     xcr = C.c_void_p(Xc.data_ptr() + 4 * x1.dp * (row0 // 128)) if (Xc is not None and (flags_r & KV_GRAM)) else None
     ldr = round_up(n_r, 4)
     Sr, jcr, wsr = kv_plan(x1.kind, n_r, x2.n, x1.d, t, flags_r, ldr)
     if Sr == S and jcr == jc and not (flags_r & KV_SPLIT):
-        check(L.gpamd_kv_partials_f32(*kind_args(x1), x1r, n_r, _ptr(x2.xp), x2.n, x1.d, xcr, _ptr(vt), vt.stride(0), t,
-                                      C.c_void_p(P.data_ptr() + 4 * row0), ldo, S, jc, flags_r, done_ptr, st), f"kv_partials ({what})")
+        _kv_launch(x1, x2, x1r, n_r, X2, xcr, vt, t, C.c_void_p(P.data_ptr() + 4 * row0), ldo, S, jc, flags_r, done_ptr, st, cull, row0,
+                   f"kv_partials ({what})")
         return
     Pr = workspace(vt.device, wsr, slot=slot)
-    check(L.gpamd_kv_partials_f32(*kind_args(x1), x1r, n_r, _ptr(x2.xp), x2.n, x1.d, xcr, _ptr(vt), vt.stride(0), t, _ptr(Pr), ldr, Sr, jcr, flags_r,
-                                  done_ptr, st), f"kv_partials ({what})")
+    _kv_launch(x1, x2, x1r, n_r, X2, xcr, vt, t, _ptr(Pr), ldr, Sr, jcr, flags_r, done_ptr, st, cull, row0, f"kv_partials ({what})")
     check(L.gpamd_kv_reduce_f32(_ptr(Pr), Sr, ldr, t, n_r, None, None, None, None, 0, C.c_void_p(P.data_ptr() + 4 * row0), ldo, done_ptr, st),
           f"kv_reduce ({what})")
     if S > 1:
@@ -440,20 +529,25 @@ def kv_partials_sorted(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor,
     groups it does not serve fall to the direct-difference kernels inside the library); the rows of the WIDE groups on the direct-difference
     kernels -- further launches into the same slabs."""
     X1, Xc, unsort, n_c, n_b = gram_operands(x1, x2, flags)
-    L = lib()
+    X2, cull = x2.xp, None
+    sq = far_cull(x1, x2)
+    if sq is not None:
+        # far-pair tile culling (settings.far_pair_cutoff): BOTH clouds in Hilbert order -- the rows as in block-centred mode (whatever the
+        # generation mode: the cloud-centred expansion and the direct differences accept any row order), the contracted cloud and the columns of V
+        # through x2's own sorted view (one gather of t x m floats per product)
+        sv1, sv2 = x1.sorted_view(), x2.sorted_view()
+        if unsort is None:
+            X1, unsort = sv1.xs, sv1.inv_pad
+        X2 = sv2.xs
+        vt = vt.index_select(1, sv2.perm_pad)
+        cull = (sq, sv1, sv2)
     if n_c:
-        check(
-            L.gpamd_kv_partials_f32(
-                *kind_args(x1), _ptr(X1), n_c, _ptr(x2.xp), x2.n, x1.d, _ptr(Xc), _ptr(vt), vt.stride(0), t, _ptr(P), ldo, S, jc,
-                flags, done_ptr, st
-            ),
-            "kv_partials",
-        )
+        _kv_launch(x1, x2, _ptr(X1), n_c, X2, _ptr(Xc), vt, t, _ptr(P), ldo, S, jc, flags, done_ptr, st, cull, 0, "kv_partials")
     if n_b > n_c:
-        _kv_region(x1, x2, X1, Xc, n_c, n_b - n_c, flags | KV_BLOCK128, vt, t, P, ldo, S, jc, done_ptr, st, 1, "medium rows")
+        _kv_region(x1, x2, X1, Xc, n_c, n_b - n_c, flags | KV_BLOCK128, vt, t, P, ldo, S, jc, done_ptr, st, 1, "medium rows", X2, cull)
     if n_b < x1.n:
         wflags = KV_SPLIT if ((flags & KV_SPLIT) and x1.d <= DIRECT_SPLIT_MAX_DIM) else 0   # direct differences (+ the split contraction, kv_directh.hpp)
-        _kv_region(x1, x2, X1, None, n_b, x1.n - n_b, wflags, vt, t, P, ldo, S, jc, done_ptr, st, 2, "wide rows")
+        _kv_region(x1, x2, X1, None, n_b, x1.n - n_b, wflags, vt, t, P, ldo, S, jc, done_ptr, st, 2, "wide rows", X2, cull)
     return unsort
 
 

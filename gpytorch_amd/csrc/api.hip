@@ -11,6 +11,7 @@
 
 #include "cg_kernels.hpp"
 #include "kv_dispatch.hpp"
+#include "kv_cull.hpp"
 #include "kv_valu.hpp"
 #include "kv_gramv.hpp"
 #include "kv_gram4.hpp"
@@ -368,7 +369,24 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
 int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt,
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream) {
+  return gpamd_kv_partials_far_f32(kind, kparam, X1p, n, X2p, m, d, X1c, Vt, ldv, t, P, ldo, S, jchunk, flags, done, stream, nullptr, nullptr, nullptr,
+                                   nullptr, 0.f, nullptr, 0);
+}
+
+int64_t gpamd_kv_far_workspace_ints(int n, int S, int jchunk) {
+  if (n <= 0 || S <= 0 || jchunk <= 0) return 0;
+  return (int64_t)((n + 127) / 128) * S * (jchunk / 128 + 1);   // (the smallest row block of any kernel is 128 rows)
+}
+
+int gpamd_kv_partials_far_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt,
+                              int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done, void* stream,
+                              const float* row_centres, const float* row_radii, const float* tile_centres, const float* tile_radii, float sq_cutoff,
+                              int* tile_ws, int64_t tile_ws_ints) {
   if (kind < 0 || kind > GPAMD_RQ) return fail(GPAMD_EINVAL, "kv: unknown kind");
+  const bool cull = sq_cutoff > 0.f && row_centres && row_radii && tile_centres && tile_radii && tile_ws;
+  if (sq_cutoff > 0.f && !cull) return fail(GPAMD_EINVAL, "kv: far-pair culling needs all four bounding-sphere arrays and the tile-list workspace");
+  if (cull && (jchunk % 128 || S <= 0 || tile_ws_ints < gpamd_kv_far_workspace_ints(n, S, jchunk)))
+    return fail(GPAMD_EINVAL, "kv: far-pair culling needs jchunk % 128 == 0 (gpamd_kv_plan) and gpamd_kv_far_workspace_ints(n, S, jchunk) ints of workspace");
   if (n <= 0 || m <= 0 || t <= 0 || S <= 0) return fail(GPAMD_EINVAL, "kv: bad shape");
   if (d < 1 || d > KV_MAX_DIM) return fail(GPAMD_EUNSUPPORTED, "kv: input dimension must be in 1..32");
   // kernels are instantiated for D in {1,2,3,4,5,6,8,10,12,16,20,24,32} valid dimensions; other d use the next one
@@ -405,6 +423,16 @@ int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const
     a.done = done;
     a.kparam = kparam;
     a.Xc = X1c;
+    if (cull && v.split) {
+      // far-pair culling (split-operand kernels only, kv_mfma.hpp): this group's tile lists, built for ITS row block on the same stream
+      CullArgs c;
+      c.rc = row_centres; c.rr = row_radii; c.tc = tile_centres; c.tr = tile_radii;
+      c.tiles = tile_ws; c.tpc1 = jchunk / 128 + 1;
+      c.n = n; c.m = m; c.dp = (dk + 3) / 4 * 4; c.bm = v.bm; c.bn = v.bn; c.nrb = a.nrb; c.jchunk = jchunk;
+      c.sq_cut = sq_cutoff; c.done = done;
+      hipLaunchKernelGGL(cull_list_kernel, dim3((unsigned)a.nrb * (unsigned)S), dim3(64), 0, st, c);
+      a.tiles = tile_ws; a.tpc1 = c.tpc1;
+    }
     unsigned grid = (unsigned)a.nrb * (unsigned)S;
     const void* fn = family_ptr(kind, mode, dk, variant_key(v), v.ex, v.ni);
     if (!fn) return fail(GPAMD_EUNSUPPORTED, "kv: no kernel variant for this shape");

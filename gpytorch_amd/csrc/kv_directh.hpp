@@ -133,7 +133,9 @@ void kv_directh_kernel(KvhArgs ka) {
   };
 
   // prologue: x rows of the first tile, B operands of its first step
-  load_x(jbeg);
+  const int* tl = kv_tile_list(a, unit);   // far-pair tile culling (kv_mfma.hpp): the look-ahead staging takes the next SURVIVING tile; no list: every tile
+  const int jfirst = kv_tile_at<BN>(tl, jbeg, 0);
+  load_x(jfirst);
   store_x(0);
   __syncthreads();
   u32x4 bh[2], bl[2];
@@ -153,11 +155,12 @@ void kv_directh_kernel(KvhArgs ka) {
     }
   };
   int buf = 0;
-  for (int j0 = jbeg; j0 < jend; j0 += BN, buf ^= 1) {
+  for (int j0 = jfirst, jn, tk = 1; j0 < jend; j0 = jn, buf ^= 1, ++tk) {
+    jn = kv_tile_at<BN>(tl, jbeg, tk);
     __syncthreads();   // every wave is done with the V planes of the previous tile and with Xf[buf ^ 1]
     {
       load_v(j0);
-      load_x(j0 + BN);   // past the end of the chunk: zero rows (the last step's look-ahead generation must stay finite)
+      load_x(jn);        // past the end of the chunk: zero rows (the last step's look-ahead generation must stay finite)
       store_x(buf ^ 1);
 #pragma unroll
       for (int rr = 0; rr < VQ; ++rr) {

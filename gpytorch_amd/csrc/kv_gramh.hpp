@@ -256,8 +256,11 @@ void kv_gramh_kernel(KvhArgs ka) {
     }
   };
 
-  // prologue: x rows of the first tile, B operands of its first step
-  stage_x(jbeg, 0);
+  // prologue: x rows of the first tile, B operands of its first step.  (Far-pair culling, kv_mfma.hpp: the tile sequence comes from this unit's
+  // list -- the look-ahead staging below takes the NEXT SURVIVING tile; no list: jbeg, jbeg + BN, ...)
+  const int* tl = kv_tile_list(a, unit);
+  const int jfirst = kv_tile_at<BN>(tl, jbeg, 0);
+  stage_x(jfirst, 0);
   __syncthreads();
   u32x4 bh[2], bl[2];
   // LEAN (NI * CT > 4: four row tiles per wave and two column tiles, d <= 3): operands of a half are fetched just before its MFMAs
@@ -285,11 +288,12 @@ void kv_gramh_kernel(KvhArgs ka) {
     }
   };
   int buf = 0;
-  for (int j0 = jbeg; j0 < jend; j0 += BN, buf ^= 1) {
+  for (int j0 = jfirst, jn, tk = 1; j0 < jend; j0 = jn, buf ^= 1, ++tk) {
+    jn = kv_tile_at<BN>(tl, jbeg, tk);
     __syncthreads();   // every wave is done with the V planes of the previous tile and with Xh[buf ^ 1]
     {
       load_v(j0);
-      load_x(j0 + BN);   // past the end of the chunk: zero rows and a zero extra column (the last step's look-ahead generation
+      load_x(jn);        // past the end of the chunk: zero rows and a zero extra column (the last step's look-ahead generation
                          // must stay finite and add nothing to the extra column)
       store_x(buf ^ 1);
 #pragma unroll

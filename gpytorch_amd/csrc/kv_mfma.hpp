@@ -37,7 +37,23 @@ struct KvArgs {
   const int* done;     // optional device flag: non-zero -> the launch is a no-op (converged CG)
   float kparam;        // shape parameter of the covariance family (RQ: alpha); 0 otherwise
   const float* Xc = nullptr;   // Gram-form kernels: optional [ceil(n / 128)][DP] chunk centres of X1 (gram_f16.hpp) or nullptr
+  // Far-pair tile culling (opt-in, settings.far_pair_cutoff; off = the reference's arithmetic: every pair is evaluated).  tiles != nullptr: the
+  // workgroup of unit u = s * nrb + rb visits only the tiles listed in tiles[u * tpc1 ..] (tile starts j0, ascending, terminated by an entry
+  // >= jend) instead of jbeg, jbeg + BN, ...: cull_list_kernel (below) builds the lists from the bounding spheres of both clouds right before the
+  // product.  The tile loops carry ONE scalar pointer for it -- the sphere test itself lives in the list kernel: held in the product kernels it
+  // cost the split kernels 8-16 VGPRs (spills at two waves per SIMD) and the few-column kernels a resident wave, culling or not.
+  // Read by the split-operand kernels only (kv_gramh.hpp, kv_directh.hpp: >= 5 columns on the library's default contraction): their look-ahead
+  // staging already asks "which tile next".  The fp32-MFMA kernels and the few-column kernels visit every tile whatever is passed here -- reading
+  // j0 from a list broke the strength reduction of kv_gram's staging addresses (300 bytes of scratch per lane at three waves per SIMD), and any
+  // edit of kv_gramv's loop moved the allocator's occupancy choice for a dozen instantiations (3 -> 1 waves at Matern-5/2 d = 10, four columns).
+  const int* tiles = nullptr;
+  int tpc1 = 0;                // entries per unit: tiles per j chunk + 1 (the terminator)
 };
+
+// start of the k-th tile a workgroup visits (tl: its list or nullptr = every tile of the chunk)
+template <int BN>
+__device__ __forceinline__ int kv_tile_at(const int* tl, int jbeg, int k) { return tl ? tl[k] : jbeg + k * BN; }
+__device__ __forceinline__ const int* kv_tile_list(const KvArgs& a, int unit) { return a.tiles ? a.tiles + (int64_t)unit * a.tpc1 : nullptr; }
 
 constexpr int KV_BN = 128;           // j-tile staged in LDS per iteration
 constexpr int KV_LDT = KV_BN + 4;    // padded LDS row (keeps 16-B alignment, conflict-free b128 reads)

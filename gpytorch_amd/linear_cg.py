@@ -278,7 +278,7 @@ def linear_cg(
             flags = B.kv_flags(x, x, t)
             S, jc, wsn = B.kv_plan(x.kind, n, n, x.d, t, flags, ld)
             P = B.workspace(dev, wsn)
-            if B.gram_operands(x, x, flags)[2] is not None:
+            if B.rows_sorted(x, x, flags):
                 Psum = torch.zeros(t, ld, device=dev, dtype=torch.float32)
                 Pq1 = torch.zeros(t, ld, device=dev, dtype=torch.float32)
         ldp = ld

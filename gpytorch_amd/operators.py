@@ -1074,7 +1074,7 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         else:
             steps = lanczos_steps(n, dev, rank, generator=gen)
         flags = B.kv_flags(p1, p1, 1 + nb)
-        sorted_rows = B.gram_operands(p1, p1, flags)[2] is not None
+        sorted_rows = B.rows_sorted(p1, p1, flags)
         S, jc, wsn = B.kv_plan(p1.kind, n, n, p1.d, 1 + nb, flags, ld)
         P = B.workspace(dev, wsn)
         W = torch.zeros(1 + nb, ld, device=dev, dtype=torch.float32)

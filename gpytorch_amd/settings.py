@@ -374,6 +374,26 @@ class split_contraction(_feature_flag):
     _default = _os.environ.get("GPAMD_KV_SPLIT", "1") not in ("0", "")
 
 
+class far_pair_cutoff(_value_context):
+    """Opt-in far-pair TILE CULLING of the fused float32 kernel products (default ``None`` = off: every pair is evaluated, the reference's
+    arithmetic -- its KeOps seam reduces over all j, ``gpytorch/kernels/keops/rbf_kernel.py:44-55``).
+
+    ``far_pair_cutoff(eps)``: with both clouds in Hilbert order, a 128-point tile of the contracted cloud is skipped for a block of output rows when
+    the bounding spheres of the two are so far apart that EVERY covariance between them is <= ``eps`` (before the outputscale): it is neither loaded
+    nor generated.  Every dropped entry of K is <= eps, so  |(K V)_ic - culled| <= eps * sum_j |V_jc|  per output entry -- with eps = 1e-7 below
+    the float32 rounding of the entries that are kept.  Applies where the cloud is many lengthscales wide (block-centred Gram mode or the
+    direct-difference kernels: short lengthscales, e.g. the first iterations of the reference's 3droad notebook at lengthscale 0.05,
+    ``examples/02_Scalable_Exact_GPs/KeOps_GP_Regression.ipynb``); compact clouds and the heavy-tailed RQ family are not affected (nothing is far).
+    The forward products (mBCG, posterior caches, matmul) are culled; the backward's bilinear derivative still visits every tile."""
+
+    _global_value = None
+
+    def __init__(self, value):
+        if value is not None and not (0.0 < float(value) < 1.0):
+            raise ValueError("far_pair_cutoff: eps must lie in (0, 1), or None to switch culling off")
+        super().__init__(value)
+
+
 class fast_computations:
     """``linear_operator.settings.fast_computations``: three independent flags."""
 

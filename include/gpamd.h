@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GPAMD_ABI_VERSION 4
+#define GPAMD_ABI_VERSION 5
 
 /* covariance families: gpytorch/kernels/rbf_kernel.py:68-85, matern_kernel.py:85-110 (nu = 1/2, 3/2, 5/2) */
 enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3,
@@ -34,7 +34,8 @@ enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3
  * every entry point that evaluates the covariance or prepares points for it (ABI version 2: the library holds no per-thread kernel
  * state, so operators with different alpha may interleave freely on one thread -- AdditiveKernel(RQ, RQ)).  ABI version 3: the
  * float64 / generic entry points take it too (`double kparam`), so the family runs on every path.  ABI version 4 (additive): the block-Lanczos
- * vector entry points gpamd_block_{project,subtract,transform}_f32, and fused float32 kernels for input dimensions up to 32 (was 16). */
+ * vector entry points gpamd_block_{project,subtract,transform}_f32, and fused float32 kernels for input dimensions up to 32 (was 16).
+ * ABI version 5 (additive): gpamd_kv_partials_far_f32 / gpamd_kv_far_workspace_ints -- the same product with far-pair tile culling. */
 
 enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 
@@ -91,6 +92,29 @@ int gpamd_kv_plan(int kind, int n, int m, int d, int t, int flags, int64_t ldo, 
 int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt,
                           int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done,
                           void* stream);
+
+/* The same product with FAR-PAIR TILE CULLING (opt-in; the reference evaluates every pair -- gpytorch/kernels/keops/rbf_kernel.py:44-55 leaves the
+ * reduction over all j to KeOps -- and so does gpamd_kv_partials_f32).  For kernels whose mass sits within a few lengthscales (short lengthscales on
+ * a wide cloud: the reference's 3droad workload starts at lengthscale 0.05 on z-scored inputs, examples/02_Scalable_Exact_GPs/KeOps_GP_Regression.ipynb)
+ * most 128-point tiles of the contracted cloud hold no covariance above f32 resolution for a given block of output rows.  The caller orders BOTH
+ * clouds along a space-filling curve (rows of X1p and of X2p, with Vt's columns in X2p's order) and passes bounding spheres:
+ *   row_centres  float[ceil(n / 128)][dp], row_radii float[ceil(n / 128)]:  every 128-row aligned chunk of X1p lies within row_radii[q] of row_centres[q];
+ *   tile_centres float[ceil(m / 128)][dp], tile_radii float[ceil(m / 128)]: the same for the 128-point aligned tiles of X2p;
+ *   sq_cutoff: a squared distance in PREPARED coordinates (gpamd_prep_points_f32) beyond which the caller accepts k = 0.
+ * A workgroup (128 .. 512 output rows: the union of its chunks' spheres) skips every tile of its j chunk whose sphere is farther than sqrt(sq_cutoff)
+ * from its own; a skipped tile is neither loaded nor generated.  With sq_cutoff = s(eps), the squared distance at which the family's k falls to
+ * eps, every dropped entry of K is <= eps, i.e. |(K V)_ic - culled| <= eps * sum_j |V_jc|.  sq_cutoff <= 0: exactly gpamd_kv_partials_f32 (the
+ * other far arguments are ignored).  jchunk must be a multiple of 128 (gpamd_kv_plan's always is).  The spheres are taken on trust like the
+ * GPAMD_KV_GRAM preconditions.  A small kernel builds, per column group, the list of surviving tiles of every (row block, j chunk) unit into
+ * tile_workspace on the same stream; the product kernels walk the list.  Culled: the column groups that run on the split-operand kernels
+ * (GPAMD_KV_SPLIT, >= 5 columns: kv_gramh.hpp, kv_directh.hpp -- the library's default contraction); every other group (fp32-MFMA contraction,
+ * fewer than five columns) evaluates every tile whatever is passed here -- exact, only not faster.  All other arguments as gpamd_kv_partials_f32. */
+int gpamd_kv_partials_far_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt,
+                              int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done, void* stream,
+                              const float* row_centres, const float* row_radii, const float* tile_centres, const float* tile_radii, float sq_cutoff,
+                              int* tile_workspace, int64_t tile_workspace_ints);
+/* ints of tile_workspace for a launch plan (S, jchunk) over n output rows: one list of (jchunk / 128 + 1) tile starts per (row block, j chunk). */
+int64_t gpamd_kv_far_workspace_ints(int n, int S, int jchunk);
 
 /* Out = scale * sum_s P[s] + (dscale + dvec) .* Vd  (scale/dscale device scalars, NULL = 1 / 0; dvec: optional
  * float[n] diagonal; Vd may be NULL): ScaleKernel.forward (gpytorch/kernels/scale_kernel.py:117-118) and the

@@ -93,7 +93,10 @@ def _path(m, lik):
     return {0: "direct-difference kernels (outside the Gram-form policy)", 1: "Gram form, cloud-centred", 2: "Gram form, block-centred"}[mode], float(p1.zmax2), wide
 
 
-def road3d(dev, n=217_437, n_test=None, iters=25, seed=0):
+def road3d(dev, n=217_437, n_test=None, iters=25, seed=0, far_eps=None):
+    """far_eps: settings.far_pair_cutoff for the whole run (None = the library default: every pair)."""
+    import contextlib
+
     import gpytorch_amd as g
 
     n_test = n if n_test is None else n_test
@@ -107,8 +110,8 @@ def road3d(dev, n=217_437, n_test=None, iters=25, seed=0):
     mll = g.ExactMarginalLogLikelihood(lik, m)
     from gpytorch_amd import linear_cg as LCG
 
-    secs, losses, cg_its, paths = [], [], [], []
-    with warnings.catch_warnings():
+    secs, losses, cg_its, paths, ls_hist = [], [], [], [], []
+    with warnings.catch_warnings(), (g.settings.far_pair_cutoff(far_eps) if far_eps else contextlib.nullcontext()):
         warnings.simplefilter("ignore")
         for i in range(iters):
             if i in (0, iters - 1):
@@ -125,6 +128,7 @@ def road3d(dev, n=217_437, n_test=None, iters=25, seed=0):
             secs.append(time.perf_counter() - t0)
             losses.append(float(loss.detach()))
             cg_its.append(it)
+            ls_hist.append(float(m.covar_module.base_kernel.lengthscale.detach().reshape(-1)[0]))
         m.eval()
         lik.eval()
         torch.cuda.synchronize(dev)
@@ -143,6 +147,7 @@ def road3d(dev, n=217_437, n_test=None, iters=25, seed=0):
         "kernel_path_first_last": [p[0] for p in paths], "max_sq_scaled_radius_first_last": [p[1] for p in paths], "wide_rows_first_last": [p[2] for p in paths],
         "hyper": {"lengthscale": float(m.covar_module.base_kernel.lengthscale.detach().reshape(-1)[0]), "outputscale": float(m.covar_module.outputscale.detach()),
                   "noise": float(lik.noise.detach().reshape(-1)[0])},
+        "far_pair_cutoff": far_eps, "lengthscale_per_iteration": ls_hist,
         "prediction_seconds_cold_caches": pred_s, "test_rmse": rmse, "variance_min": float(var.min()),
         "reference": "notebook: 'a matter of minutes' for 25 iterations on one GPU (KeOps), RMSE 0.138 on the real data",
     }
@@ -204,13 +209,13 @@ def protein(dev, n=36_584, n_test=9_146, d=9, lbfgs_iters=5, seed=0):
     }
 
 
-def main(config, gpus=1, size=None, steps=None):
+def main(config, gpus=1, size=None, steps=None, far_eps=None):
     assert gpus == 1, "the reference workloads are single-process runs (probe sharding of the training MLL: settings.sharding)"
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     if config == "road3d":
         kw = {} if size is None else {"n": size, "n_test": size}
-        rec = road3d(dev, iters=steps or 25, **kw)
+        rec = road3d(dev, iters=steps or 25, far_eps=far_eps, **kw)
         value, metric = rec["seconds_per_iteration_median"], "road3d_training_iteration_seconds"
     else:
         kw = {} if size is None else {"n": size, "n_test": max(2, size // 4)}

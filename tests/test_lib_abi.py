@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
     for name in declared:
         assert hasattr(h, name), f"{name} declared in gpamd.h but not exported"
     assert sorted(SIGNATURES) == declared, "ctypes table and gpamd.h disagree"
-    assert h.gpamd_abi_version() == 4
+    assert h.gpamd_abi_version() == 5
 
 
 def test_library_exports_nothing_beyond_the_header():
@@ -81,6 +81,10 @@ def test_argument_validation_without_gpu():
     # split-operand contraction: the j chunk must be the plan's (a multiple of the 128-row LDS tile) -- refused before any launch
     rc = h.gpamd_kv_partials_f32(0, 0.0, None, 1000, None, 1000, 3, None, None, 1000, 11, None, 1000, 1, 1004, 1 | 8, None, None)
     assert rc == -1 and b"jchunk % 128" in h.gpamd_last_error()
+    # far-pair culling (ABI version 5): a cutoff without the spheres / the tile-list workspace is refused before any launch; the workspace bound
+    rc = h.gpamd_kv_partials_far_f32(0, 0.0, None, 1000, None, 1000, 3, None, None, 1000, 11, None, 1000, 1, 1024, 1 | 8, None, None, None, None, None, None, 23.0, None, 0)
+    assert rc == -1 and b"bounding-sphere" in h.gpamd_last_error()
+    assert h.gpamd_kv_far_workspace_ints(1000, 3, 1024) == 8 * 3 * 9 and h.gpamd_kv_far_workspace_ints(0, 1, 128) == 0
     # batched small-member entry points: shapes and the RQ shape-parameter array are checked before any launch
     assert h.gpamd_kernel_dense_batched_f32(0, None, None, 0, None, 5, 4, 2, None, None, None, 8, None) == -1
     assert h.gpamd_kernel_dense_batched_f32(4, None, None, 5, None, 5, 4, 2, None, None, None, 8, None) == -1 and b"kparam" in h.gpamd_last_error()
@@ -126,6 +130,33 @@ def test_settings_contexts():
         assert settings.fast_computations.log_prob.off() and settings.fast_computations.solves.on()
     assert settings.fast_computations.log_prob.on()
     assert settings.min_variance.value(torch.float32) == 1e-6
+
+
+def test_far_pair_cutoff_setting_and_distance():
+    """settings.far_pair_cutoff: off by default (the reference's arithmetic), validated; backend.far_sq_cutoff inverts each family's profile in the
+    PREPARED coordinates of csrc/common.hpp (RBF k = 2^-s, Matern k = poly(r) e^-r with r = sqrt(s), RQ k = (1 + s)^-alpha)."""
+    import math
+
+    import pytest
+
+    from gpytorch_amd import backend as B
+    from gpytorch_amd import settings
+
+    assert settings.far_pair_cutoff.value() is None
+    with settings.far_pair_cutoff(1e-7):
+        assert settings.far_pair_cutoff.value() == 1e-7
+    assert settings.far_pair_cutoff.value() is None
+    for bad in (0.0, 1.0, -1e-3, 2.0):
+        with pytest.raises(ValueError):
+            settings.far_pair_cutoff(bad)
+    for eps in (1e-2, 1e-5, 1e-7):
+        assert abs(2.0 ** -B.far_sq_cutoff("rbf", eps) - eps) < 1e-12 * eps + 1e-18
+        assert abs((1.0 + B.far_sq_cutoff("rq", eps, 1.3)) ** -1.3 - eps) < 1e-9 * eps
+        for kind, poly in (("matern12", lambda r: 1.0), ("matern32", lambda r: 1.0 + r), ("matern52", lambda r: 1.0 + r + r * r / 3.0)):
+            r = math.sqrt(B.far_sq_cutoff(kind, eps))
+            assert abs(poly(r) * math.exp(-r) - eps) < 1e-6 * eps and poly(r * 1.001) * math.exp(-r * 1.001) < eps
+    # longer tails need larger cutoffs
+    assert B.far_sq_cutoff("matern12", 1e-7) < B.far_sq_cutoff("matern32", 1e-7) < B.far_sq_cutoff("matern52", 1e-7)
 
 
 def test_product_never_imports_oracle():
