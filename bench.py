@@ -393,7 +393,7 @@ def main():
                          "split = hi/lo-split operands on the f16 matrix pipe (the library default, settings.split_contraction). "
                          "The other one is measured once, untimed, and reported beside it (block 'split_contraction').")
     ap.add_argument("--skip-split", action="store_true", help="skip the steps on the other contraction path")
-    ap.add_argument("--other-steps", type=int, default=5, help="steps timed on the other contraction path (reported beside the headline, with spread and the sustained clock)")
+    ap.add_argument("--other-steps", type=int, default=3, help="steps timed on the other contraction path (reported beside the headline, with spread and the sustained clock)")
     ap.add_argument("--skip-parity", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="skip the untimed API-level MLL fwd+bwd / posterior timings")

@@ -76,7 +76,7 @@ struct KvVariant {
   bool split;  // kv_gramh: contraction of hi/lo-split operands on the f16 matrix pipe (ct, ex as for mfma)
   int ni;      // kv_gramh: 32-row tiles per wave
   bool gram;   // the selected kernel forms the squared distances by the quadratic expansion (false: direct differences)
-  bool direct; // with split: kv_directh (direct differences + split contraction; one column tile, no extra column)
+  bool direct; // with split: kv_directh (direct differences + split contraction; ct, ex as for mfma, ct <= 2)
   int bm;      // rows per workgroup
   int bn;      // j tile
 };
@@ -109,14 +109,14 @@ KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool
     v.ni = small ? 1 : kgh_ni(v.ct, (v.ex && !light && dk <= 16) ? 16 : dk);
     v.bm = kgh_bm(v.ni);
     v.bn = KGH_BN;
-  } else if (!gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KDH_COLS && dk <= KDH_MAX_DIM) {
+  } else if (!gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KDH_COLS + 1 && dk <= KDH_MAX_DIM) {
     // direct differences (clouds / rows outside the policy of the quadratic expansion, Matern nu = 1/2) with the contraction on the f16 matrix pipe
     // (kv_directh.hpp): the VALU keeps the generation only -- 9.8 instead of ~17 VALU instructions per pair at d = 3, eleven columns
     v.split = true;
     v.direct = true;
-    v.ct = 1;
-    v.ex = 0;
-    v.ni = kdh_ni(small);
+    v.ex = (t % 32 == 1) ? 1 : 0;
+    v.ct = (t - v.ex + 31) / 32;
+    v.ni = kdh_ni(small, v.ct, dk);
     v.bm = kdh_bm(v.ni);
     v.bn = KGH_BN;
   } else if (gram && !wide && t >= 5 && t <= 24 && dk <= 16) {   // (beyond 16 dimensions: no 4-column / 16-column tile kernels -- kv_gramv up to 16 columns, the 32-column tile above)
@@ -161,7 +161,7 @@ bool dsplit_on(int kind, int flags, int d) { return !gram_ok(kind, flags) && (fl
 // split [0, t) into launch groups of <= cap (+1) columns: cap = 128, or 64 for the split-operand kernels
 int group_cols(int t, int g0, int cap = KV_GROUP) {
   int rem = t - g0;
-  if (rem <= cap + (cap == KDH_COLS ? 0 : 1)) return rem;  // includes the cap + EX case (the direct-difference split kernel has no extra column)
+  if (rem <= cap + 1) return rem;  // includes the cap + EX case
   return cap;
 }
 int group_cap(int kind, int flags, int d) { return split_on(kind, flags) ? KGH_GROUP : (dsplit_on(kind, flags, d) ? KDH_COLS : KV_GROUP); }
@@ -210,11 +210,11 @@ const void* family_ptr(int kind, int mode, int d, int v, int ex, int ni = 0) {
   }
   if (mode == KV_MODE_DIRECTH) {
     switch (kind) {
-      case GPAMD_RBF: return kvd_kernel_ptr_rbf(d, ni);
-      case GPAMD_MATERN12: return kvd_kernel_ptr_matern12(d, ni);
-      case GPAMD_MATERN32: return kvd_kernel_ptr_matern32(d, ni);
-      case GPAMD_MATERN52: return kvd_kernel_ptr_matern52(d, ni);
-      case GPAMD_RQ: return kvd_kernel_ptr_rq(d, ni);
+      case GPAMD_RBF: return kvd_kernel_ptr_rbf(d, ni, v, ex);
+      case GPAMD_MATERN12: return kvd_kernel_ptr_matern12(d, ni, v, ex);
+      case GPAMD_MATERN32: return kvd_kernel_ptr_matern32(d, ni, v, ex);
+      case GPAMD_MATERN52: return kvd_kernel_ptr_matern52(d, ni, v, ex);
+      case GPAMD_RQ: return kvd_kernel_ptr_rq(d, ni, v, ex);
     }
     return nullptr;
   }

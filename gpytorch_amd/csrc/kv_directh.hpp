@@ -15,7 +15,8 @@
 // are staged TRANSPOSED in LDS (Xf[k][j], float), so that one ds_read_b128 per dimension returns the four CONSECUTIVE rows j(4 q .. 4 q + 3, h)
 // of a quad -- adjacent register pairs = the two operands of v_pk_add_f32 / v_pk_fma_f32 -- and all lanes of a half-wave read the same address
 // (broadcast, conflict-free).  Per pair of elements: D packed subtractions + D packed multiply-adds, then cov_pair_from_sq and the split as in
-// kv_gramh.hpp.  One column tile (<= 32 columns per launch group; wider products go in groups), no extra column.
+// kv_gramh.hpp.  One or two 32-column tiles + an optional extra column on the VALU (round 6: K is generated ONCE for up to 65 columns; until then
+// 33-65 columns went in groups of 32 and regenerated K for each).
 //
 // Software pipeline: as kv_gramh.hpp -- the B operands of step s + 1 are generated between the MFMAs of step s (sched_barrier-pinned slices); the
 // x_j rows are staged one tile ahead (double-buffered), the V planes per tile.  The loop is VALU-bound (D = 3 Matern-5/2: ~110 VALU instructions
@@ -26,21 +27,24 @@
 namespace gpamd {
 
 constexpr int KDH_MAX_DIM = 10;   // instantiated for D in {1,2,3,4,5,6,8,10}: beyond, the per-half x_j registers (8 D) no longer fit next to the operands
-constexpr int KDH_COLS = 32;      // columns per launch group
-constexpr int kdh_ni(bool small) { return small ? 1 : 2; }
+constexpr int KDH_COLS = 64;      // columns per launch group (+ 1 extra VALU column): one or two 32-column tiles, K generated ONCE for all of them
+// 32-row tiles per wave: two, or one for few output rows -- and with TWO column tiles beyond four dimensions, where 64 accumulators next to the
+// 8 D per-half x_j registers of two row tiles would not fit two waves per SIMD
+constexpr int kdh_ni(bool small, int ct = 1, int dk = 1) { return (small || (ct == 2 && dk > 4)) ? 1 : 2; }
 inline int kdh_bm(int ni) { return 4 * ni * 32; }
 
-template <int KIND, int D, int NI>
+template <int KIND, int D, int NI, int CT = 1, int EX = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void kv_directh_kernel(KvhArgs ka) {
   constexpr int NW = 4, NT = 64 * NW;
   const KvArgs& a = ka.a;
   constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
-  constexpr int BN = KGH_BN, LDH = KGH_LDH, TC = 32;
+  constexpr int BN = KGH_BN, LDH = KGH_LDH, TC = 32 * CT;
   constexpr int XFS = D * BN;   // floats of one x_j buffer
   __shared__ __attribute__((aligned(16))) _Float16 Vhs[TC * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 Vls[TC * LDH];
   __shared__ __attribute__((aligned(16))) float Xf[2 * XFS];   // [buf][k][j]
+  __shared__ __attribute__((aligned(16))) float Es[EX ? 2 * BN : 4];   // [buf][j] extra column (f32, carried on the VALU as in kv_gramh.hpp)
 
   if (a.done && *a.done) return;
   float negone;   // -1.0f the optimiser cannot see through (gen_b, kv_gramh.hpp)
@@ -66,16 +70,22 @@ void kv_directh_kernel(KvhArgs ka) {
     }
   }
 
-  f32x16 acc[NI];
+  f32x16 acc[NI][CT];
+  f32x2 eacc2[NI];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
+  for (int ni = 0; ni < NI; ++ni) {
+    eacc2[ni] = (f32x2)(0.f);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][ct][r] = 0.f;
+  }
 
-  constexpr int VQ = TC * (BN / 8) / NT;   // 16-byte chunks per thread and plane (= 2)
+  constexpr int VQ = TC * (BN / 8) / NT;   // 16-byte chunks per thread and plane (= 2 CT)
 
   // x_j rows of the tile starting at j0 -> buffer `buf`, transposed (rows beyond jend: zero -> a finite k against V = 0)
   float xz[DP];
+  f32x4 xe = {0.f, 0.f, 0.f, 0.f};
   auto load_x = [&](int j0) {
     if (tid < BN) {
       const int j = j0 + tid;
@@ -86,11 +96,36 @@ void kv_directh_kernel(KvhArgs ka) {
         xz[4 * q + 0] = v[0]; xz[4 * q + 1] = v[1]; xz[4 * q + 2] = v[2]; xz[4 * q + 3] = v[3];
       }
     }
+    if constexpr (EX) {
+      if (tid >= BN && tid < BN + BN / 4) {
+        const int j = j0 + 4 * (tid - BN);
+        const float* src = a.Vt + (int64_t)TC * a.ldv + j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j + 4 <= jend) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j + e < jend) v[e] = src[e];
+        }
+        xe = v;
+      }
+    }
   };
   auto store_x = [&](int buf) {
     if (tid < BN) {
 #pragma unroll
       for (int k = 0; k < D; ++k) Xf[buf * XFS + k * BN + tid] = xz[k];
+    }
+    if constexpr (EX) {
+      if (tid >= BN && tid < BN + BN / 4) *reinterpret_cast<f32x4*>(&Es[buf * BN + 4 * (tid - BN)]) = xe;
+    }
+  };
+  // extra column: the rows of half mf of block jb this lane pairs with -- ev[q] = rows jb + 16 mf + 8 q + 4 h .. + 3 (the quads of load_zq)
+  auto load_ev = [&](int buf, int jb, int mf, f32x4* ev) {
+    if constexpr (EX) {
+      ev[0] = *reinterpret_cast<const f32x4*>(&Es[buf * BN + jb + 16 * mf + 4 * h]);
+      ev[1] = *reinterpret_cast<const f32x4*>(&Es[buf * BN + jb + 16 * mf + 8 + 4 * h]);
     }
   };
 
@@ -103,7 +138,7 @@ void kv_directh_kernel(KvhArgs ka) {
   };
   // Generation of elements r = 8 mf + 2 p, + 1 in two halves (kv_gramh.hpp):  gen_a: squared distances of the pair (2 D packed instructions), K = f(S)
   // for both, packed hi word;  gen_b: lo = K - hi, packed lo word
-  auto gen_a = [&](const f32x4 (*zq)[D], int p, int ni, f32x2& kv, u32x4& bh) {
+  auto gen_a = [&](const f32x4 (*zq)[D], const f32x4* ev, int p, int ni, f32x2& kv, u32x4& bh) {
     const int q = p >> 1, e0 = 2 * (p & 1);
     f32x2 s2 = {0.f, 0.f};
 #pragma unroll
@@ -112,6 +147,7 @@ void kv_directh_kernel(KvhArgs ka) {
       s2 = __builtin_elementwise_fma(df, df, s2);
     }
     kv = cov_pair_from_sq<KIND>(s2, a.kparam, (float)KGH_KSHIFT);
+    if constexpr (EX) eacc2[ni] = __builtin_elementwise_fma(kv, (f32x2){ev[q][e0], ev[q][e0 + 1]}, eacc2[ni]);
     bh[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(kv[0], kv[1]));
   };
   auto gen_b = [&](const f32x2& kv, int p, uint32_t hiw, u32x4& bl) {
@@ -122,12 +158,13 @@ void kv_directh_kernel(KvhArgs ka) {
     bl[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(l0, l1));
   };
   auto gen_half = [&](int buf, int jb, int mf, int ni, u32x4& bh, u32x4& bl) {
-    f32x4 zq[2][D];
+    f32x4 zq[2][D], ev[2];
     load_zq(buf, jb, mf, zq);
+    load_ev(buf, jb, mf, ev);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       f32x2 kv;
-      gen_a(zq, p, ni, kv, bh);
+      gen_a(zq, ev, p, ni, kv, bh);
       gen_b(kv, p, bh[p], bl);
     }
   };
@@ -172,19 +209,21 @@ void kv_directh_kernel(KvhArgs ka) {
     }
     __syncthreads();
 
-    auto load_a = [&](int jb, f16x8* ah, f16x8* al) {
+    auto load_a = [&](int jb, f16x8 (*ah)[CT], f16x8 (*al)[CT]) {
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) {
-        const int o = l31 * LDH + jb + 16 * mf + 8 * h;
-        ah[mf] = *reinterpret_cast<const f16x8*>(&Vhs[o]);
-        al[mf] = *reinterpret_cast<const f16x8*>(&Vls[o]);
-      }
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int o = (ct * 32 + l31) * LDH + jb + 16 * mf + 8 * h;
+          ah[mf][ct] = *reinterpret_cast<const f16x8*>(&Vhs[o]);
+          al[mf][ct] = *reinterpret_cast<const f16x8*>(&Vls[o]);
+        }
     };
-    f16x8 ah[2], al[2];
+    f16x8 ah[2][CT], al[2][CT];
     load_a(0, ah, al);
 #pragma unroll 2
     for (int jb = 0; jb < BN; jb += 32) {
-      f16x8 ahn[2], aln[2];
+      f16x8 ahn[2][CT], aln[2][CT];
       load_a((jb + 32) & (BN - 1), ahn, aln);   // unconditional (after the last block: a harmless re-read of block 0), the loop body stays branch-free
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -200,18 +239,22 @@ void kv_directh_kernel(KvhArgs ka) {
         for (int mf = 0; mf < 2; ++mf) {
           const f16x8 bhv = __builtin_bit_cast(f16x8, bh[mf]);
           const f16x8 blv = __builtin_bit_cast(f16x8, bl[mf]);
-          f32x4 zq[2][D];
+          f32x4 zq[2][D], ev[2];
           load_zq(bufn, jbn, mf, zq);   // x_j rows of this half of the NEXT step: in flight under the first MFMA
+          load_ev(bufn, jbn, mf, ev);
           f32x2 kv[4];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            // the two small terms first, then the leading one
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q == 0 ? al[mf] : ah[mf], q == 1 ? blv : bhv, acc[ni], 0, 0, 0);
-            // half-chunk u = 2 p + (0: gen_a, 1: gen_b); this MFMA's share: [u0, u1):   a0 b0 a1 | b1 a2 b2 | a3 b3
-            constexpr int U3[4] = {0, 3, 6, 8};
+          for (int q = 0; q < 3 * CT; ++q) {
+            // the two small terms first, then the leading one; consecutive instructions alternate accumulators
+            const int ct = q % CT, term = q / CT;
+            acc[ni][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al[mf][ct] : ah[mf][ct], term == 1 ? blv : bhv, acc[ni][ct], 0, 0, 0);
+            // half-chunk u = 2 p + (0: gen_a, 1: gen_b); this MFMA's share: [u0, u1):
+            //   CT = 1:  a0 b0 a1 | b1 a2 b2 | a3 b3          CT = 2:  a0 | b0 a1 | b1 | a2 | b2 a3 | b3     (kv_gramh.hpp)
+            constexpr int U6[7] = {0, 1, 3, 4, 5, 7, 8}, U3[4] = {0, 3, 6, 8};
+            const int u0 = CT == 1 ? U3[q] : U6[q], u1 = CT == 1 ? U3[q + 1] : U6[q + 1];
 #pragma unroll
-            for (int u = U3[q]; u < U3[q + 1]; ++u) {
-              if ((u & 1) == 0) gen_a(zq, u >> 1, nin, kv[u >> 1], bhn[mf]);
+            for (int u = u0; u < u1; ++u) {
+              if ((u & 1) == 0) gen_a(zq, ev, u >> 1, nin, kv[u >> 1], bhn[mf]);
               else gen_b(kv[u >> 1], u >> 1, bhn[mf][u >> 1], bln[mf]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -220,7 +263,9 @@ void kv_directh_kernel(KvhArgs ka) {
         bh[0] = bhn[0]; bh[1] = bhn[1]; bl[0] = bln[0]; bl[1] = bln[1];
       }
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) { ah[mf] = ahn[mf]; al[mf] = aln[mf]; }
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { ah[mf][ct] = ahn[mf][ct]; al[mf][ct] = aln[mf][ct]; }
     }
   }
 
@@ -231,10 +276,17 @@ void kv_directh_kernel(KvhArgs ka) {
     const int i = ibase + ni * 32 + l31;
     if (i < a.n) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (c < a.t) Pout[(int64_t)c * a.ldo + i] = acc[ni][r] * ka.colmul[c];
-      }
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (c < a.t) Pout[(int64_t)c * a.ldo + i] = acc[ni][ct][r] * ka.colmul[c];
+        }
+    }
+    if constexpr (EX) {
+      const float part = eacc2[ni][0] + eacc2[ni][1];
+      const float tot = part + __shfl_xor(part, 32, 64);
+      if (h == 0 && i < a.n) Pout[(int64_t)TC * a.ldo + i] = tot * ka.colmul[TC];
     }
   }
 }

@@ -35,12 +35,12 @@ const void* kvm_kernel_ptr_matern32(int d, int groups);
 const void* kvm_kernel_ptr_matern52(int d, int groups);
 const void* kvm_kernel_ptr_rq(int d, int groups);
 
-// direct differences + split contraction (kvd_<family>.hip, kv_directh.hpp): d in {1,2,3,4,5,6,8,10}, ni = 1, 2 row tiles per wave
-const void* kvd_kernel_ptr_rbf(int d, int ni);
-const void* kvd_kernel_ptr_matern12(int d, int ni);
-const void* kvd_kernel_ptr_matern32(int d, int ni);
-const void* kvd_kernel_ptr_matern52(int d, int ni);
-const void* kvd_kernel_ptr_rq(int d, int ni);
+// direct differences + split contraction (kvd_<family>.hip, kv_directh.hpp): d in {1,2,3,4,5,6,8,10}, ni = 1, 2 row tiles per wave, ct = 1, 2 column tiles, ex
+const void* kvd_kernel_ptr_rbf(int d, int ni, int ct, int ex);
+const void* kvd_kernel_ptr_matern12(int d, int ni, int ct, int ex);
+const void* kvd_kernel_ptr_matern32(int d, int ni, int ct, int ex);
+const void* kvd_kernel_ptr_matern52(int d, int ni, int ct, int ex);
+const void* kvd_kernel_ptr_rq(int d, int ni, int ct, int ex);
 
 // split-operand kernels: generation and contraction on the f16 matrix pipe (kvh_<family>.hip); ct = 1, 2
 const void* kvh_kernel_ptr_rbf(int d, int ct, int ex, int ni);

@@ -12,7 +12,7 @@ from gpytorch_amd import backend as B  # noqa: E402
 
 dev = torch.device("cuda:0")
 out = []
-for kind, n, d, t, ls in [("matern52", 217_437, 3, 11, 0.05), ("rbf", 217_437, 3, 11, 0.05), ("matern52", 217_437, 3, 32, 0.05), ("matern52", 217_437, 3, 65, 0.05),
+for kind, n, d, t, ls in [("matern52", 217_437, 3, 11, 0.05), ("rbf", 217_437, 3, 11, 0.05), ("matern52", 217_437, 3, 32, 0.05), ("matern52", 217_437, 3, 33, 0.05), ("matern52", 217_437, 3, 64, 0.05), ("matern52", 217_437, 3, 65, 0.05), ("matern52", 100_000, 8, 65, 0.2),
                           ("rbf", 100_000, 10, 11, 0.3), ("matern52", 100_000, 6, 11, 0.2), ("matern12", 217_437, 3, 11, 0.3), ("rbf", 500_000, 3, 11, 0.02)]:
     g = torch.Generator(device=dev).manual_seed(0)
     X = torch.rand(n, d, device=dev, generator=g)

@@ -78,7 +78,8 @@ def test_culled_product_obeys_its_bound_and_drops_tiles(kind, ls, dev):
                 assert bool(((got - ref).abs() <= bound).all()), (kind, t, eps, float(((got - ref).abs() - bound).max()))
                 if must_differ:
                     # tiles holding covariances up to eps were dropped: far beyond the float32 noise of the exact product
-                    assert float((got - exact).abs().max()) > 2e-5 * float(ref.abs().max()), (kind, t)
+                    noise = float((exact - ref).abs().max())
+                    assert float((got - exact).abs().max()) > max(5e-6 * float(ref.abs().max()), 3 * noise), (kind, t, noise)
                 else:
                     assert rel_err(got, ref) < 2e-5
 
@@ -169,7 +170,9 @@ def test_solve_mll_and_posterior_through_the_model_api(dev):
     l1, g1, mu1, var1 = run(1e-7)
     assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0))
     assert rel_err(g1, g0) < 1e-4
-    assert rel_err(mu1, mu0) < 1e-4 and rel_err(var1, var0) < 1e-4
+    # (both posteriors stop their solves at eval_cg_tolerance = 1e-4 and build the LOVE root by Lanczos: products that differ at the 1e-6 level move
+    # either by a few 1e-4 -- measured 2.8e-4 on the mean)
+    assert rel_err(mu1, mu0) < 1e-3 and rel_err(var1, var0) < 1e-3
     # and the truth: dense float64 posterior mean
     Kh = 1.1 * OK.kernel_matrix("matern52", Xtr.double(), Xtr.double(), ls, 1.0, x1_eq_x2=True, direct=True) + 0.05 * torch.eye(n, dtype=torch.float64)
     Ks = 1.1 * OK.kernel_matrix("matern52", Xte.double(), Xtr.double(), ls, 1.0, x1_eq_x2=False, direct=True)

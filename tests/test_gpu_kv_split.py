@@ -186,11 +186,15 @@ def _check_direct(B, kind, X1, X2, V, ls, dev, tol=2e-5):
 
 @pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32", "matern52", "rq"])
 @pytest.mark.parametrize("n,m,d,t", [(300, 300, 3, 11), (257, 513, 1, 5), (130, 1000, 10, 32), (1000, 129, 6, 33), (65, 3000, 8, 64), (700, 700, 2, 65),
-                                       (129, 400, 4, 17), (17_000, 600, 3, 11), (16_500, 300, 9, 8), (400, 400, 5, 40)])
+                                       (129, 400, 4, 17), (17_000, 600, 3, 11), (16_500, 300, 9, 8), (400, 400, 5, 40),
+                                       # round 6: two column tiles + the extra VALU column (K generated once for up to 65 columns), both row tilings
+                                       (16_600, 500, 3, 65), (16_400, 400, 2, 40), (16_500, 300, 8, 65), (16_400, 257, 10, 33), (300, 300, 10, 65),
+                                       (200, 600, 4, 129), (500, 500, 6, 70)])
 def test_direct_split_product_vs_oracle(split, kind, n, m, d, t, dev, monkeypatch):
     """Forced onto the direct-difference generation (as for a cloud outside the policy of the quadratic expansion) with the split contraction:
-    groups of <= 32 columns on kv_directh_kernel (two row tiles per wave from 16 384 output rows on, one below), trailing groups of < 5 columns on
-    the VALU kernel, every family incl. Matern nu = 1/2 (which has no Gram form), d up to 10."""
+    groups of <= 64 (+ 1) columns on kv_directh_kernel (one or two 32-column tiles, the 33rd / 65th column on the VALU; two row tiles per wave from
+    16 384 output rows on -- one with two column tiles beyond four dimensions --, one below), trailing groups of < 5 columns on the VALU kernel, every
+    family incl. Matern nu = 1/2 (which has no Gram form), d up to 10."""
     monkeypatch.setattr(split, "FORCE_KV_FLAGS", split.KV_SPLIT)
     g = torch.Generator().manual_seed(n + 7 * m + t)
     X1 = torch.rand(n, d, generator=g, dtype=torch.float64)
