@@ -65,6 +65,7 @@ GRAM_MAX_EXTENT_SQ = 2.5e7
 GRAM_MAX_EXTENT_SQ_RQ = 60000.0
 DIRECT_SPLIT_MAX_DIM = 10   # csrc/kv_directh.hpp KDH_MAX_DIM
 KV_BLOCK128 = 16         # flag of gpamd_kv_partials_f32: the caller bounds 128-row blocks only (SortedView's medium groups)
+KV_SPLIT_FEW = 32        # with KV_SPLIT: fewer than five columns on the split kernels too (far-pair culling: only they walk tile lists)
 _warned_fallback = set()
 FORCE_GENERIC = False    # tests: send float32 / d <= 16 problems down the generic (row-block + GEMM) path too
 FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or KV_GRAM regardless of |z|
@@ -73,12 +74,13 @@ FORCE_KV_FLAGS = None    # tests / tuning: force 0 (direct-difference kernel) or
 class PreparedPoints:
     """A point cloud converted for the fused kernels: float32 [n, dp], scaled by 1/lengthscale."""
 
-    __slots__ = ("xp", "n", "d", "dp", "kind", "_zmax2", "param", "_sorted", "order_key")
+    __slots__ = ("xp", "n", "d", "dp", "kind", "_zmax2", "param", "_sorted", "order_key", "_far_keep")
 
     def __init__(self, xp, n, d, dp, kind, param=None):
         self.xp, self.n, self.d, self.dp, self.kind = xp, n, d, dp, kind
         self._zmax2 = None
         self.param = param   # shape parameter of the covariance family (RQ: alpha, a Python float) or None
+        self._far_keep = {}  # far-pair culling: surviving share of (512-row block, tile) pairs per (contracted cloud, cutoff), far_kept_fraction
         self._sorted = None  # lazily: SortedView (Hilbert order + chunk centres) for the block-centred Gram expansion
         self.order_key = None  # identity of the SOURCE cloud when the scaling is uniform (prep_points): the Hilbert order is then shared
         #                        by every evaluation of a training run (it is invariant under translation and uniform scaling)
@@ -267,6 +269,7 @@ class SortedView:
         return per_chunk[0], torch.nn.functional.pad(worst, (0, ng * 4 - nch)).reshape(ng, 4).max(1).values
 
 
+FAR_FEW_MAX_KEPT = 0.3   # far-pair culling: products of fewer than five columns move to the (culled) split kernels below this surviving share of tiles
 FAR_MIN_POINTS = 1024   # far-pair culling: smaller clouds are launch-bound, the two extra gathers per product would cost more than any tile saves
 
 
@@ -380,10 +383,21 @@ def kv_flags(x1: PreparedPoints, x2: PreparedPoints, t: int) -> int:
         split = _split_on()
     else:
         split = SPLIT_CONTRACTION
+    # far-pair culling in force for this product (settings.far_pair_cutoff): products of fewer than five columns go to the split kernels too -- where
+    # few enough tiles survive: a mostly empty 32-column tile costs 2.5-3x a few-column kernel per visited tile (road3d-shaped cloud: the culled
+    # one-column product wins below ~0.35 surviving, and is 1.3x SLOWER at lengthscale 0.35 where 0.98 survive)
+    few = 0
+    if split and t < 5:
+        sq = far_cull(x1, x2)
+        if sq is not None:
+            key = (id(x2), round(sq, 6))
+            if key not in x1._far_keep:
+                x1._far_keep[key] = far_kept_fraction(x1, x2, sq, 512)
+            few = KV_SPLIT_FEW if x1._far_keep[key] < FAR_FEW_MAX_KEPT else 0
     if x1.kind == "matern12" or gram_mode(x1, x2) == 0:
-        # direct differences: the contraction still goes to the f16 matrix pipe (csrc/kv_directh.hpp, 5 .. 32 columns per group, d <= 10)
-        return KV_SPLIT if (split and x1.d <= DIRECT_SPLIT_MAX_DIM) else 0
-    return KV_GRAM | (KV_SPLIT if split else 0)
+        # direct differences: the contraction still goes to the f16 matrix pipe (csrc/kv_directh.hpp, 5 .. 65 columns per group, d <= 10)
+        return (KV_SPLIT | few) if (split and x1.d <= DIRECT_SPLIT_MAX_DIM) else 0
+    return KV_GRAM | ((KV_SPLIT | few) if split else 0)
 
 
 def prep_points(kind: str, x: torch.Tensor, lengthscale: torch.Tensor, shift: torch.Tensor | None = None, param=None) -> PreparedPoints:
@@ -546,7 +560,7 @@ def kv_partials_sorted(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor,
     if n_b > n_c:
         _kv_region(x1, x2, X1, Xc, n_c, n_b - n_c, flags | KV_BLOCK128, vt, t, P, ldo, S, jc, done_ptr, st, 1, "medium rows", X2, cull)
     if n_b < x1.n:
-        wflags = KV_SPLIT if ((flags & KV_SPLIT) and x1.d <= DIRECT_SPLIT_MAX_DIM) else 0   # direct differences (+ the split contraction, kv_directh.hpp)
+        wflags = (flags & (KV_SPLIT | KV_SPLIT_FEW)) if ((flags & KV_SPLIT) and x1.d <= DIRECT_SPLIT_MAX_DIM) else 0   # direct differences (+ the split contraction, kv_directh.hpp)
         _kv_region(x1, x2, X1, None, n_b, x1.n - n_b, wflags, vt, t, P, ldo, S, jc, done_ptr, st, 2, "wide rows", X2, cull)
     return unsort
 

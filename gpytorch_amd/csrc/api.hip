@@ -95,26 +95,29 @@ bool gram_ok(int kind, int flags);
 KvVariant pick_variant(int t, bool gram, int flags = 0, bool light = false, bool small = false, int dk = 16) {   // dk: kernel dims (light: dk <= 3 and RBF)  // t <= 129 handled per launch group; light: RBF, d <= 3
   KvVariant v{};
   const bool wide = flags & GPAMD_KV_WIDE;
+  // GPAMD_KV_SPLIT_FEW: groups of fewer than five columns stay on the split-operand kernels too (a 32-column tile mostly empty: slower than the
+  // few-column kernels when every tile is visited, faster when the caller culls far tiles -- only the split kernels walk tile lists)
+  const int min_cols = (flags & GPAMD_KV_SPLIT_FEW) ? 1 : KGH_MIN_COLS;
   if (flags & GPAMD_KV_BLOCK128) {
-    if (gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KGH_GROUP + 1) small = true;
+    if (gram && (flags & GPAMD_KV_SPLIT) && t >= min_cols && t <= KGH_GROUP + 1) small = true;
     else gram = false;
   }
   v.gram = gram;
-  if (gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KGH_GROUP + 1) {
+  if (gram && (flags & GPAMD_KV_SPLIT) && t >= min_cols && t <= KGH_GROUP + 1) {
     v.split = true;
-    v.ex = (t % 32 == 1) ? 1 : 0;
+    v.ex = (t % 32 == 1 && t > 1) ? 1 : 0;
     v.ct = (t - v.ex + 31) / 32;
     // four row tiles per wave with two column tiles ("lean", kv_gramh.hpp) where they fit: one Gram MFMA per block (dk <= 3) and, with the extra
     // column, the light generation of the RBF only (the other families would spill 7..15 registers there)
     v.ni = small ? 1 : kgh_ni(v.ct, (v.ex && !light && dk <= 16) ? 16 : dk);
     v.bm = kgh_bm(v.ni);
     v.bn = KGH_BN;
-  } else if (!gram && (flags & GPAMD_KV_SPLIT) && t >= KGH_MIN_COLS && t <= KDH_COLS + 1 && dk <= KDH_MAX_DIM) {
+  } else if (!gram && (flags & GPAMD_KV_SPLIT) && t >= min_cols && t <= KDH_COLS + 1 && dk <= KDH_MAX_DIM) {
     // direct differences (clouds / rows outside the policy of the quadratic expansion, Matern nu = 1/2) with the contraction on the f16 matrix pipe
     // (kv_directh.hpp): the VALU keeps the generation only -- 9.8 instead of ~17 VALU instructions per pair at d = 3, eleven columns
     v.split = true;
     v.direct = true;
-    v.ex = (t % 32 == 1) ? 1 : 0;
+    v.ex = (t % 32 == 1 && t > 1) ? 1 : 0;
     v.ct = (t - v.ex + 31) / 32;
     v.ni = kdh_ni(small, v.ct, dk);
     v.bm = kdh_bm(v.ni);

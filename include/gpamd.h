@@ -56,7 +56,12 @@ enum {
   /* with GRAM and block centres X1c: the caller bounds the radius of 128-row aligned blocks only (not of the 256 / 512-row blocks the larger
    * row tilings centre): column groups of 5..65 columns with SPLIT run the split kernels at one row tile per wave (128 rows per workgroup),
    * every other column group takes the direct-difference kernels. */
-  GPAMD_KV_BLOCK128 = 16
+  GPAMD_KV_BLOCK128 = 16,
+  /* with SPLIT (ABI version 5): column groups of FEWER than five columns run on the split-operand kernels as well (one 32-column tile, mostly empty)
+   * instead of the few-column kernels.  Slower when every tile is visited (the default selection stands for that reason); set by callers of
+   * gpamd_kv_partials_far_f32, whose tile lists only the split-operand kernels walk: a one-column product of a numerically sparse K then skips the far
+   * tiles too.  gpamd_kv_plan must be called with the same flags (the workspace holds the f16 planes of these groups). */
+  GPAMD_KV_SPLIT_FEW = 32
 };
 
 int gpamd_abi_version(void);
@@ -107,8 +112,9 @@ int gpamd_kv_partials_f32(int kind, float kparam, const float* X1p, int n, const
  * other far arguments are ignored).  jchunk must be a multiple of 128 (gpamd_kv_plan's always is).  The spheres are taken on trust like the
  * GPAMD_KV_GRAM preconditions.  A small kernel builds, per column group, the list of surviving tiles of every (row block, j chunk) unit into
  * tile_workspace on the same stream; the product kernels walk the list.  Culled: the column groups that run on the split-operand kernels
- * (GPAMD_KV_SPLIT, >= 5 columns: kv_gramh.hpp, kv_directh.hpp -- the library's default contraction); every other group (fp32-MFMA contraction,
- * fewer than five columns) evaluates every tile whatever is passed here -- exact, only not faster.  All other arguments as gpamd_kv_partials_f32. */
+ * (GPAMD_KV_SPLIT: kv_gramh.hpp, kv_directh.hpp -- the library's default contraction; groups of fewer than five columns only with
+ * GPAMD_KV_SPLIT_FEW); every other group (fp32-MFMA contraction, the few-column kernels) evaluates every tile whatever is passed here -- exact,
+ * only not faster.  All other arguments as gpamd_kv_partials_f32. */
 int gpamd_kv_partials_far_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Vt,
                               int64_t ldv, int t, float* P, int64_t ldo, int S, int jchunk, int flags, const int* done, void* stream,
                               const float* row_centres, const float* row_radii, const float* tile_centres, const float* tile_radii, float sq_cutoff,

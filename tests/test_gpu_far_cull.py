@@ -84,10 +84,16 @@ def test_culled_product_obeys_its_bound_and_drops_tiles(kind, ls, dev):
                     assert rel_err(got, ref) < 2e-5
 
 
-def test_rectangular_product_and_few_columns(dev):
-    """Test points against training points (two different sorted views); fewer than five columns run un-culled (exact) on the few-column kernels."""
+@pytest.mark.parametrize("few_below", [None, 1.01], ids=["few_by_policy", "few_forced"])
+def test_rectangular_product_and_few_columns(few_below, dev, monkeypatch):
+    """Test points against training points (two different sorted views); fewer than five columns: where few enough tiles survive (the policy
+    ``FAR_FEW_MAX_KEPT``; forced in the second variant) ``kv_flags`` adds KV_SPLIT_FEW and they run culled on the split kernels as well (one mostly
+    empty 32-column tile) instead of un-culled on the few-column kernels."""
     import gpytorch_amd as g
     from gpytorch_amd import backend as B
+
+    if few_below is not None:
+        monkeypatch.setattr(B, "FAR_FEW_MAX_KEPT", few_below)
 
     n, m, ls = 5000, 9000, 0.06
     X1, X2 = road_like(n, seed=4), road_like(m, seed=5)
@@ -98,8 +104,13 @@ def test_rectangular_product_and_few_columns(dev):
         V = torch.randn(m, t, generator=torch.Generator().manual_seed(t))
         vt = B.to_probe_major(V.to(dev))
         with g.settings.far_pair_cutoff(1e-7):
-            assert B.far_cull(p1, p2) is not None
+            sq = B.far_cull(p1, p2)
+            assert sq is not None
+            assert bool(B.kv_flags(p1, p2, t) & B.KV_SPLIT_FEW) == (t < 5 and B.far_kept_fraction(p1, p2, sq, 512) < B.FAR_FEW_MAX_KEPT)
+            if few_below is not None:
+                assert bool(B.kv_flags(p1, p2, t) & B.KV_SPLIT_FEW) == (t < 5)
             got = B.from_probe_major(B.kv(p1, p2, vt), n)
+        assert not (B.kv_flags(p1, p2, t) & B.KV_SPLIT_FEW)
         assert rel_err(got, K @ V.double()) < 2e-5, t
     # the diagonal epilogue after the rows were taken back to the original order
     V = torch.randn(m, 7, generator=torch.Generator().manual_seed(11))
