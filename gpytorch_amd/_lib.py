@@ -99,6 +99,11 @@ SIGNATURES = {
     "gpamd_kv_grad2_xworkspace_floats": (_i64, [_i, _i, _i, _i]),
     "gpamd_kv_grad2_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p]),
     "gpamd_kv_grad2_split_workspace_floats": (_i64, [_i, _i]),
+    "gpamd_kv_grad2_far_workspace_ints": (_i64, [_i, _i]),
+    "gpamd_kv_grad2_far_f32": (_i, [_i, _f, _p, _i, _p, _i, _i, _p, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p,
+                                    _p, _p, _p, _p, _f, _p, _i64]),
+    "gpamd_kv_grad_far_workspace_ints": (_i64, [_i, _i]),
+    "gpamd_kv_grad_far_f32": (_i, [_i, _p, _i, _p, _i, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _f, _p, _i64]),
 }
 
 

@@ -501,10 +501,7 @@ def _kv_launch(x1, x2, X1ptr, n_r: int, X2, Xcptr, vt, t: int, Pptr, ldo: int, S
     assert row0 % 128 == 0
     rc = C.c_void_p(sv1.centers.data_ptr() + 4 * x1.dp * (row0 // 128))
     rr = C.c_void_p(sv1.radii.data_ptr() + 4 * (row0 // 128))
-    nws = int(L.gpamd_kv_far_workspace_ints(n_r, S, jc))
-    tws = _far_ws.get(vt.device)
-    if tws is None or tws.numel() < nws:
-        tws = _far_ws[vt.device] = torch.empty(max(nws, 1 << 18), device=vt.device, dtype=torch.int32)
+    tws = _far_tile_ws(vt.device, int(L.gpamd_kv_far_workspace_ints(n_r, S, jc)))
     check(L.gpamd_kv_partials_far_f32(*kind_args(x1), X1ptr, n_r, _ptr(X2), x2.n, x1.d, Xcptr, _ptr(vt), vt.stride(0), t, Pptr, ldo, S, jc, flags,
                                       done_ptr, st, rc, rr, _ptr(sv2.centers), _ptr(sv2.radii), float(sq), _ptr(tws), tws.numel()), what)
 
@@ -793,27 +790,75 @@ def pivoted_cholesky(xp: PreparedPoints, scale, rank: int, tol: float):
     return L[:m, :n], piv[:m], m
 
 
-def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor, iso: bool = False) -> torch.Tensor:
+def _far_tile_ws(dev, nints: int) -> torch.Tensor:
+    tws = _far_ws.get(dev)
+    if tws is None or tws.numel() < nints:
+        tws = _far_ws[dev] = torch.empty(max(nints, 1 << 18), device=dev, dtype=torch.int32)
+    return tws
+
+
+def far_sorted_right(x2: PreparedPoints, rt: torch.Tensor):
+    """(sorted x2 array, rt with its columns in x2's Hilbert order, zero-padded to a multiple of four, x2's sorted view) for a culled derivative call."""
+    sv2 = x2.sorted_view()
+    rts = rt[:, : x2.n].index_select(1, sv2.perm)
+    if rts.shape[1] % 4:
+        rts = torch.nn.functional.pad(rts, (0, 4 - rts.shape[1] % 4))
+    return sv2.xs, rts.contiguous(), sv2
+
+
+def kv_grad(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch.Tensor, iso: bool = False, far=None) -> torch.Tensor:
     """Fused bilinear derivative with W = lt^T rt (lt: [t, ld_n] over x1, rt: [t, ld_m] over x2).
 
     Returns float32 [1 + dp]:  g[0] = sum_ij W_ij k_ij;  g[1+q] = sum_ij W_ij dk/ds_ij (z_iq - z_jq)^2
-    where z are the PREPARED coordinates and s the squared prepared distance."""
+    where z are the PREPARED coordinates and s the squared prepared distance.
+
+    Far-pair culling (``settings.far_pair_cutoff``): both clouds and their vector blocks go to the kernel in Hilbert order (the sums are order-free) with the
+    bounding spheres of their 128-point chunks.  ``far`` = (sq, row_centres, row_radii, X2 sorted, rt sorted, sv2): the caller (``kv_grad2``, for its wide
+    rows) has x1 / lt in curve order already and hands over the spheres of those rows and the sorted right operands."""
     _require_gpu(lt, "left")
     assert x1.kind == x2.kind and x1.dp == x2.dp and lt.shape[0] == rt.shape[0] and x1.fused and x2.fused
     lt = lt if lt.dtype == torch.float32 else lt.to(torch.float32)
     rt = rt if rt.dtype == torch.float32 else rt.to(torch.float32)
     t = lt.shape[0]
     dev = lt.device
+    X1, X2 = x1.xp, x2.xp
+    cull = None
+    if far is not None:
+        sq, rc, rr, X2, rt, sv2 = far
+        cull = (sq, rc, rr, sv2)
+    else:
+        sq = far_cull(x1, x2)
+        if sq is not None:
+            sv1 = x1.sorted_view()
+            X1 = sv1.xs
+            lt = lt[:, : x1.n].index_select(1, sv1.perm)
+            if lt.shape[1] % 4:
+                lt = torch.nn.functional.pad(lt, (0, 4 - lt.shape[1] % 4))
+            lt = lt.contiguous()
+            X2, rt, sv2 = far_sorted_right(x2, rt)
+            cull = (sq, sv1.centers, sv1.radii, sv2)
     nd = int(lib().gpamd_kv_grad_workspace_doubles(x1.n, x2.n, t, x1.dp))
     ws = torch.empty(nd, device=dev, dtype=torch.float64)
     out = torch.empty(1 + x1.dp, device=dev, dtype=torch.float32)
-    check(
-        lib().gpamd_kv_grad_f32(
-            kind_id(x1), _ptr(x1.xp), x1.n, _ptr(x2.xp), x2.n, x1.dp, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0),
-            t, 1 if iso else 0, _ptr(out), _ptr(ws), nd, _stream(dev),
-        ),
-        "kv_grad",
-    )
+    if cull is None:
+        check(
+            lib().gpamd_kv_grad_f32(
+                kind_id(x1), _ptr(X1), x1.n, _ptr(X2), x2.n, x1.dp, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0),
+                t, 1 if iso else 0, _ptr(out), _ptr(ws), nd, _stream(dev),
+            ),
+            "kv_grad",
+        )
+    else:
+        sq, rc, rr, sv2 = cull
+        tws = _far_tile_ws(dev, int(lib().gpamd_kv_grad_far_workspace_ints(x1.n, x2.n)))
+        check(
+            lib().gpamd_kv_grad_far_f32(
+                kind_id(x1), _ptr(X1), x1.n, _ptr(X2), x2.n, x1.dp, _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0),
+                t, 1 if iso else 0, _ptr(out), _ptr(ws), nd, _stream(dev), _ptr(rc), _ptr(rr), _ptr(sv2.centers), _ptr(sv2.radii), float(sq),
+                _ptr(tws), tws.numel(),
+            ),
+            "kv_grad (far-pair culling)",
+        )
     return out
 
 
@@ -855,6 +900,14 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
     X1, Xc, unsort, _, n_c = gram_operands(x1, x2, KV_GRAM)   # (the derivative kernel centres 128-row blocks: compact AND medium rows)
     n_rows = x1.n
     wide = None
+    # far-pair culling (settings.far_pair_cutoff) rides on the block-centred mode -- rows in curve order with chunk spheres; a cloud narrow enough for
+    # the cloud-centred expansion has nothing far: the contracted cloud and the right vectors go in x2's Hilbert order too (the sums are order-free)
+    sq = far_cull(x1, x2) if unsort is not None else None
+    X2 = x2.xp
+    if sq is not None:
+        rt = rt if rt.dtype == torch.float32 else rt.to(torch.float32)
+        rt_orig = rt
+        X2, rt, sv2 = far_sorted_right(x2, rt)
     if unsort is not None:
         # block-centred expansion: the left vectors follow x1's Hilbert order (one gather of t x n floats per backward pass)
         lt = lt[:, : x1.n].index_select(1, x1.sorted_view().perm).contiguous()
@@ -867,10 +920,12 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
                 ltw = torch.nn.functional.pad(ltw, (0, 4 - ltw.shape[1] % 4))
             if want_gz1 or x1.kind == "rq":
                 # input gradients / the shape-parameter sum of the tail rows: dense row blocks (HIP generation + library GEMMs, float64 sums)
-                wide = kv_grad_generic(xw, x2, ltw, rt, want_gz1=want_gz1)
+                wide = kv_grad_generic(xw, x2, ltw, rt if sq is None else rt_orig, want_gz1=want_gz1)
             else:
                 # hyper-parameter sums only: the fused direct-difference derivative kernel (kv_grad.hpp) on the rectangular block
-                gw = kv_grad(xw, x2, ltw, rt, iso=False)
+                sv1 = x1.sorted_view()
+                far = None if sq is None else (sq, sv1.centers[n_c // 128 :], sv1.radii[n_c // 128 :], X2, rt, sv2)
+                gw = kv_grad(xw, x2, ltw, rt, iso=False, far=far)
                 wide = torch.cat([gw.double(), torch.zeros(1, device=dev, dtype=torch.float64)])
             lt = lt[:, :n_c].contiguous()
             n_rows = n_c
@@ -898,13 +953,25 @@ def kv_grad2(x1: PreparedPoints, x2: PreparedPoints, lt: torch.Tensor, rt: torch
             lt = torch.nn.functional.pad(lt, (0, (-lt.shape[1]) % 4)).contiguous()
         if rt.stride(0) % 4 or rt.data_ptr() % 16:
             rt = torch.nn.functional.pad(rt, (0, (-rt.shape[1]) % 4)).contiguous()
-    check(
-        L.gpamd_kv_grad2_f32(
-            *kind_args(x1), _ptr(X1), n_rows, _ptr(x2.xp), x2.n, x1.d, _ptr(Xc), _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
-            1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, KV_SPLIT if split else 0, _ptr(sws), ns, _stream(dev),
-        ),
-        "kv_grad2",
-    )
+    if sq is None:
+        check(
+            L.gpamd_kv_grad2_f32(
+                *kind_args(x1), _ptr(X1), n_rows, _ptr(X2), x2.n, x1.d, _ptr(Xc), _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
+                1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, KV_SPLIT if split else 0, _ptr(sws), ns, _stream(dev),
+            ),
+            "kv_grad2",
+        )
+    else:
+        sv1 = x1.sorted_view()
+        tws = _far_tile_ws(dev, int(L.gpamd_kv_grad2_far_workspace_ints(n_rows, x2.n)))
+        check(
+            L.gpamd_kv_grad2_far_f32(
+                *kind_args(x1), _ptr(X1), n_rows, _ptr(X2), x2.n, x1.d, _ptr(Xc), _ptr(lt), lt.stride(0), _ptr(rt), rt.stride(0), t,
+                1 if iso else 0, _ptr(out), _ptr(gzt), ldg, _ptr(ws), nd, _ptr(xws), nx, KV_SPLIT if split else 0, _ptr(sws), ns, _stream(dev),
+                _ptr(sv1.centers), _ptr(sv1.radii), _ptr(sv2.centers), _ptr(sv2.radii), float(sq), _ptr(tws), tws.numel(),
+            ),
+            "kv_grad2 (far-pair culling)",
+        )
     if wide is not None:
         gw, gzw = wide if want_gz1 else (wide, None)
         gw = gw.to(out.dtype)

@@ -433,7 +433,7 @@ int gpamd_kv_partials_far_f32(int kind, float kparam, const float* X1p, int n, c
       c.tiles = tile_ws; c.tpc1 = jchunk / 128 + 1;
       c.n = n; c.m = m; c.dp = (dk + 3) / 4 * 4; c.bm = v.bm; c.bn = v.bn; c.nrb = a.nrb; c.jchunk = jchunk;
       c.sq_cut = sq_cutoff; c.done = done;
-      hipLaunchKernelGGL(cull_list_kernel, dim3((unsigned)a.nrb * (unsigned)S), dim3(64), 0, st, c);
+      hipLaunchKernelGGL(cull_list_kernel<0>, dim3((unsigned)a.nrb * (unsigned)S), dim3(64), 0, st, c);
       a.tiles = tile_ws; a.tpc1 = c.tpc1;
     }
     unsigned grid = (unsigned)a.nrb * (unsigned)S;

@@ -18,6 +18,11 @@ enum Kind : int { KIND_RBF = 0, KIND_MATERN12 = 1, KIND_MATERN32 = 2, KIND_MATER
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// Far-pair tile culling (kv_cull.hpp): start of the k-th tile of the contracted cloud a (row block, j chunk) unit visits -- tl: the unit's list of
+// surviving tile starts (ascending, terminated by an entry >= the chunk end) or nullptr = every tile of the chunk, jbeg + k * BN.
+template <int BN>
+__device__ __forceinline__ int tile_start(const int* tl, int jbeg, int k) { return tl ? tl[k] : jbeg + k * BN; }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));

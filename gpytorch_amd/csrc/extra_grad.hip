@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
+#include "kv_cull.hpp"
 #include "kv_grad.hpp"
 
 using namespace gpamd;
@@ -75,6 +76,21 @@ int64_t gpamd_kv_grad_workspace_doubles(int n, int m, int t, int dp) {
 int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Lt, int64_t ldl,
                       const float* Rt, int64_t ldr, int t, int iso, float* out, double* workspace,
                       int64_t workspace_doubles, void* stream) {
+  return gpamd_kv_grad_far_f32(kind, X1p, n, X2p, m, dp, Lt, ldl, Rt, ldr, t, iso, out, workspace, workspace_doubles, stream, nullptr, nullptr, nullptr,
+                               nullptr, 0.f, nullptr, 0);
+}
+
+int64_t gpamd_kv_grad_far_workspace_ints(int n, int m) {
+  if (n <= 0 || m <= 0) return 0;
+  int S, jc, nrb;
+  grad_plan(n, m, &S, &jc, &nrb);
+  return (int64_t)nrb * S * (jc / 64 + 1);
+}
+
+int gpamd_kv_grad_far_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Lt, int64_t ldl,
+                          const float* Rt, int64_t ldr, int t, int iso, float* out, double* workspace,
+                          int64_t workspace_doubles, void* stream, const float* row_centres, const float* row_radii, const float* tile_centres,
+                          const float* tile_radii, float sq_cutoff, int* tile_workspace, int64_t tile_workspace_ints) {
   if (kind < 0 || kind > 3 || n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m) {
     snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad: bad arguments");
     return GPAMD_EINVAL;
@@ -86,6 +102,19 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
   const int64_t units = (int64_t)nrb * S;
   if (workspace_doubles < groups * units * (1 + dp)) return GPAMD_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  const bool cull = sq_cutoff > 0.f;   // far-pair culling (include/gpamd.h gpamd_kv_partials_far_f32): one tile list per unit, shared by the column groups
+  if (cull) {
+    if (!row_centres || !row_radii || !tile_centres || !tile_radii || !tile_workspace || tile_workspace_ints < units * (jc / 64 + 1)) {
+      snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad: far-pair culling needs the four bounding-sphere arrays and gpamd_kv_grad_far_workspace_ints ints");
+      return GPAMD_EINVAL;
+    }
+    CullArgs c;
+    c.rc = row_centres; c.rr = row_radii; c.tc = tile_centres; c.tr = tile_radii;
+    c.tiles = tile_workspace; c.tpc1 = jc / 64 + 1;
+    c.n = n; c.m = m; c.dp = dp; c.bm = 128; c.bn = 64; c.nrb = nrb; c.jchunk = jc;
+    c.sq_cut = sq_cutoff; c.done = nullptr;
+    hipLaunchKernelGGL(cull_list_kernel<0>, dim3((unsigned)units), dim3(64), 0, st, c);
+  }
   for (int g = 0; g < groups; ++g) {
     const int c0 = g * GRAD_TGROUP;
     const int tg = (t - c0) < GRAD_TGROUP ? (t - c0) : GRAD_TGROUP;
@@ -97,6 +126,7 @@ int gpamd_kv_grad_f32(int kind, const float* X1p, int n, const float* X2p, int m
     a.n = n; a.m = m; a.t = tg;
     a.S = S; a.jchunk = jc; a.nrb = nrb;
     a.part = workspace + (int64_t)g * units * (1 + dp);
+    if (cull) { a.tiles = tile_workspace; a.tpc1 = jc / 64 + 1; }
     const int th = (tg + 1) / 2;
     const size_t lds = ((size_t)4 * 2 * th * 32 + (size_t)4 * 64 * dp) * sizeof(float);
     int rc = -2;

@@ -1,10 +1,12 @@
-// Far-pair tile culling: the list kernel (settings.far_pair_cutoff / gpamd_kv_partials_far_f32).  Included by api.hip only.
+// Far-pair tile culling: the list kernel (settings.far_pair_cutoff / gpamd_kv_partials_far_f32, gpamd_kv_grad2_far_f32, gpamd_kv_grad_far_f32).
+// Included by the translation units that hold those entry points (a template, so that each may instantiate it).
 #pragma once
-#include "kv_mfma.hpp"
+#include "common.hpp"
 
 namespace gpamd {
 
-// Tile lists for far-pair culling: one wave per unit (s, rb).  Row block rb = rows [rb * bm, + bm) of X1 (bm a multiple of 128): its sphere has
+// Tile lists for far-pair culling: one wave per unit (s, rb).  (bn = 64: the derivative kernels' j step -- every step takes the sphere of the
+// 128-point tile it lies in.)  Row block rb = rows [rb * bm, + bm) of X1 (bm a multiple of 128): its sphere has
 // centre = the mean of its 128-row chunk centres (what load_center forms; chunk indices clamped to the last chunk) and radius
 // max_q |c_q - centre| + r_q.  A tile of bn contracted points (bn = 128 or 256: one or two 128-point spheres) survives when any of its spheres
 // comes within sqrt(sq_cut) of the row block's; 64 tiles per step, a ballot compacts the survivors in order.
@@ -17,6 +19,7 @@ struct CullArgs {
   const int* done;
 };
 constexpr int CULL_MAX_DP = 32;
+template <int UNUSED>
 __global__ __launch_bounds__(64) void cull_list_kernel(CullArgs a) {
   if (a.done && *a.done) return;
   const int unit = blockIdx.x, lane = threadIdx.x;

@@ -29,6 +29,8 @@ struct GradArgs {
   int n, m, t;
   int S, jchunk, nrb;  // j split, chunk length (multiple of 64), row blocks of 128
   double* part;        // [nrb*S][1 + DP]
+  const int* tiles = nullptr;   // far-pair culling (kv_cull.hpp): per unit, the starts of the 64-row j steps it visits (nullptr: all of them)
+  int tpc1 = 0;
 };
 
 template <int KIND, int DP, int ISO>
@@ -69,7 +71,8 @@ __global__ __launch_bounds__(256) void kv_grad_kernel(GradArgs a) {
   for (int q = 0; q <= DP; ++q) g[q] = 0.0;
   __builtin_amdgcn_wave_barrier();
 
-  for (int j0 = jbeg; j0 < jend; j0 += 64) {
+  const int* tl = a.tiles ? a.tiles + (int64_t)unit * a.tpc1 : nullptr;
+  for (int tk = 0, j0; (j0 = tile_start<64>(tl, jbeg, tk)) < jend; ++tk) {
     // stage x_j for the two 32-wide j tiles (wave-private LDS: in-order DS ops, no block barrier)
     {
       const int j = min(j0 + lane, a.m - 1);

@@ -53,6 +53,8 @@ struct Grad2Args {
   const _Float16* Rh = nullptr;
   const _Float16* Rl = nullptr;
   const float* wscale = nullptr;
+  const int* tiles = nullptr;   // far-pair culling (kv_cull.hpp): per unit, the starts of the 64-row j steps it visits (nullptr: all of them)
+  int tpc1 = 0;
 };
 
 constexpr int G2_CPL = WS_CP + 8;   // LDS row stride (f16) of the R planes: 176 B -> conflict-free ds_read_b128
@@ -205,9 +207,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(g2_waves<D,
       }
     }
   };
-  fetch(jbeg);
+  const int* tl = a.tiles ? a.tiles + (int64_t)unit * a.tpc1 : nullptr;   // far-pair culling: the look-ahead fetch takes the next SURVIVING step
+  const int jfirst = tile_start<BN>(tl, jbeg, 0);
+  if (jfirst < jend) fetch(jfirst);
 
-  for (int j0 = jbeg; j0 < jend; j0 += BN) {
+  for (int j0 = jfirst, jn, tk = 1; j0 < jend; j0 = jn, ++tk) {
+    jn = tile_start<BN>(tl, jbeg, tk);
     __syncthreads();
     // ---- registers -> LDS: the R tile transposed to Rs[j][k-half][c/2], the split augmented x_j rows, the [1 | z | z^2] columns
     if constexpr (WSPLIT) {
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(g2_waves<D,
       }
     }
     __syncthreads();
-    if (j0 + BN < jend) fetch(j0 + BN);
+    if (jn < jend) fetch(jn);
 
     // ---- W^T tiles of the two 32-row j blocks on the matrix pipe (A = R, B = L; 4 k-steps per LDS read)
     f32x16 w0, w1;

@@ -52,7 +52,7 @@ struct KvArgs {
 
 // start of the k-th tile a workgroup visits (tl: its list or nullptr = every tile of the chunk)
 template <int BN>
-__device__ __forceinline__ int kv_tile_at(const int* tl, int jbeg, int k) { return tl ? tl[k] : jbeg + k * BN; }
+__device__ __forceinline__ int kv_tile_at(const int* tl, int jbeg, int k) { return tile_start<BN>(tl, jbeg, k); }
 __device__ __forceinline__ const int* kv_tile_list(const KvArgs& a, int unit) { return a.tiles ? a.tiles + (int64_t)unit * a.tpc1 : nullptr; }
 
 constexpr int KV_BN = 128;           // j-tile staged in LDS per iteration

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "cg_kernels.hpp"
+#include "kv_cull.hpp"
 #include "kv_grad2.hpp"
 
 using namespace gpamd;
@@ -153,6 +154,22 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
                        const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
                        int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, int flags, float* sworkspace,
                        int64_t sworkspace_floats, void* stream) {
+  return gpamd_kv_grad2_far_f32(kind, kparam, X1p, n, X2p, m, d, X1c, Lt, ldl, Rt, ldr, t, iso, out, Gz1t, ldg, workspace, workspace_doubles, xworkspace,
+                                xworkspace_floats, flags, sworkspace, sworkspace_floats, stream, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0);
+}
+
+int64_t gpamd_kv_grad2_far_workspace_ints(int n, int m) {
+  if (n <= 0 || m <= 0) return 0;
+  int S, jc, nrb;
+  g2_plan(n, m, &S, &jc, &nrb);
+  return (int64_t)nrb * S * (jc / G2_BN + 1);
+}
+
+int gpamd_kv_grad2_far_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Lt, int64_t ldl,
+                           const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
+                           int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, int flags, float* sworkspace,
+                           int64_t sworkspace_floats, void* stream, const float* row_centres, const float* row_radii, const float* tile_centres,
+                           const float* tile_radii, float sq_cutoff, int* tile_workspace, int64_t tile_workspace_ints) {
   if (n <= 0 || m <= 0 || t <= 0 || ldl < n || ldr < m || d < 1 || d > 32) {
     snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: bad arguments");
     return GPAMD_EINVAL;
@@ -177,6 +194,21 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
   }
   const int mode = (iso && !Gz1t) ? 0 : 1;
   hipStream_t st = (hipStream_t)stream;
+  // far-pair culling (include/gpamd.h gpamd_kv_partials_far_f32): one list of surviving 64-row j steps per (128-row block, j chunk) unit, shared by
+  // every column group of this call
+  const bool cull = sq_cutoff > 0.f;
+  if (cull) {
+    if (!row_centres || !row_radii || !tile_centres || !tile_radii || !tile_workspace || tile_workspace_ints < units * (jc / G2_BN + 1)) {
+      snprintf(gpamd::g_err, sizeof(gpamd::g_err), "kv_grad2: far-pair culling needs the four bounding-sphere arrays and gpamd_kv_grad2_far_workspace_ints ints");
+      return GPAMD_EINVAL;
+    }
+    CullArgs c;
+    c.rc = row_centres; c.rr = row_radii; c.tc = tile_centres; c.tr = tile_radii;
+    c.tiles = tile_workspace; c.tpc1 = jc / G2_BN + 1;
+    c.n = n; c.m = m; c.dp = dp; c.bm = 128; c.bn = G2_BN; c.nrb = nrb; c.jchunk = jc;
+    c.sq_cut = sq_cutoff; c.done = nullptr;
+    hipLaunchKernelGGL(cull_list_kernel<0>, dim3((unsigned)units), dim3(64), 0, st, c);
+  }
   // split-operand workspace: [Lh | Ll | Rh | Rl | colmax L | colmax R | scales]
   const int64_t npad = pad_to(n, 128), mpad = pad_to(m, G2_BN);
   _Float16* Lh = reinterpret_cast<_Float16*>(sworkspace);
@@ -203,6 +235,7 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
     a.Px = Gz1t ? xworkspace + (int64_t)g * S * dp * ldx : nullptr;
     a.ldx = ldx;
     a.pxstride = (int64_t)dp * ldx;
+    if (cull) { a.tiles = tile_workspace; a.tpc1 = jc / G2_BN + 1; }
     int rc = -2;
     if (split) {
       // pre-pass (kv_wsplit.hpp): column maxima of both blocks, scales with a constant product, the four planes

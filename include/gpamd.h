@@ -35,7 +35,8 @@ enum { GPAMD_RBF = 0, GPAMD_MATERN12 = 1, GPAMD_MATERN32 = 2, GPAMD_MATERN52 = 3
  * state, so operators with different alpha may interleave freely on one thread -- AdditiveKernel(RQ, RQ)).  ABI version 3: the
  * float64 / generic entry points take it too (`double kparam`), so the family runs on every path.  ABI version 4 (additive): the block-Lanczos
  * vector entry points gpamd_block_{project,subtract,transform}_f32, and fused float32 kernels for input dimensions up to 32 (was 16).
- * ABI version 5 (additive): gpamd_kv_partials_far_f32 / gpamd_kv_far_workspace_ints -- the same product with far-pair tile culling. */
+ * ABI version 5 (additive): gpamd_kv_partials_far_f32 / gpamd_kv_far_workspace_ints -- the same product with far-pair tile culling --, its
+ * derivative twins gpamd_kv_grad2_far_f32 / gpamd_kv_grad_far_f32, and the flag GPAMD_KV_SPLIT_FEW. */
 
 enum { GPAMD_EINVAL = -1, GPAMD_EUNSUPPORTED = -2, GPAMD_EWORKSPACE = -3 };
 
@@ -301,6 +302,24 @@ int gpamd_kv_grad2_f32(int kind, float kparam, const float* X1p, int n, const fl
                        const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
                        int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, int flags, float* sworkspace,
                        int64_t sworkspace_floats, void* stream);
+
+/* The two derivative kernels with FAR-PAIR TILE CULLING (ABI version 5; contract, spheres and bound as gpamd_kv_partials_far_f32: both clouds and their
+ * vector blocks in curve order, bounding spheres of the 128-point chunks, sq_cutoff the squared prepared distance beyond which k -- and with it dk/ds --
+ * is accepted as zero; sq_cutoff <= 0: exactly the un-culled entry points).  A (128-row block, j chunk) unit skips the 64-row j steps whose 128-point
+ * tile lies farther than sqrt(sq_cutoff) from its rows: neither the W tile nor the covariance derivative of a skipped step is formed.  The sums are
+ * order-free, so the caller need not take anything back to the original order (Gz1t comes out in X1p's order, as always).
+ * tile_workspace: gpamd_kv_grad2_far_workspace_ints(n, m) / gpamd_kv_grad_far_workspace_ints(n, m) ints. */
+int64_t gpamd_kv_grad2_far_workspace_ints(int n, int m);
+int gpamd_kv_grad2_far_f32(int kind, float kparam, const float* X1p, int n, const float* X2p, int m, int d, const float* X1c, const float* Lt, int64_t ldl,
+                           const float* Rt, int64_t ldr, int t, int iso, float* out, float* Gz1t, int64_t ldg, double* workspace,
+                           int64_t workspace_doubles, float* xworkspace, int64_t xworkspace_floats, int flags, float* sworkspace,
+                           int64_t sworkspace_floats, void* stream, const float* row_centres, const float* row_radii, const float* tile_centres,
+                           const float* tile_radii, float sq_cutoff, int* tile_workspace, int64_t tile_workspace_ints);
+int64_t gpamd_kv_grad_far_workspace_ints(int n, int m);
+int gpamd_kv_grad_far_f32(int kind, const float* X1p, int n, const float* X2p, int m, int dp, const float* Lt, int64_t ldl,
+                          const float* Rt, int64_t ldr, int t, int iso, float* out, double* workspace,
+                          int64_t workspace_doubles, void* stream, const float* row_centres, const float* row_radii, const float* tile_centres,
+                          const float* tile_radii, float sq_cutoff, int* tile_workspace, int64_t tile_workspace_ints);
 
 /* ---- batches of SMALL independent GPs (gpytorch/kernels/kernel.py:163-208 batch_shape; test/examples/test_batch_gp_regression.py).
  * Members below settings.max_cholesky_size are factorised, not iterated: what the member loop costs there is launches.  These two

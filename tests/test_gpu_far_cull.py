@@ -188,3 +188,49 @@ def test_solve_mll_and_posterior_through_the_model_api(dev):
     Kh = 1.1 * OK.kernel_matrix("matern52", Xtr.double(), Xtr.double(), ls, 1.0, x1_eq_x2=True, direct=True) + 0.05 * torch.eye(n, dtype=torch.float64)
     Ks = 1.1 * OK.kernel_matrix("matern52", Xte.double(), Xtr.double(), ls, 1.0, x1_eq_x2=False, direct=True)
     assert rel_err(mu1, Ks @ torch.linalg.solve(Kh, y.double())) < 2e-3
+
+
+@pytest.mark.parametrize("kind,ls,t", [("matern52", 0.05, 11), ("rbf", 0.05, 30), ("matern32", 0.1, 11), ("matern12", 0.03, 11), ("matern52", 0.012, 11)])
+def test_bilinear_derivative_is_culled_too(kind, ls, t, dev):
+    """The backward: the Gram-form derivative kernel (compact + medium rows), the direct-difference derivative of the wide rows and the all-direct
+    case (Matern-1/2; a cloud outside every Gram policy) walk the same tile lists (``gpamd_kv_grad2_far_f32`` / ``gpamd_kv_grad_far_f32``).  Left / right
+    vectors of one sign, so that the sums do not cancel and a relative comparison with the un-culled kernels means something: eps = 1e-7 is invisible
+    (the sums are dominated by near pairs: even a coarse cutoff moves them by 1e-5 only, so that steps ARE skipped is read off the tile list itself),
+    and the input gradients come back in the original row order."""
+    import gpytorch_amd as g
+    from gpytorch_amd import backend as B
+
+    n = 20_000
+    X = road_like(n, seed=9)
+    xp = _prep(B, kind, X, ls, dev)
+    gen = torch.Generator().manual_seed(t)
+    lt = B.to_probe_major(torch.rand(n, t, generator=gen).to(dev) + 0.1)
+    rt = B.to_probe_major(torch.rand(n, t, generator=gen).to(dev) + 0.1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gram = B.grad_gram_ok(xp, xp)
+
+        def run(want_x):
+            if gram:
+                return B.kv_grad2(xp, xp, lt, rt, iso=True, want_gz1=want_x)
+            return B.kv_grad(xp, xp, lt, rt, iso=True), None
+
+        g0, gx0 = run(False)
+        with g.settings.far_pair_cutoff(1e-7):
+            assert B.far_cull(xp, xp) is not None
+            g1, gx1 = run(False)
+            # steps really are skipped: the tile list of unit 0 (the first 128 rows of the curve order against the first j chunk) as the list kernel
+            # left it in the workspace -- ascending step starts, then the terminator (= the chunk length): far fewer entries than the chunk has steps
+            tl = B._far_ws[torch.device(dev)][:8192].tolist() if torch.device(dev) in B._far_ws else B._far_ws[next(iter(B._far_ws))][:8192].tolist()
+            k = 1
+            while k < len(tl) and tl[k] > tl[k - 1]:
+                k += 1
+            chunk = tl[k - 1]
+            assert chunk % 64 == 0 and 0 < chunk <= B.round_up(n, 64) and k - 1 < 0.7 * (chunk // 64), (kind, k, chunk)
+        sc = float(g0.abs().max())
+        assert float((g1 - g0).abs().max()) < 2e-5 * sc, (kind, g0.tolist(), g1.tolist())
+        if gram and kind != "rq":
+            _, gx0 = run(True)
+            with g.settings.far_pair_cutoff(1e-7):
+                _, gx1 = run(True)
+            assert float((gx1 - gx0).abs().max()) < 2e-5 * float(gx0.abs().max())
