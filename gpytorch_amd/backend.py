@@ -269,6 +269,7 @@ class SortedView:
         return per_chunk[0], torch.nn.functional.pad(worst, (0, ng * 4 - nch)).reshape(ng, 4).max(1).values
 
 
+REGION_MERGE_MAX_ROWS = 4096   # kv_partials_sorted: medium + wide rows up to this many share ONE direct-difference launch
 FAR_FEW_MAX_KEPT = 0.3   # far-pair culling: products of fewer than five columns move to the (culled) split kernels below this surviving share of tiles
 FAR_MIN_POINTS = 1024   # far-pair culling: smaller clouds are launch-bound, the two extra gathers per product would cost more than any tile saves
 
@@ -540,6 +541,11 @@ def kv_partials_sorted(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor,
     groups it does not serve fall to the direct-difference kernels inside the library); the rows of the WIDE groups on the direct-difference
     kernels -- further launches into the same slabs."""
     X1, Xc, unsort, n_c, n_b = gram_operands(x1, x2, flags)
+    if n_c < n_b < x1.n and x1.n - n_c <= REGION_MERGE_MAX_ROWS:
+        # a few medium AND a few wide rows (protein-shaped cloud: 2048 + 232 of 36 584): one direct-difference launch for both instead of two region
+        # launches -- each region costs five launches per product (split pre-pass, kernel, slab reduction, zeroing), and at this size the products are
+        # launch-bound; direct differences are valid for any row (and 1.1-1.6x slower per row: nothing for a few thousand rows)
+        n_b = n_c
     X2, cull = x2.xp, None
     sq = far_cull(x1, x2)
     if sq is not None:

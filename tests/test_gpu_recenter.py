@@ -346,6 +346,38 @@ def test_elongated_runs_take_the_128_row_blocks(kind, ls, split, dev, monkeypatc
     assert abs(float(out[1]) - gs) < 5e-5 * abs(gs)          # sum W dk/ds s: the single-lengthscale sum (MODE 0 convention: out[1])
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "split"])
+def test_a_few_medium_and_wide_rows_share_one_direct_launch(split, dev, monkeypatch):
+    """Round 6.  A cloud with a FEW medium and a FEW wide rows (the protein-shaped workload: 2048 + 232 of 36 584): ``kv_partials_sorted`` sends both
+    to ONE direct-difference region launch (``REGION_MERGE_MAX_ROWS``) instead of two -- at that size each region's five launches are what the
+    product costs.  Same numbers against float64 rows as the three-region form (forced by raising / zeroing the limit)."""
+    from gpytorch_amd import backend as B
+
+    monkeypatch.setattr(B, "SPLIT_CONTRACTION", split)
+    n, d, ls = 24_000, 6, 0.57
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(n, d, generator=g).clamp_(-3.0, 3.0)                  # standardised features: a compact bulk, a sparse shell
+    Xd = X.to(dev)
+    xp = B.prep_points("rbf", Xd, torch.tensor([ls]), Xd.mean(0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert B.gram_mode(xp, xp) == 2
+    sv = xp.sorted_view()
+    n_med, n_wide = sv.n_block - sv.n_compact, n - sv.n_block
+    assert n_med > 0 and n_wide > 0 and n_med + n_wide <= B.REGION_MERGE_MAX_ROWS, (sv.n_compact, sv.n_block)
+    rows = torch.cat([sv.perm[:64].cpu(), sv.perm[sv.n_compact : sv.n_compact + 128].cpu(), sv.perm[-128:].cpu()]).unique()
+    Krows = OK.kernel_matrix("rbf", X[rows].double(), X.double(), ls, 1.0, x1_eq_x2=False, direct=True)
+    for t in (1, 11, 65):
+        V = torch.randn(n, t, generator=torch.Generator().manual_seed(t))
+        vt = B.to_probe_major(V.to(dev))
+        ref = Krows @ V.double()
+        merged = B.kv(xp, xp, vt)[:, rows.to(dev)].t().double().cpu()
+        monkeypatch.setattr(B, "REGION_MERGE_MAX_ROWS", 0)
+        three = B.kv(xp, xp, vt)[:, rows.to(dev)].t().double().cpu()
+        monkeypatch.setattr(B, "REGION_MERGE_MAX_ROWS", 4096)
+        assert rel_err(merged, ref) < 2e-5 and rel_err(three, ref) < 2e-5, (t, rel_err(merged, ref), rel_err(three, ref))
+
+
 @pytest.mark.parametrize("kind", ["matern32", "matern52"])
 @pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "split"])
 def test_contracted_points_near_the_extent_limit_of_the_saturating_norms(kind, split, dev, monkeypatch):
