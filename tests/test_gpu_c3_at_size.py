@@ -43,11 +43,12 @@ def _grads(xp32, res, ls, os_, dev):
     return total, parts[0], parts[1]
 
 
-def test_c3_mll_ingredients_fused_float32_vs_float64_bbmm(dev):
+def _run_both_precisions(dev, n, tol, max_iter):
+    """The C3 model's MLL ingredients and gradients on the fused float32 path and on the float64 BBMM path (same probes, same preconditioner factor)."""
     from gpytorch_amd import backend as B
     from gpytorch_amd.bbmm import build_preconditioner, inv_quad_logdet_forward, preconditioner_from_factor
 
-    kind, n, d, ls, probes, tol = "matern52", 500_000, 10, 0.8, 3, 0.05   # (3 probes + y = 4 columns: the float64 run takes the VALU-contraction kernel, kv_f64v)
+    kind, d, ls, probes = "matern52", 10, 0.8, 3   # (3 probes + y = 4 columns: the float64 run takes the VALU-contraction kernel, kv_f64v)
     X, y = synth(n, d)
     Xd, yd = X.to(dev), y.to(dev)
     lsv = torch.tensor([ls], device=dev)
@@ -71,7 +72,7 @@ def test_c3_mll_ingredients_fused_float32_vs_float64_bbmm(dev):
             kw = {"probes": zprobe}                                         # the SAME probe vectors (un-normalised [n, t])
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        res = inv_quad_logdet_forward(xp, sc, s2, rhs_t, precond=pre, tolerance=tol, max_iter=400, **kw)
+        res = inv_quad_logdet_forward(xp, sc, s2, rhs_t, precond=pre, tolerance=tol, max_iter=max_iter, **kw)
         torch.cuda.synchronize(dev)
         fwd = time.perf_counter() - t0
         assert res.info.tolerance_reached
@@ -94,6 +95,31 @@ def test_c3_mll_ingredients_fused_float32_vs_float64_bbmm(dev):
         r.pop("ysol")
     log["float32_fused"], log["float64_bbmm"] = a, b
     log["y_solve_rel_l2_difference"] = ysol_err
+    return log, a, b, ysol_err
+
+
+def test_c3_model_converged_solves_net_gradients_within_1e_3(dev):
+    """The same comparison where BOTH runs have converged (cg_tolerance 1e-3, n = 60 000 -- the size of the dense-truth tests of this model): the
+    NET hyper-parameter gradients, the quantities a user sees, agree to 1e-3 -- the bar ``north_star`` states.  (At n = 500 000 and the looser
+    tolerance 0.05 below, the two runs are different iterates of one sequence and the net outputscale derivative -- a 3-5-fold cancellation of its
+    log-determinant and data-fit parts -- is only within 5e-3: asserted there per part, advisor finding of round 5.)"""
+    log, a, b, ysol_err = _run_both_precisions(dev, 60_000, 1e-3, 1000)
+    os.makedirs("gpurun_out", exist_ok=True)
+    log["grad_net_relative_difference"] = {}
+    assert abs(a["inv_quad"] - b["inv_quad"]) < 1e-4 * abs(b["inv_quad"]), log
+    assert ysol_err < 1e-3, log
+    assert abs(a["logdet"] - b["logdet"]) < 1e-3 * abs(b["logdet"]), log
+    for k, name in enumerate(("lengthscale", "outputscale", "noise")):
+        ga, gb = a["grad_lengthscale_outputscale_noise"][k], b["grad_lengthscale_outputscale_noise"][k]
+        log["grad_net_relative_difference"][name] = abs(ga - gb) / abs(gb)
+    with open("gpurun_out/c3_model_converged_vs_float64.json", "w") as f:
+        json.dump(log, f, indent=1)
+    for name, v in log["grad_net_relative_difference"].items():
+        assert v < 1e-3, (name, log)
+
+
+def test_c3_mll_ingredients_fused_float32_vs_float64_bbmm(dev):
+    log, a, b, ysol_err = _run_both_precisions(dev, 500_000, 0.05, 400)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/c3_at_size_vs_float64.json", "w") as f:
         json.dump(log, f, indent=1)
