@@ -208,6 +208,35 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
 
         return partials, prepared[0][0].dtype
 
+    # ---- float64 product on the prepared points of the float32 path (mixed-precision corrections: settings.rhs_refinement; round 6) ----
+    def float64_product_available(self) -> bool:
+        """Every member has a fused float64 product (float32 model, d <= 16: ``csrc/kv_f64.hpp``)."""
+        return all(xp.fused and xp.dp <= B.FUSED_F64_MAX_DP for xp, _ in self._prepared())
+
+    def _matvec64(self):
+        """a64 [c, ld] (probe-major, float64) -> (sum_i theta_i K_i + sigma^2 I + D) a in float64: one fused float64 product per member
+        (``bbmm.matvec64``), the diagonal once."""
+        from .bbmm import matvec64
+
+        mvs = [matvec64(xp, os_, None) for xp, os_ in self._prepared()]
+        nz = self.noise.detach().reshape(()).to(torch.float64)
+        dv = self._dvec(torch.float64)
+
+        def mv(a64):
+            out = mvs[0](a64)
+            for m_ in mvs[1:]:
+                out = out + m_(a64)
+            out = out + nz * a64
+            return out if dv is None else out + dv.unsqueeze(0) * a64
+
+        return mv
+
+    def matmul_float64(self, rhs: torch.Tensor) -> torch.Tensor:
+        """K_hat @ rhs ([n, c] -> [n, c]) in float64 on the prepared points of the float32 path (``bbmm.variational_inv_quad``)."""
+        if not self.float64_product_available():
+            return None
+        return B.from_probe_major(self._matvec64()(B.to_probe_major(rhs.detach(), torch.float64)), self.shape[-1])
+
     def solve(self, rhs, lhs=None):
         squeeze = rhs.dim() == 1
         r = rhs.unsqueeze(-1) if squeeze else rhs
@@ -219,8 +248,23 @@ class SumFusedAddedDiagLinearOperator(LinearOperator):
             dv = self._dvec(wd)
             if not hasattr(self, "_precond_cache"):
                 self._precond_cache = sum_preconditioner(self._prepared(), nz, dv, self.shape[-1])
-            sol_t, _ = linear_cg(None, None, nz, B.to_probe_major(r.detach(), wd), n_tridiag=0, tolerance=settings.cg_tolerance.value(),
+
+            def cg32(rt):
+                return linear_cg(None, None, nz, rt, n_tridiag=0, tolerance=settings.cg_tolerance.value(),
                                  kv_partials=partials, dvec=dv, nvec=self.shape[-1], preconditioner=self._precond_cache)
+
+            rhs_t = B.to_probe_major(r.detach(), wd)
+            sol_t, _ = cg32(rhs_t)
+            if settings.rhs_refinement.on() and sol_t.dtype == torch.float32 and self.float64_product_available():
+                # mixed-precision refinement of the float32 solves on the sum operator too (round 6): float64 residual through the members' fused
+                # float64 products, one more float32 solve of it (bbmm.refine_with_) -- as the single-kernel and Kronecker operators do
+                from .bbmm import refine_with_
+
+                def solve32(res):
+                    d_, inf = cg32(res)
+                    return d_, inf.iterations
+
+                refine_with_(rhs_t.to(torch.float64), sol_t, self._matvec64(), solve32, settings.rhs_refinement.steps)
             sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
         if lhs is not None:
             sol = lhs @ sol

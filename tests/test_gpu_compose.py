@@ -291,3 +291,54 @@ def test_rq_gp_mll_bbmm_and_cholesky(dev):
                             float(m.covar_module.raw_outputscale.grad), float(lik.noise_covar.raw_noise.grad.sum())], dtype=torch.float64)
         want = torch.tensor([float(gref[0]) * sp(0.3), float(gref[1]) * sp(2.2), float(gref[2]) * sp(1.3), float(gref[3]) * sp(0.1 - 1e-4)], dtype=torch.float64)
         assert float((got - want).norm() / want.norm()) < tol_g, (branch, got, want)
+
+
+def test_rhs_refinement_on_the_additive_operator(dev):
+    """Round 6: ``settings.rhs_refinement`` on the SUM operator (round 5 had it on the single-kernel operator, round 6 on the Kronecker one): the
+    float32 mBCG solve of an ill-conditioned additive system is refined with a float64 residual through the members' fused float64 products, and
+    the exact predictive variance of f takes the variational quadratic form (one float64 product, no second solve).  Against dense float64."""
+    import gpytorch_amd as g
+
+    n, ns, d = 4000, 64, 2
+    X, y = make_data(n + ns, d)
+    X, y = X.float().double(), y.float().double()                  # the model's float32 inputs, exactly
+    Xt, yt, Xs = X[:n], y[:n], X[n:]
+
+    class M(g.models.ExactGP):
+        def __init__(self, x, yy, lik):
+            super().__init__(x, yy, lik)
+            self.mean_module = g.means.ZeroMean()
+            self.covar_module = g.kernels.ScaleKernel(g.kernels.RBFKernel()) + g.kernels.ScaleKernel(g.kernels.MaternKernel(nu=2.5))
+
+        def forward(self, x):
+            return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = g.likelihoods.GaussianLikelihood().to(dev)
+    m = M(Xt.float().to(dev), yt.float().to(dev), lik).to(dev)
+    ka, kb = m.covar_module.kernels
+    ka.base_kernel.lengthscale, ka.outputscale = 0.3, 1.0
+    kb.base_kernel.lengthscale, kb.outputscale = 0.8, 0.5
+    lik.noise = 1e-3                                               # kappa ~ 1e6: float32 solves stall near 1e-3
+    Kh = 1.0 * OK.rbf(Xt, Xt, 0.3, x1_eq_x2=True, direct=True) + 0.5 * OK.matern(Xt, Xt, 0.8, 2.5, x1_eq_x2=True, direct=True) + 1e-3 * torch.eye(n, dtype=torch.float64)
+    Ks = 1.0 * OK.rbf(Xs, Xt, 0.3, x1_eq_x2=False, direct=True) + 0.5 * OK.matern(Xs, Xt, 0.8, 2.5, x1_eq_x2=False, direct=True)
+    Lc = torch.linalg.cholesky(Kh)
+    sol_ref = torch.cholesky_solve(yt.unsqueeze(-1), Lc)
+    fvar_ref = 1.5 - (Ks * torch.cholesky_solve(Ks.t(), Lc).t()).sum(-1)
+    S = g.settings
+    op = lik(m.train()(Xt.float().to(dev))).lazy_covariance_matrix
+    assert op.float64_product_available()
+    V = torch.randn(n, 3, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    assert rel_err(op.matmul_float64(V.to(dev)), Kh @ V) < 1e-5      # (float64 arithmetic on the float32-PREPARED points: their rounding, 1e-7 in z, is what is left)
+    errs = {}
+    for refine in (False, True):
+        with torch.no_grad(), S.max_cholesky_size(0), S.cg_tolerance(1e-4), S.max_cg_iterations(4000), S.rhs_refinement(refine):
+            errs[refine] = rel_err(op.solve(yt.float().to(dev).unsqueeze(-1)), sol_ref)
+    assert errs[True] < 0.2 * errs[False] and errs[True] < 1e-4, errs
+    m.eval(), lik.eval()
+    verr = {}
+    for refine in (False, True):
+        m.train(), m.eval()
+        with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.cg_tolerance(1e-4), S.max_cg_iterations(4000), S.rhs_refinement(refine):
+            fvar = m(Xs.float().to(dev)).variance.double().cpu()
+        verr[refine] = float((fvar - fvar_ref).abs().max() / 1e-3)      # in units of the noise
+    assert verr[True] < 0.05 and verr[True] < verr[False], verr
