@@ -223,6 +223,37 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
             iq = iq.sum(-1)
         return iq, (ld if logdet else None)
 
+    # ---- float64 product on the prepared points of the float32 path (mixed-precision corrections: settings.rhs_refinement; round 6) ----
+    def float64_product_available(self) -> bool:
+        p1, _ = self.had.kx.prepared()
+        return bool(p1.fused and p1.dp <= B.FUSED_F64_MAX_DP)
+
+    def _matvec64(self):
+        """a64 [c, ld] (probe-major, float64) -> ((theta K_XX) o K_TT[i, i] + D) a in float64: ``hadamard_matvec`` on the prepared points widened to
+        float64 (the fused float64 product with T x columns, ``csrc/kv_f64.hpp``), groups of at most 80 / T columns."""
+        p1, _ = self.had.kx.prepared()
+        x64 = B.PreparedPoints(p1.xp.to(torch.float64), p1.n, p1.d, p1.dp, p1.kind, p1.param)
+        os_ = self.had.kx._os()
+        os64 = None if os_ is None else os_.detach().to(torch.float64)
+        ktt, ti = self.had.tasks.ktt.detach().to(torch.float64), self.had.tasks.i1
+        dv = self._dvec(torch.float64)
+        grp = max(1, 80 // ktt.shape[-1])
+
+        def mv(a64):
+            out = torch.empty_like(a64)
+            for c0 in range(0, a64.shape[0], grp):
+                blk = a64[c0 : c0 + grp].contiguous()
+                out[c0 : c0 + grp] = hadamard_matvec(x64, x64, os64, ktt, ti, ti, blk)[:, : blk.shape[1]] + dv.unsqueeze(0)[:, : blk.shape[1]] * blk
+            return out
+
+        return mv
+
+    def matmul_float64(self, rhs: torch.Tensor) -> torch.Tensor:
+        """K_hat @ rhs ([n, c] -> [n, c]) in float64 on the prepared points of the float32 path (``bbmm.variational_inv_quad``)."""
+        if not self.float64_product_available():
+            return None
+        return B.from_probe_major(self._matvec64()(B.to_probe_major(rhs.detach(), torch.float64)), self.shape[-1])
+
     def solve(self, rhs, lhs=None):
         squeeze = rhs.dim() == 1
         r = rhs.unsqueeze(-1) if squeeze else rhs
@@ -234,8 +265,22 @@ class HadamardFusedAddedDiagLinearOperator(LinearOperator):
             if not hasattr(self, "_precond_cache"):
                 p1, _ = self.had.kx.prepared()
                 self._precond_cache = hadamard_preconditioner(p1, self.had.kx._os(), self.had.tasks.ktt, self.had.tasks.i1, dv, self.shape[-1])
-            sol_t, _ = linear_cg(None, None, None, B.to_probe_major(r.detach(), wd), n_tridiag=0, tolerance=settings.cg_tolerance.value(),
+
+            def cg32(rt):
+                return linear_cg(None, None, None, rt, n_tridiag=0, tolerance=settings.cg_tolerance.value(),
                                  kv_partials=partials, dvec=dv, nvec=self.shape[-1], preconditioner=self._precond_cache)
+
+            rhs_t = B.to_probe_major(r.detach(), wd)
+            sol_t, _ = cg32(rhs_t)
+            if settings.rhs_refinement.on() and sol_t.dtype == torch.float32 and self.float64_product_available():
+                # mixed-precision refinement on the Hadamard operator too (round 6): float64 residual through hadamard_matvec on the widened points
+                from .bbmm import refine_with_
+
+                def solve32(res):
+                    d_, inf = cg32(res)
+                    return d_, inf.iterations
+
+                refine_with_(rhs_t.to(torch.float64), sol_t, self._matvec64(), solve32, settings.rhs_refinement.steps)
             sol = B.from_probe_major(sol_t, self.shape[-1]).to(rhs.dtype)
         if lhs is not None:
             sol = lhs @ sol

@@ -105,3 +105,37 @@ def test_hadamard_multitask_gp_mean_abs_error(dev):
             p2 = lik(m(test_x.to(dev), torch.ones(51, dtype=torch.long, device=dev))).mean
     assert float((torch.sin(test_x * 2 * math.pi).to(dev) - p1).abs().mean()) < 0.1
     assert float((torch.cos(test_x * 2 * math.pi).to(dev) - p2).abs().mean()) < 0.1
+
+
+def test_rhs_refinement_on_the_hadamard_operator(dev):
+    """Round 6: ``settings.rhs_refinement`` on the Hadamard (data kernel o task kernel of the observed tasks) operator: float64 residual through
+    ``hadamard_matvec`` on the prepared points widened to float64, one more float32 solve of it.  Ill-conditioned (noise 1e-3): the float32 mBCG solve
+    stalls near 1e-3 of the dense float64 solution; refined, it is an order of magnitude closer."""
+    import gpytorch_amd as g
+
+    n = 3000
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(n, 2, generator=gen)
+    i = torch.randint(0, 2, (n,), generator=gen)
+    y = torch.where(i == 0, torch.sin(4 * x[:, 0]), torch.cos(3 * x[:, 1])) + 0.05 * torch.randn(n, generator=gen)
+    m, lik = _model(g, x, i, y, dev)
+    Bf = torch.tensor([[0.9], [-0.4]])
+    v = torch.tensor([0.3, 0.5])
+    m.covar_module.lengthscale = 0.35
+    with torch.no_grad():
+        m.task_covar_module.covar_factor.copy_(Bf)
+    m.task_covar_module.var = v
+    lik.noise = 1e-3
+    op = lik(m.train()(*m.train_inputs)).lazy_covariance_matrix
+    ktt = (Bf @ Bf.t() + torch.diag(v)).double()
+    Kh = OK.rbf(x.double(), x.double(), 0.35, x1_eq_x2=True, direct=True) * ktt[i][:, i] + 1e-3 * torch.eye(n, dtype=torch.float64)
+    assert op.float64_product_available()
+    V = torch.randn(n, 3, generator=gen, dtype=torch.float64)
+    assert rel_err(op.matmul_float64(V.to(dev)), Kh @ V) < 1e-5
+    sol_ref = torch.linalg.solve(Kh, y.double().unsqueeze(-1))
+    S = g.settings
+    errs = {}
+    for refine in (False, True):
+        with torch.no_grad(), S.max_cholesky_size(0), S.cg_tolerance(1e-4), S.max_cg_iterations(4000), S.rhs_refinement(refine):
+            errs[refine] = rel_err(op.solve(y.to(dev).unsqueeze(-1)), sol_ref)
+    assert errs[True] < 0.2 * errs[False] and errs[True] < 2e-4, errs
