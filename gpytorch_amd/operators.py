@@ -980,9 +980,37 @@ class FusedKernelAddedDiagLinearOperator(LinearOperator):
         n = self.shape[-1]
         rhs_loc = rs.local(B.to_probe_major(r.detach()))
         self._preconditioner()  # the reference default has one (max_preconditioner_size = 15): built replicated, applied row-sharded
-        sol_loc, info = linear_cg(None, self.kernel_op._os(), self._nz(), rhs_loc, n_tridiag=0, tolerance=settings.cg_tolerance.value(),
-                                  dvec=self._dvec_local(rs), row_shard=rs, preconditioner=self._cache["precond"])
+        os_, nz, dvl = self.kernel_op._os(), self._nz(), self._dvec_local(rs)
+
+        def cg32(rt):
+            return linear_cg(None, os_, nz, rt, n_tridiag=0, tolerance=settings.cg_tolerance.value(),
+                             dvec=dvl, row_shard=rs, preconditioner=self._cache["precond"])
+
+        sol_loc, info = cg32(rhs_loc)
         self._cache["last_cg_info"] = info
+        if settings.rhs_refinement.on() and sol_loc.dtype == torch.float32 and self.float64_product_available():
+            # mixed-precision refinement of the row-sharded solve (round 6): the float64 residual of this rank's rows from ONE rectangular fused
+            # float64 product (local rows x all columns, the search directions all-gathered in float64), one more sharded float32 solve of it
+            from .bbmm import refine_with_
+
+            x_loc64 = B.PreparedPoints(rs.x_loc.xp.to(torch.float64), rs.x_loc.n, rs.x_loc.d, rs.x_loc.dp, rs.x_loc.kind, rs.x_loc.param)
+            x_all64 = B.PreparedPoints(rs.x_all.xp.to(torch.float64), rs.x_all.n, rs.x_all.d, rs.x_all.dp, rs.x_all.kind, rs.x_all.param)
+            os64 = None if os_ is None else os_.detach().to(torch.float64)
+            nz64 = None if nz is None else nz.detach().to(torch.float64)
+            dv64 = None if dvl is None else dvl.to(torch.float64)
+
+            def mv64(a64):
+                out = torch.empty_like(a64)
+                for c0 in range(0, a64.shape[0], 80):
+                    blk = a64[c0 : c0 + 80].contiguous()
+                    out[c0 : c0 + 80] = B.kv(x_loc64, x_all64, rs.gather(blk), scale=os64, dscale=nz64, vd=blk, dvec=dv64)
+                return out
+
+            def solve32(res):
+                d_, inf = cg32(res)
+                return d_, inf.iterations
+
+            refine_with_(rhs_loc.to(torch.float64), sol_loc, mv64, solve32, settings.rhs_refinement.steps)
         return B.from_probe_major(rs.gather(sol_loc), n)
 
     def _root_inv_row_sharded(self, init_t):

@@ -232,7 +232,7 @@ def _collect(q, procs, world, budget=240.0):
     return sorted(results, key=lambda r: r[0])
 
 
-def _row_worker(rank, world, port, q, fixed_noise, precond=0):
+def _row_worker(rank, world, port, q, fixed_noise, precond=0, refine=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -241,13 +241,13 @@ def _row_worker(rank, world, port, q, fixed_noise, precond=0):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
-    mu, var, info = _posterior(g, dev, fixed_noise, dist.group.WORLD, precond)
+    mu, var, info = _posterior(g, dev, fixed_noise, dist.group.WORLD, precond, refine)
     q.put((rank, mu.cpu().numpy(), var.cpu().numpy(), info))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _posterior(g, dev, fixed_noise, row_group, precond=0):
+def _posterior(g, dev, fixed_noise, row_group, precond=0, refine=False):
     n, ns, d = 1501, 257, 3  # n not divisible by the world size or by 4: ragged last shard
     X, y = make_data(n, d)
     Xs = torch.rand(ns, d, generator=torch.Generator().manual_seed(9))
@@ -276,7 +276,7 @@ def _posterior(g, dev, fixed_noise, row_group, precond=0):
     S = g.settings
     torch.manual_seed(77)  # the Lanczos start vector of the LOVE cache comes from the default generator (rank 0's, when sharded)
     with torch.no_grad(), S.max_cholesky_size(0), S.eval_cg_tolerance(1e-4), S.fast_pred_var(), S.max_root_decomposition_size(500), \
-            S.max_preconditioner_size(precond), S.min_preconditioning_size(100), S.sharding(row_group=row_group):
+            S.max_preconditioner_size(precond), S.min_preconditioning_size(100), S.sharding(row_group=row_group), S.rhs_refinement(refine):
         mu = m(Xs.to(dev)).mean  # mean-cache CG (the most recent solve: LOVE below is Lanczos only)
         from gpytorch_amd import linear_cg as LCG
 
@@ -285,23 +285,24 @@ def _posterior(g, dev, fixed_noise, row_group, precond=0):
     return mu, var, iters
 
 
-@pytest.mark.parametrize("world,fixed_noise,precond", [(2, False, 0), (3, True, 0), (2, False, 15)])
-def test_row_sharded_posterior_on_device(world, fixed_noise, precond, dev):
+@pytest.mark.parametrize("world,fixed_noise,precond,refine", [(2, False, 0, False), (3, True, 0, False), (2, False, 15, False), (2, True, 15, True)])
+def test_row_sharded_posterior_on_device(world, fixed_noise, precond, refine, dev):
     """the small-t solves of the predictive posterior (mean-cache CG, LOVE Lanczos) with every rank owning
     a block of ROWS of K_hat.  `world` processes share cuda:0 (gloo carries the all-gathers of the search directions and the
     per-iteration all-reduces of the solver's partial sums): same CG iteration count, mean and LOVE variance as the
     single-process run, on every rank.  precond = 15: the reference-default pivoted-Cholesky preconditioner, built replicated and
-    applied row-sharded (its k x t coefficients all-reduced per apply)."""
+    applied row-sharded (its k x t coefficients all-reduced per apply).  refine: ``settings.rhs_refinement`` on the sharded solve (round 6: the float64
+    residual of a rank's rows from one rectangular fused float64 product) against the refined single-process solve."""
     import gpytorch_amd as g
 
     port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_row_worker, args=(r, world, port, q, fixed_noise, precond)) for r in range(world)]
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, q, fixed_noise, precond, refine)) for r in range(world)]
     for p in procs:
         p.start()
     results = _collect(q, procs, world)
-    mu, var, iters = _posterior(g, dev, fixed_noise, None, precond)
+    mu, var, iters = _posterior(g, dev, fixed_noise, None, precond, refine)
     mu, var = mu.cpu(), var.cpu()
     assert iters > (3 if precond else 10)
     assert float(var.min()) > 1e-4  # the single-process LOVE variances are themselves converged (nothing clipped)
