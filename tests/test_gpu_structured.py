@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # ------------------------------------------------------------------------------------------------ additive, two RQ members
-def _additive_rq_model(g, X, y, dev):
+def _additive_rq_model(g, X, y, dev, dtype=torch.float32):
     class M(g.models.ExactGP):
         def __init__(self, x, yy, lik):
             super().__init__(x, yy, lik)
@@ -38,7 +38,9 @@ def _additive_rq_model(g, X, y, dev):
             return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
 
     lik = g.likelihoods.GaussianLikelihood().to(dev)
-    m = M(X.float().to(dev), y.float().to(dev), lik).to(dev)
+    m = M(X.to(dtype).to(dev), y.to(dtype).to(dev), lik).to(dev)
+    if dtype == torch.float64:
+        m, lik = m.double(), lik.double()
     ka, kb = m.covar_module.kernels
     ka.base_kernel.lengthscale, ka.base_kernel.alpha, ka.outputscale = 0.25, 0.7, 1.1
     kb.base_kernel.lengthscale, kb.base_kernel.alpha, kb.outputscale = 0.9, 2.5, 0.4
@@ -46,15 +48,16 @@ def _additive_rq_model(g, X, y, dev):
     return m, lik
 
 
-@pytest.mark.parametrize("precond", [0, 30])
-def test_additive_of_two_rq_kernels_with_different_alpha(precond, dev):
+@pytest.mark.parametrize("precond,dtype", [(0, torch.float32), (30, torch.float32), (30, torch.float64)], ids=["f32-0", "f32-30", "f64-30"])
+def test_additive_of_two_rq_kernels_with_different_alpha(precond, dtype, dev):
     """ScaleKernel(RQ, alpha = 0.7) + ScaleKernel(RQ, alpha = 2.5) on the BBMM path: value and EVERY gradient (both lengthscales, both
-    alphas, both outputscales, the noise) against dense float64 autograd; with and without the row-built preconditioner."""
+    alphas, both outputscales, the noise) against dense float64 autograd; with and without the row-built preconditioner.  float64 (round 6): the
+    members of a STRUCTURED operator on the generic path -- fused float64 products, the shape-parameter sums from the row-block derivative."""
     import gpytorch_amd as g
 
     n, d = 1800, 2
     X, y = make_data(n, d)
-    m, lik = _additive_rq_model(g, X, y, dev)
+    m, lik = _additive_rq_model(g, X, y, dev, dtype)
     ka, kb = m.covar_module.kernels
     mll = g.ExactMarginalLogLikelihood(lik, m)
     m.train()
@@ -316,3 +319,97 @@ def test_multitask_mll_probe_sharded_over_two_ranks(dev):
                       (gref[3] * sg(MT["tn"] - 1e-4)).reshape(-1)])
     got = torch.tensor(g0, dtype=torch.float64)
     assert float((got - want).norm() / want.norm()) < 0.15, (got, want)
+
+
+# ------------------------------------------------------------------------------------------------ RQ members in float64 (round 6)
+@pytest.mark.parametrize("structure", ["kronecker", "hadamard"])
+def test_rq_data_kernel_in_float64_on_the_structured_operators(structure, dev):
+    """Round 5 left "RQ members of the structured operators in float64" open.  A float64 model with an RQ data kernel under the Kronecker multitask
+    operator and under the Hadamard (observed-task) operator, BBMM branch with a COMPLETE probe basis (exact trace): value and the gradients with
+    respect to lengthscale and alpha against dense float64 autograd."""
+    import gpytorch_amd as g
+
+    S = g.settings
+    ls, alpha = 0.4, 1.3
+    gen = torch.Generator().manual_seed(3)
+    if structure == "kronecker":
+        n, T = 120, 2
+        X = torch.rand(n, 2, generator=gen, dtype=torch.float64)
+        Y = torch.stack([torch.sin(4 * X[:, 0]), torch.cos(3 * X[:, 1])], -1) + 0.1 * torch.randn(n, T, generator=gen, dtype=torch.float64)
+        Bf, v, tn = torch.tensor([[0.8], [-0.5]], dtype=torch.float64), torch.tensor([0.4, 0.6], dtype=torch.float64), torch.tensor([0.05, 0.1], dtype=torch.float64)
+
+        class MT(g.models.ExactGP):
+            def __init__(self, x, y, lik):
+                super().__init__(x, y, lik)
+                self.mean_module = g.means.MultitaskMean(g.means.ZeroMean(), num_tasks=T)
+                self.covar_module = g.kernels.MultitaskKernel(g.kernels.RQKernel(), num_tasks=T, rank=1)
+
+            def forward(self, x):
+                return g.distributions.MultitaskMultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+        lik = g.likelihoods.MultitaskGaussianLikelihood(num_tasks=T, has_global_noise=False).to(dev).double()
+        m = MT(X.to(dev), Y.to(dev), lik).to(dev).double()
+        kx = m.covar_module.data_covar_module
+        kx.lengthscale, kx.alpha = ls, alpha
+        with torch.no_grad():
+            m.covar_module.task_covar_module.covar_factor.copy_(Bf)
+        m.covar_module.task_covar_module.var = v
+        lik.task_noises = tn
+        N = n * T
+        args, target = (m.train_inputs[0],), m.train_targets
+
+        def dense(p_ls, p_a):
+            Kx = OK.rq(X, X, p_ls, p_a, x1_eq_x2=True, direct=True)
+            return torch.kron(Kx, Bf @ Bf.t() + torch.diag(v)) + torch.diag(tn.repeat(n)), Y.reshape(-1)
+    else:
+        n = 300
+        X = torch.rand(n, 2, generator=gen, dtype=torch.float64)
+        idx = torch.randint(0, 2, (n,), generator=gen)
+        yv = torch.where(idx == 0, torch.sin(4 * X[:, 0]), torch.cos(3 * X[:, 1])) + 0.1 * torch.randn(n, generator=gen, dtype=torch.float64)
+        Bf, v = torch.tensor([[0.9], [-0.4]], dtype=torch.float64), torch.tensor([0.3, 0.5], dtype=torch.float64)
+
+        class HM(g.models.ExactGP):
+            def __init__(self, train_x, train_y, likelihood):
+                super().__init__(train_x, train_y, likelihood)
+                self.mean_module = g.means.ZeroMean()
+                self.covar_module = g.kernels.RQKernel()
+                self.task_covar_module = g.kernels.IndexKernel(num_tasks=2, rank=1)
+
+            def forward(self, x, i):
+                return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x).mul(self.task_covar_module(i)))
+
+        lik = g.likelihoods.GaussianLikelihood().to(dev).double()
+        m = HM((X.to(dev), idx.to(dev)), yv.to(dev), lik).to(dev).double()
+        kx = m.covar_module
+        kx.lengthscale, kx.alpha = ls, alpha
+        with torch.no_grad():
+            m.task_covar_module.covar_factor.copy_(Bf)
+        m.task_covar_module.var = v
+        lik.noise = 0.1
+        N = n
+        args, target = m.train_inputs, m.train_targets
+
+        def dense(p_ls, p_a):
+            Kx = OK.rq(X, X, p_ls, p_a, x1_eq_x2=True, direct=True)
+            return Kx * (Bf @ Bf.t() + torch.diag(v))[idx][:, idx] + 0.1 * torch.eye(n, dtype=torch.float64), yv
+
+    mll = g.ExactMarginalLogLikelihood(lik, m)
+    m.train(), lik.train()
+    S.deterministic_probes.probe_vectors = math.sqrt(N) * torch.eye(N, dtype=torch.float64)
+    try:
+        with S.max_cholesky_size(0), S.cg_tolerance(1e-6), S.deterministic_probes(True), S.max_preconditioner_size(0), S.max_lanczos_quadrature_iterations(80):
+            val = mll(m(*args), target)
+            val.backward()
+    finally:
+        S.deterministic_probes.probe_vectors = None
+    p_ls = torch.tensor(ls, dtype=torch.float64, requires_grad=True)
+    p_a = torch.tensor(alpha, dtype=torch.float64, requires_grad=True)
+    Kh, yy = dense(p_ls, p_a)
+    ref = OG.dense_log_prob(Kh, yy) / N
+    g_ls, g_a = torch.autograd.grad(ref, [p_ls, p_a])
+    assert val.dtype == torch.float64
+    assert abs(float(val) - float(ref)) < 5e-3 * max(1.0, abs(float(ref))), (float(val), float(ref))     # (SLQ value on an exact probe basis: Lanczos steps)
+    sp = lambda t_: 1.0 - math.exp(-t_)  # noqa: E731
+    got_ls, got_a = float(kx.raw_lengthscale.grad.sum()), float(kx.raw_alpha.grad.sum())
+    assert abs(got_ls - float(g_ls) * sp(ls)) < 2e-2 * abs(float(g_ls) * sp(ls)) + 1e-5, (got_ls, float(g_ls) * sp(ls))
+    assert abs(got_a - float(g_a) * sp(alpha)) < 2e-2 * abs(float(g_a) * sp(alpha)) + 1e-5, (got_a, float(g_a) * sp(alpha))
