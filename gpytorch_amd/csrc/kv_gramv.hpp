@@ -110,6 +110,28 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
               acc2[ni][0] = __builtin_elementwise_fma(kv, vv, acc2[ni][0]);
             }
           }
+        } else if constexpr (T == 2 && KIND != KIND_RBF) {
+          // TWO columns (four and more keep the scalar form: with two more operand pairs live the allocator gave up a resident wave at d = 10), families with more than one transcendental per pair (Matern: v_sqrt + v_exp + a polynomial; RQ: v_log + v_exp): two
+          // j rows per call of the PAIR form, whose arithmetic around the transcendentals is packed (common.hpp cov_pair_from_sq; round 6 -- until then
+          // only the one-column variant used it: 36 -> ~28 issue cycles per pair at two columns, the fused solve + Lanczos product of the prediction caches)
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            f32x2 vp0[TP], vp1[TP];
+#pragma unroll
+            for (int c = 0; c < TP; ++c) {
+              vp0[c] = *reinterpret_cast<const f32x2*>(&Vs[(jl + e) * T + 2 * c]);
+              vp1[c] = *reinterpret_cast<const f32x2*>(&Vs[(jl + e + 1) * T + 2 * c]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const f32x2 kv = cov_pair_from_sq<KIND>((f32x2){kk[ni][4 * g + e], kk[ni][4 * g + e + 1]}, a.kparam);
+#pragma unroll
+              for (int c = 0; c < TP; ++c) {
+                acc2[ni][c] = __builtin_elementwise_fma((f32x2)(kv[0]), vp0[c], acc2[ni][c]);
+                acc2[ni][c] = __builtin_elementwise_fma((f32x2)(kv[1]), vp1[c], acc2[ni][c]);
+              }
+            }
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
