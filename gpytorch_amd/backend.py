@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -270,6 +271,19 @@ class SortedView:
 
 
 REGION_MERGE_MAX_ROWS = 4096   # kv_partials_sorted: medium + wide rows up to this many share ONE direct-difference launch
+# kv_partials_sorted: the region launches of a block-centred product (medium / wide rows: a few per cent of the rows on launches that cannot fill
+# the chip) go to a SECOND HIP stream and run beside the compact launch instead of behind it -- fork at the start of the product, join before the
+# slabs are read (GPAMD_REGION_STREAMS=0: one stream, the round-5 order; off under stream capture and under far-pair culling, whose tile-list
+# workspace the launches share)
+REGION_STREAMS = os.environ.get("GPAMD_REGION_STREAMS", "1") != "0"
+_side_streams: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    return s
 FAR_FEW_MAX_KEPT = 0.3   # far-pair culling: products of fewer than five columns move to the (culled) split kernels below this surviving share of tiles
 FAR_MIN_POINTS = 1024   # far-pair culling: smaller clouds are launch-bound, the two extra gathers per product would cost more than any tile saves
 
@@ -454,6 +468,8 @@ def workspace(device, nfloats: int, slot: int = 0) -> torch.Tensor:
     key = (device.type, device.index, slot)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
+        if buf is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)   # the buffer being dropped may still be read on another stream than the allocating one (region streams)
         buf = torch.empty(max(nfloats, 1 << 20), device=device, dtype=torch.float32)
         _ws_cache[key] = buf
     return buf
@@ -558,13 +574,30 @@ def kv_partials_sorted(x1: PreparedPoints, x2: PreparedPoints, vt: torch.Tensor,
         X2 = sv2.xs
         vt = vt.index_select(1, sv2.perm_pad)
         cull = (sq, sv1, sv2)
+    def regions(st_r):
+        if n_b > n_c:
+            _kv_region(x1, x2, X1, Xc, n_c, n_b - n_c, flags | KV_BLOCK128, vt, t, P, ldo, S, jc, done_ptr, st_r, 1, "medium rows", X2, cull)
+        if n_b < x1.n:
+            wflags = (flags & (KV_SPLIT | KV_SPLIT_FEW)) if ((flags & KV_SPLIT) and x1.d <= DIRECT_SPLIT_MAX_DIM) else 0   # direct differences (+ the split contraction, kv_directh.hpp)
+            _kv_region(x1, x2, X1, None, n_b, x1.n - n_b, wflags, vt, t, P, ldo, S, jc, done_ptr, st_r, 2, "wide rows", X2, cull)
+
+    main = torch.cuda.current_stream(vt.device)
+    if (REGION_STREAMS and n_c and n_c < x1.n and cull is None and st is not None and (st.value or 0) == main.cuda_stream
+            and not torch.cuda.is_current_stream_capturing()):
+        # fork: the region launches (own workspaces, their own rows of the shared slabs) on the side stream, issued FIRST so that their short
+        # workgroups take their slots while the compact launch's pre-pass runs; join before anything reads the slabs.  In-order side stream:
+        # the region workspaces of consecutive products never overlap; P's region rows were last read by the previous product's reduction,
+        # which precedes the fork on the main stream.
+        side = _side_stream(vt.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            regions(C.c_void_p(side.cuda_stream))
+        _kv_launch(x1, x2, _ptr(X1), n_c, X2, _ptr(Xc), vt, t, _ptr(P), ldo, S, jc, flags, done_ptr, st, cull, 0, "kv_partials")
+        main.wait_stream(side)
+        return unsort
     if n_c:
         _kv_launch(x1, x2, _ptr(X1), n_c, X2, _ptr(Xc), vt, t, _ptr(P), ldo, S, jc, flags, done_ptr, st, cull, 0, "kv_partials")
-    if n_b > n_c:
-        _kv_region(x1, x2, X1, Xc, n_c, n_b - n_c, flags | KV_BLOCK128, vt, t, P, ldo, S, jc, done_ptr, st, 1, "medium rows", X2, cull)
-    if n_b < x1.n:
-        wflags = (flags & (KV_SPLIT | KV_SPLIT_FEW)) if ((flags & KV_SPLIT) and x1.d <= DIRECT_SPLIT_MAX_DIM) else 0   # direct differences (+ the split contraction, kv_directh.hpp)
-        _kv_region(x1, x2, X1, None, n_b, x1.n - n_b, wflags, vt, t, P, ldo, S, jc, done_ptr, st, 2, "wide rows", X2, cull)
+    regions(st)
     return unsort
 
 

@@ -68,11 +68,16 @@ int gpamd_lanczos_normalize_f32(const float* r, int n, const float* rr, float* o
 }
 
 // ---- preconditioner coefficients W = R Q1^T in mixed precision (lanczos_kernels.hpp: pc_coef_kernel) ----
+// slices of the row index (one workgroup and one partial each): >= 128 elements per workgroup, at most 256 slices.  (Round 6: 256 elements until then --
+// at n = 36 584 each of 143 workgroups ran eight load -> barrier -> compute rounds, latency end to end; five rounds on 229 workgroups now.)
+static long pc_slices(int n) {
+  long nb = ((long)n + 127) / 128;
+  return nb > 256 ? 256 : (nb < 1 ? 1 : nb);
+}
+constexpr long PC_SMALL_GRID = 384;   // fewer workgroups than this (1.5 per CU) in the 128-row-tile form: the 32-row-tile form (four times as many)
 int64_t gpamd_precond_coef_workspace_doubles(int n, int t, int k) {
   if (n <= 0 || t <= 0 || k <= 0) return 0;
-  long nb = ((long)n + 255) / 256;   // >= 256 elements per workgroup: small n still spreads over several CUs
-  if (nb > 256) nb = 256;
-  return (int64_t)nb * t * k;
+  return (int64_t)pc_slices(n) * t * k;
 }
 
 int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* Q, int64_t ldq, int k, int n, double* W,
@@ -80,8 +85,7 @@ int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* 
   if (!R || !Q || !W || !workspace || n <= 0 || t <= 0 || k <= 0 || ldr < n || ldq < n) return lz_fail("precond_coef: bad arguments");
   if (k > 512) return lz_fail("precond_coef: rank > 512");
   const unsigned ktiles = (unsigned)((k + 16 * PC_MT - 1) / (16 * PC_MT));   // 128 basis rows per blockIdx.y
-  long nb = ((long)n + 255) / 256;   // >= 256 elements per workgroup: small n still spreads over several CUs
-  if (nb > 256) nb = 256;
+  long nb = pc_slices(n);
   if (workspace_doubles < (int64_t)nb * t * k) return GPAMD_EWORKSPACE;
   const int slice = (int)(((long)n + nb - 1) / nb + PC_CHUNK - 1) / PC_CHUNK * PC_CHUNK;
   nb = ((long)n + slice - 1) / slice;
@@ -89,11 +93,13 @@ int gpamd_precond_coef_f32f64(const float* R, int64_t ldr, int t, const double* 
   for (int c0 = 0; c0 < t; c0 += 80) {   // column groups of <= 80 (16 x 5 register tile)
     const int tg = t - c0 < 80 ? t - c0 : 80;
     double* part = workspace;             // reused per group: the sum kernel of a group runs before the next group's partials
-    if (tg <= 16)
+    if (tg <= 16 && nb * ktiles < PC_SMALL_GRID)
+      hipLaunchKernelGGL((pc_coef_kernel<1, double, float, 2>), dim3((unsigned)nb, (unsigned)((k + 31) / 32)), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
+    else if (tg <= 16)
       hipLaunchKernelGGL((pc_coef_kernel<1>), dim3((unsigned)nb, ktiles), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
     else
       hipLaunchKernelGGL((pc_coef_kernel<5>), dim3((unsigned)nb, ktiles), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice, part);
-    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((4 * tg * k + 255) / 256), dim3(256), 0, st, (const double*)part, (int)nb, tg * k, W + (int64_t)c0 * k);
+    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((PC_SUM_LANES * tg * k + 255) / 256), dim3(256), 0, st, (const double*)part, (int)nb, tg * k, W + (int64_t)c0 * k);
   }
   return lz_check("precond_coef");
 }
@@ -123,9 +129,13 @@ int block_project(const TQ* Q, int64_t ldq, int k, const TR* R, int64_t ldr, int
   nb = ((long)n + slice - 1) / slice;
   for (int c0 = 0; c0 < b; c0 += 16) {
     const int tg = b - c0 < 16 ? b - c0 : 16;
-    hipLaunchKernelGGL((pc_coef_kernel<1, TQ, TR>), dim3((unsigned)nb, (unsigned)((k + 16 * PC_MT - 1) / (16 * PC_MT))), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg,
-                       Q, ldq, k, n, slice, workspace);
-    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((4 * tg * k + 255) / 256), dim3(256), 0, st, (const double*)workspace, (int)nb, tg * k, W + (int64_t)c0 * k);
+    if (nb * ((k + 16 * PC_MT - 1) / (16 * PC_MT)) < PC_SMALL_GRID)   // few workgroups: 32-row basis tiles (lanczos_kernels.hpp, MT = 2; bitwise the same sums)
+      hipLaunchKernelGGL((pc_coef_kernel<1, TQ, TR, 2>), dim3((unsigned)nb, (unsigned)((k + 31) / 32)), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg, Q, ldq, k, n, slice,
+                         workspace);
+    else
+      hipLaunchKernelGGL((pc_coef_kernel<1, TQ, TR>), dim3((unsigned)nb, (unsigned)((k + 16 * PC_MT - 1) / (16 * PC_MT))), dim3(256), 0, st, R + (int64_t)c0 * ldr, ldr, tg,
+                         Q, ldq, k, n, slice, workspace);
+    hipLaunchKernelGGL(pc_coef_sum_kernel, dim3((PC_SUM_LANES * tg * k + 255) / 256), dim3(256), 0, st, (const double*)workspace, (int)nb, tg * k, W + (int64_t)c0 * k);
   }
   return lz_check("block_project");
 }

@@ -124,68 +124,73 @@ constexpr int PC_MT = 8;      // 128 basis rows per tile (blockIdx.y of pc_coef_
 // TQ / TR: types of the basis rows and of the projected rows (double / float: the preconditioner's Q1 against float32 residuals; float / float: the Lanczos
 // basis of the block recurrences below and the Gram matrix of the pivoted-Cholesky factor; double / double: the second Cholesky-QR pass of the preconditioner).  blockIdx.y selects a
 // tile of 128 basis rows, so k is unbounded for callers that launch a second grid dimension (the preconditioner launches one: k <= 128).
-template <int CT, typename TQ = double, typename TR = float>  // t <= 16 * CT
+// MT: basis rows per thread (16 MT per blockIdx.y tile).  8 for long slices; 2 for SMALL n (round 6): at n = 36 584 the 8-row form is 143 workgroups of eight
+// load -> barrier -> compute rounds each (59 us for 80 Mflop, 23 applies per protein-shaped closure) -- a quarter of the tile gives four times the
+// workgroups with a quarter of the staging per round.  Every W[c][m] is the same sum in the same order whatever MT: bitwise equal results.
+template <int CT, typename TQ = double, typename TR = float, int MT = 8>  // t <= 16 * CT
 __global__ __launch_bounds__(256) void pc_coef_kernel(const TR* __restrict__ R, int64_t ldr, int t, const TQ* __restrict__ Q,
                                                       int64_t ldq, int k, int n, int slice, double* __restrict__ part) {
   __shared__ TR Rs[16 * CT][PC_CHUNK + 1];
-  __shared__ TQ Qs[16 * PC_MT][PC_CHUNK + 1];
+  __shared__ TQ Qs[16 * MT][PC_CHUNK + 1];
   const int tid = threadIdx.x, tc = tid >> 4, tm = tid & 15;
   const int i0 = blockIdx.x * slice, i1 = min(n, i0 + slice);
-  const int m0 = blockIdx.y * (16 * PC_MT), kt = min(16 * PC_MT, k - m0);   // this block's basis rows [m0, m0 + kt)
-  double acc[CT][PC_MT];
+  const int m0 = blockIdx.y * (16 * MT), kt = min(16 * MT, k - m0);   // this block's basis rows [m0, m0 + kt)
+  double acc[CT][MT];
 #pragma unroll
   for (int a = 0; a < CT; ++a)
 #pragma unroll
-    for (int b = 0; b < PC_MT; ++b) acc[a][b] = 0.0;
+    for (int b = 0; b < MT; ++b) acc[a][b] = 0.0;
   for (int ib = i0; ib < i1; ib += PC_CHUNK) {
     __syncthreads();
     for (int e = tid; e < 16 * CT * PC_CHUNK; e += 256) {
       const int c = e / PC_CHUNK, ii = e % PC_CHUNK;
       Rs[c][ii] = (c < t && ib + ii < i1) ? R[(int64_t)c * ldr + ib + ii] : TR(0);
     }
-    for (int e = tid; e < 16 * PC_MT * PC_CHUNK; e += 256) {
+    for (int e = tid; e < 16 * MT * PC_CHUNK; e += 256) {
       const int m = e / PC_CHUNK, ii = e % PC_CHUNK;
       Qs[m][ii] = (m < kt && ib + ii < i1) ? Q[(int64_t)(m0 + m) * ldq + ib + ii] : TQ(0);
     }
     __syncthreads();
 #pragma unroll 4
     for (int ii = 0; ii < PC_CHUNK; ++ii) {
-      double rv[CT], qv[PC_MT];
+      double rv[CT], qv[MT];
 #pragma unroll
       for (int a = 0; a < CT; ++a) rv[a] = (double)Rs[tc + 16 * a][ii];
 #pragma unroll
-      for (int b = 0; b < PC_MT; ++b) qv[b] = (double)Qs[tm + 16 * b][ii];
+      for (int b = 0; b < MT; ++b) qv[b] = (double)Qs[tm + 16 * b][ii];
 #pragma unroll
       for (int a = 0; a < CT; ++a)
 #pragma unroll
-        for (int b = 0; b < PC_MT; ++b) acc[a][b] = fma(rv[a], qv[b], acc[a][b]);
+        for (int b = 0; b < MT; ++b) acc[a][b] = fma(rv[a], qv[b], acc[a][b]);
     }
   }
   double* out = part + (int64_t)blockIdx.x * t * k;
 #pragma unroll
   for (int a = 0; a < CT; ++a)
 #pragma unroll
-    for (int b = 0; b < PC_MT; ++b) {
+    for (int b = 0; b < MT; ++b) {
       const int c = tc + 16 * a, m = tm + 16 * b;
       if (c < t && m < kt) out[(int64_t)c * k + m0 + m] = acc[a][b];
     }
 }
 
-// W[e] = sum_b part[b][e]     (e < t * k).  Four consecutive lanes share an element: lane q takes the partials b = q, q + 4, .. in order and the four
-// running sums are combined in a fixed order (bitwise reproducible); the loads of a wave still cover 16 consecutive elements per b (128 contiguous
+// W[e] = sum_b part[b][e]     (e < t * k).  PC_SUM_LANES consecutive lanes share an element: lane q takes the partials b = q, q + LANES, .. in order and the
+// running sums are combined in a fixed order (bitwise reproducible); the loads of a wave cover 8 consecutive elements per b (64 contiguous
 // bytes).  Round 6: with one thread walking all nb <= 256 partials of its element the kernel took 35 us whatever the size -- 1.3 ms of a
 // protein-shaped closure's 23 preconditioner applies (profiles/r05_s6_workload_protein_kernel_stats.csv); a quarter of the dependent loads now.
+constexpr int PC_SUM_LANES = 8;   // lanes per element (4 until the slices went down to 128 elements: up to 256 partials per element, 32 dependent loads per lane now)
 __global__ void pc_coef_sum_kernel(const double* __restrict__ part, int nb, int tk, double* __restrict__ W) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int e = gid >> 2, q = gid & 3;
+  const int e = gid / PC_SUM_LANES, q = gid % PC_SUM_LANES;
   double s = 0.0;
   if (e < tk)
-    for (int b = q; b < nb; b += 4) s += part[(int64_t)b * tk + e];
+    for (int b = q; b < nb; b += PC_SUM_LANES) s += part[(int64_t)b * tk + e];
   // (all 64 lanes take part in the shuffles; lanes of elements past the end carry zeros)
-  double o = __shfl_xor(s, 1, 64);
-  s = (q & 1) ? o + s : s + o;        // both lanes of a pair form the same sum: lower lane's value first
-  o = __shfl_xor(s, 2, 64);
-  s = (q & 2) ? o + s : s + o;
+#pragma unroll
+  for (int w = 1; w < PC_SUM_LANES; w <<= 1) {
+    const double o = __shfl_xor(s, w, 64);
+    s = (q & w) ? o + s : s + o;        // both lanes of a pair form the same sum: lower lane's value first
+  }
   if (e < tk && q == 0) W[e] = s;
 }
 
@@ -211,7 +216,19 @@ __global__ __launch_bounds__(256) void pc_apply_kernel(const float* __restrict__
     for (int e = threadIdx.x; e < nc * kt; e += 256) Ws[(e / kt) * (16 * PC_MT) + (e % kt)] = W[(int64_t)(c0 + e / kt) * k + m0 + (e % kt)];
     __syncthreads();
     if (i < n) {
-      for (int m = 0; m < kt; ++m) {
+      // eight basis rows per round: their loads are issued together (round 6 -- one load, then its 16 multiply-adds, row after row, was a chain of
+      // k memory latencies per wave: 30 us at n = 36 584 where one wave per SIMD has nothing to hide them behind); the sums keep their order
+      int m = 0;
+      for (; m + 8 <= kt; m += 8) {
+        double q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = Q[(int64_t)(m0 + m + u) * ldq + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int c = 0; c < PA_CT; ++c) acc[c] = fma(Ws[c * (16 * PC_MT) + m + u], q[u], acc[c]);
+      }
+      for (; m < kt; ++m) {
         const double q = Q[(int64_t)(m0 + m) * ldq + i];
 #pragma unroll
         for (int c = 0; c < PA_CT; ++c) acc[c] = fma(Ws[c * (16 * PC_MT) + m], q, acc[c]);

@@ -378,6 +378,38 @@ def test_a_few_medium_and_wide_rows_share_one_direct_launch(split, dev, monkeypa
         assert rel_err(merged, ref) < 2e-5 and rel_err(three, ref) < 2e-5, (t, rel_err(merged, ref), rel_err(three, ref))
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "split"])
+def test_region_launches_beside_the_compact_launch_are_bitwise_the_single_stream_product(split, dev, monkeypatch):
+    """Round 6.  The medium / wide region launches of a block-centred product run on a second HIP stream beside the compact launch
+    (``backend.REGION_STREAMS``: fork at the start of the product, join before the slabs are read).  Same kernels, same slabs, same order of the
+    slab sums: the product must be BITWISE the one-stream product -- back-to-back products without a host sync in between (the region workspaces
+    and the slabs are re-used by consecutive products: mBCG's pattern), three- and two-region forms, 1 ... 65 columns."""
+    from gpytorch_amd import backend as B
+
+    monkeypatch.setattr(B, "SPLIT_CONTRACTION", split)
+    n, d, ls = 24_000, 6, 0.57
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(n, d, generator=g).clamp_(-3.0, 3.0)
+    Xd = X.to(dev)
+    xp = B.prep_points("rbf", Xd, torch.tensor([ls]), Xd.mean(0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert B.gram_mode(xp, xp) == 2
+    sv = xp.sorted_view()
+    assert sv.n_compact > 0 and sv.n_compact < n
+    for merge in (4096, 0):
+        monkeypatch.setattr(B, "REGION_MERGE_MAX_ROWS", merge)
+        for t in (1, 4, 11, 33, 65):
+            vts = [B.to_probe_major(torch.randn(n, t, generator=torch.Generator().manual_seed(100 * t + k)).to(dev)) for k in range(6)]
+            monkeypatch.setattr(B, "REGION_STREAMS", False)
+            ref = [B.kv(xp, xp, v).clone() for v in vts]
+            monkeypatch.setattr(B, "REGION_STREAMS", True)
+            for rep in range(3):
+                got = [B.kv(xp, xp, v) for v in vts]          # six products in flight, no host sync
+                for a, b in zip(got, ref):
+                    assert torch.equal(a, b), (merge, t, rep, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("kind", ["matern32", "matern52"])
 @pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "split"])
 def test_contracted_points_near_the_extent_limit_of_the_saturating_norms(kind, split, dev, monkeypatch):
