@@ -80,8 +80,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // full across LDS tiles the split x_j rows (and the extra column) are staged ONE TILE AHEAD (double-buffered): the last step
 // of a tile generates the first block of the next one.
 // (The ablation and geometry variants this loop was measured through -- no generation / no MFMAs / staged once / no barriers, one or three
-// waves per SIMD, eight waves per workgroup, register prefetch of the next tile, a deeper Gram look-ahead -- live in tune/kv_gramh_ablate.hpp
-// and libgpamd_tune.so; DESIGN.md 3.1b has the numbers.)
+// waves per SIMD, eight waves per workgroup, register prefetch of the next tile, a deeper Gram look-ahead -- are `if constexpr` branches of THIS
+// body (kv_gramh_body.inc, constants ABL / NW / OCC; the product sets ABL = 0, NW = 4, and its ISA is byte for byte what it was before the
+// branches moved in: round 6, diff of the -S output of kvh_*.hip).  tune/kv_gramh_ablate.hpp includes the same body for libgpamd_tune.so, so the
+// two cannot drift; DESIGN.md 3.1b has the numbers.)
+// ABL: 0 the product; 1 no generation VALU; 2 no contraction MFMAs (the generated operands XOR-folded into the output: a live sink); 3 V planes /
+// x rows staged once (no global loads / LDS writes per tile; barriers stay); 4 as 3 and no barriers; 5 A operands of block 0 for every block;
+// 6 register prefetch of the next tile's planes; 7 one wave per SIMD (the wrapper's occupancy attribute); 8 no sched_barrier pinning; 10 Gram MFMA
+// one step further ahead (NI = 2).  NW: waves per workgroup.  OCC: resident waves per SIMD the wrapper holds the allocator to.
 // (beyond 20 dimensions: KH >= 5 Gram MFMAs per block -- the split x_i / x_j operands no longer fit 256 registers next to 64 accumulators, and the two
 // Xh buffers push the LDS image past half a CU: ONE wave per SIMD with the whole register file instead of 46 .. 94 spilled registers)
 template <int D>
@@ -89,330 +95,8 @@ constexpr int kgh_waves() { return D > 20 ? 1 : 2; }
 template <int KIND, int D, int CT, int NI, int EX, int SAFE = 0>   // SAFE = 1 / 2: tune library only (tune/tune_hazard.hip): every Gram result behind the full mfma_result_fence / round 5's form
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kgh_waves<D>(), kgh_waves<D>())))
 void kv_gramh_kernel(KvhArgs ka) {
-  constexpr int NW = 4, NT = 64 * NW;   // four waves per workgroup: row block = NW * NI * 32 rows sharing one staged V tile
-  const KvArgs& a = ka.a;
-  constexpr int DP = (D + 3) / 4 * 4, DQ = DP / 4;
-  constexpr int KH = GramF16<D>::KH;
-  constexpr int BN = KGH_BN, LDH = KGH_LDH, TC = 32 * CT;
-  constexpr int XHS = KH * BN * 16;     // f16 elements of one Xh buffer
-  constexpr bool PF = NI * CT <= 4 && KH <= 2;   // A operands of block jb + 32 fetched during block jb (16 CT more registers)
-  __shared__ __attribute__((aligned(16))) _Float16 Vhs[TC * LDH];
-  __shared__ __attribute__((aligned(16))) _Float16 Vls[TC * LDH];
-  __shared__ __attribute__((aligned(16))) _Float16 Xh[2 * XHS];        // [buf][kh][j][16] split augmented x_j rows
-  __shared__ __attribute__((aligned(16))) float Es[EX ? 2 * BN : 4];   // [buf][j] extra column
-
-  if (a.done && *a.done) return;
-  float negone;   // -1.0f the optimiser cannot see through (gen_b)
-  asm("s_mov_b32 %0, 0xbf800000" : "=s"(negone));
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int unit = blockIdx.x;
-  const int s = unit / a.nrb, rb = unit - s * a.nrb;
-  const int jbeg = s * a.jchunk;                  // multiple of BN
-  const int jend = min(a.m, jbeg + a.jchunk);
-  const int ibase = rb * (NW * NI * 32) + wave * (NI * 32);
-  float cz[DP];   // centre of this workgroup's row block (zero unless the host passed chunk centres: gram_f16.hpp)
-  load_center<DP>(a.Xc, ibase - wave * (NI * 32), NW * NI * 32, a.n, cz);
-
-  f16x8 bq[NI][KH];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int i = min(ibase + ni * 32 + l31, a.n - 1);
-    float z[DP];
-#pragma unroll
-    for (int q = 0; q < DQ; ++q) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(a.X1 + (int64_t)i * DP + 4 * q);
-      z[4 * q + 0] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
-    }
-    sub_center<DP>(z, cz);
-    gram_pack_b<D>(z, h, bq[ni], KIND == KIND_RBF ? (float)KGH_KSHIFT : 0.f);
-  }
-
-  f32x16 acc[NI][CT];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][ct][r] = 0.f;
-  }
-
-  constexpr int VQ = TC * (BN / 8) / NT;   // 16-byte chunks per thread and plane (= 2 CT with four waves)
-
-  // split x_j rows + extra column of the tile starting at j0 -> buffer `buf` (rows beyond jend: zero -> k = 2^KSHIFT, V = 0).
-  // Two halves: global loads into registers (load_x), then the split rows into LDS (store_x) between the barriers.
-  float xz[DP];
-  f32x4 xe = {0.f, 0.f, 0.f, 0.f};
-  bool xvalid = false;
-  auto load_x = [&](int j0) {
-    if (tid < BN) {
-      const int j = j0 + tid;
-      xvalid = j < jend;
-#pragma unroll
-      for (int q = 0; q < DQ; ++q) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (j < jend) v = *reinterpret_cast<const f32x4*>(a.X2 + (int64_t)j * DP + 4 * q);
-        xz[4 * q + 0] = v[0]; xz[4 * q + 1] = v[1]; xz[4 * q + 2] = v[2]; xz[4 * q + 3] = v[3];
-      }
-    }
-    if constexpr (EX) {
-      if (tid >= BN && tid < BN + BN / 4) {
-        const int j = j0 + 4 * (tid - BN);
-        const float* src = a.Vt + (int64_t)TC * a.ldv + j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (j + 4 <= jend) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (j + e < jend) v[e] = src[e];
-        }
-        xe = v;
-      }
-    }
-  };
-  auto store_x = [&](int buf) {
-    if (tid < BN) {
-      if (xvalid) sub_center<DP>(xz, cz);
-      gram_pack_a<D>(xz, xvalid, Xh + buf * XHS, tid, BN);
-    }
-    if constexpr (EX) {
-      if (tid >= BN && tid < BN + BN / 4) *reinterpret_cast<f32x4*>(&Es[buf * BN + 4 * (tid - BN)]) = xe;
-    }
-  };
-  auto stage_x = [&](int j0, int buf) {
-    load_x(j0);
-    store_x(buf);
-  };
-
-  auto load_aq = [&](int buf, int jb, f16x8* aq) {
-#pragma unroll
-    for (int kh = 0; kh < KH; ++kh) aq[kh] = *reinterpret_cast<const f16x8*>(&Xh[buf * XHS + gram_a_off(kh, jb + l31, h, BN)]);
-  };
-  auto gram = [&](const f16x8* aq, int ni) -> f32x16 {
-    f32x16 kk;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) kk[r] = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < KH; ++kh) kk = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[kh], bq[ni][kh], kk, 0, 0, 0);
-    // The product reads kk on the VALU one contraction MFMA later, behind the toolchain's 12 wait states -- the very distance DESIGN 3.1d measured
-    // insufficient in kv_gramv.  Round 6: 8 explicit wait states more, TIED to the result registers (no MFMA can sink below them): 20 in all, as
-    // kv_gram_kernel carries since round 5.  Measured against the alternatives on one box (profiles/r06_s4_kv_gramh_fence_ab.json,
-    // r06_s5_*): the FULL fence (32 wait states) costs 1.0 - 1.4 % (95.1 -> 96.4 ms at the headline split shape, 129.6 -> 131.0 ms at C3's) --
-    // above the 1 % it was allowed --, so the product takes the 8; every variant is bitwise equal to the others on a full chip.
-    // (SAFE: 0 = the product; 1 = the full fence -- the stress test's reference; 2 = round 5's form, the toolchain's table only: tune library, A/B)
-    if constexpr (SAFE == 1) {
-      mfma_result_fence(kk);
-    } else if constexpr (SAFE == 0) {
-      mfma_tie(kk);
-      asm volatile("s_nop 7");   // (+ the toolchain's own 12 behind it: the hazard recogniser does not count wait states inside inline asm)
-      mfma_tie(kk);
-    }
-    return kk;
-  };
-  // Generation of elements r = 8 mf + 2 p, + 1 of a step in two halves of three VALU instructions each:
-  //   gen_a: K = f(S) for both (2 v_exp_f32), packed hi word (v_cvt_pkrtz)      gen_b: lo = K - hi (2 v_fma_mix), packed lo word
-  // the extra column's two multiply-adds ride in gen_a as one v_pk_fma_f32.
-  f32x2 eacc2[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) eacc2[ni] = (f32x2)(0.f);
-  auto gen_a = [&](const f32x16& kk, int mf, int p, const f32x4* ev, int ni, f32x2& kv, u32x4& bh) {
-    // both elements at once: packed-f32 arithmetic around the transcendentals (common.hpp cov_pair_from_sq); RBF: the 2^KSHIFT scale is already
-    // inside S (gram_pack_b's nshift), the other families add it to the exponent
-    kv = cov_pair_from_sq<KIND>((f32x2){kk[8 * mf + 2 * p], kk[8 * mf + 2 * p + 1]}, a.kparam, KIND == KIND_RBF ? 0.f : (float)KGH_KSHIFT);
-    if constexpr (EX) {
-      // rows j(r, h) = (r & 3) + 8 (r >> 2) + 4 h, r = 8 mf + 2 p + e: ev[p >> 1] holds rows 16 mf + 8 (p >> 1) + 4 h .. + 3
-      const f32x2 e2 = {ev[p >> 1][2 * (p & 1)], ev[p >> 1][2 * (p & 1) + 1]};
-      eacc2[ni] = __builtin_elementwise_fma(kv, e2, eacc2[ni]);
-    }
-    bh[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(kv[0], kv[1]));
-  };
-  auto gen_b = [&](const f32x2& kv, int p, uint32_t hiw, u32x4& bl) {
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    const f16x2 hv = __builtin_bit_cast(f16x2, hiw);
-    // fmaf((float)h, -1, k) with an OPAQUE -1 (an SGPR the optimiser cannot see through, else it rewrites the fma as k - h and
-    // the conversion becomes its own instruction): with f32 denormals flushed (kvh_*.hip are built with
-    // -fgpu-flush-denormals-to-zero) the f16 -> f32 extension folds into ONE v_fma_mix_f32 per element.  (hiw comes BY VALUE:
-    // __builtin_bit_cast on element p of a `const u32x4&` parameter was compiled as element 0 for every p.  Writing the packed lo
-    // word with v_fma_mixlo_f16 / v_fma_mixhi_f16 instead -- one instruction fewer per pair -- measured slower, 90 vs 83 ms.)
-    const float l0 = __builtin_fmaf((float)hv[0], negone, kv[0]);
-    const float l1 = __builtin_fmaf((float)hv[1], negone, kv[1]);
-    bl[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(l0, l1));
-  };
-  auto load_ev = [&](int buf, int jb, int mf, f32x4* ev) {
-    if constexpr (EX) {
-      ev[0] = *reinterpret_cast<const f32x4*>(&Es[buf * BN + jb + 16 * mf + 4 * h]);
-      ev[1] = *reinterpret_cast<const f32x4*>(&Es[buf * BN + jb + 16 * mf + 8 + 4 * h]);
-    }
-  };
-  auto finish_half = [&](const f32x16& kk, int mf, int buf, int jb, int ni, u32x4& bh, u32x4& bl) {
-    f32x4 ev[2];
-    load_ev(buf, jb, mf, ev);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      f32x2 kv;
-      gen_a(kk, mf, p, ev, ni, kv, bh);
-      gen_b(kv, p, bh[p], bl);
-    }
-  };
-
-  // prologue: x rows of the first tile, B operands of its first step.  (Far-pair culling, kv_mfma.hpp: the tile sequence comes from this unit's
-  // list -- the look-ahead staging below takes the NEXT SURVIVING tile; no list: jbeg, jbeg + BN, ...)
-  const int* tl = kv_tile_list(a, unit);
-  const int jfirst = kv_tile_at<BN>(tl, jbeg, 0);
-  stage_x(jfirst, 0);
-  __syncthreads();
-  u32x4 bh[2], bl[2];
-  // LEAN (NI * CT > 4: four row tiles per wave and two column tiles, d <= 3): operands of a half are fetched just before its MFMAs
-  // instead of per block -- 128 accumulator registers leave no room for the whole block's operands
-  constexpr bool LEAN = NI * CT > 4;
-  {
-    f16x8 aq0[KH];
-    load_aq(0, 0, aq0);
-    const f32x16 kk = gram(aq0, 0);
-    finish_half(kk, 0, 0, 0, 0, bh[0], bl[0]);
-    finish_half(kk, 1, 0, 0, 0, bh[1], bl[1]);
-  }
-
-  // V planes of one tile: global -> registers (-> LDS between the barriers)
-  u32x4 pvh[VQ], pvl[VQ];
-  auto load_v = [&](int j0) {
-    const int64_t jc = min((int64_t)j0, ka.ldh - BN);   // past the chunk end: any in-bounds tile (never consumed)
-#pragma unroll
-    for (int rr = 0; rr < VQ; ++rr) {
-      const int idx = tid + NT * rr;
-      const int c = idx / (BN / 8), q = idx % (BN / 8);
-      const int64_t off = (int64_t)c * ka.ldh + jc + 8 * q;
-      pvh[rr] = *reinterpret_cast<const u32x4*>(ka.Vh + off);
-      pvl[rr] = *reinterpret_cast<const u32x4*>(ka.Vl + off);
-    }
-  };
-  int buf = 0;
-  for (int j0 = jfirst, jn, tk = 1; j0 < jend; j0 = jn, buf ^= 1, ++tk) {
-    jn = kv_tile_at<BN>(tl, jbeg, tk);
-    __syncthreads();   // every wave is done with the V planes of the previous tile and with Xh[buf ^ 1]
-    {
-      load_v(j0);
-      load_x(jn);        // past the end of the chunk: zero rows and a zero extra column (the last step's look-ahead generation
-                         // must stay finite and add nothing to the extra column)
-      store_x(buf ^ 1);
-#pragma unroll
-      for (int rr = 0; rr < VQ; ++rr) {
-        const int idx = tid + NT * rr;
-        const int c = idx / (BN / 8), q = idx % (BN / 8);
-        *reinterpret_cast<u32x4*>(&Vhs[c * LDH + 8 * q]) = pvh[rr];
-        *reinterpret_cast<u32x4*>(&Vls[c * LDH + 8 * q]) = pvl[rr];
-      }
-    }
-    __syncthreads();
-
-    // A operands of a block (V planes): 16 contiguous bytes per (16-row half, column tile, plane).  Block jb + 32's are
-    // fetched during block jb (LDS latency off the critical path); only the first block of a tile waits for them.
-    auto load_a = [&](int jb, f16x8 (*ah)[CT], f16x8 (*al)[CT]) {
-#pragma unroll
-      for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const int o = (ct * 32 + l31) * LDH + jb + 16 * mf + 8 * h;
-          ah[mf][ct] = *reinterpret_cast<const f16x8*>(&Vhs[o]);
-          al[mf][ct] = *reinterpret_cast<const f16x8*>(&Vls[o]);
-        }
-    };
-    f16x8 ah[2][CT], al[2][CT], aqc[KH];
-    if constexpr (!LEAN) load_a(0, ah, al);
-    load_aq(buf, 0, aqc);
-#pragma unroll 2
-    for (int jb = 0; jb < BN; jb += 32) {
-      // x rows of the next block (of the next tile after the last block: staged one tile ahead)
-      f16x8 aqn[KH], ahn[2][CT], aln[2][CT];
-      load_aq(jb == BN - 32 ? (buf ^ 1) : buf, (jb + 32) & (BN - 1), aqn);
-      if constexpr (PF) load_a((jb + 32) & (BN - 1), ahn, aln);   // unconditional (after the last block: a harmless re-read of block 0); branches in
-                                                // this loop body let the optimiser sink the look-ahead generation out of its slots
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        // next step: (jb, ni + 1), or the first row tile of the next block -- of the NEXT LDS tile after the last block (its x
-        // rows are already staged; past the end of the chunk they are zero rows and the result is never used)
-        const bool wrap = (ni == NI - 1);
-        const int nin = wrap ? 0 : ni + 1;
-        const int jbn = wrap ? ((jb + 32) & (BN - 1)) : jb;
-        const int bufn = (wrap && jb == BN - 32) ? (buf ^ 1) : buf;
-        f32x4 ev[2][2];
-        if constexpr (!LEAN) {
-          load_ev(bufn, jbn, 0, ev[0]);
-          load_ev(bufn, jbn, 1, ev[1]);
-        }
-        const f32x16 kkn = gram(wrap ? aqn : aqc, nin);
-        u32x4 bhn[2], bln[2];
-        __builtin_amdgcn_sched_barrier(0);
-        // contraction of this step, each MFMA followed by its share of the next step's generation; sched_barrier(0) pins the
-        // source order (left alone the scheduler groups the MFMAs, and the wave stalls 32 cycles on each with the VALU idle).
-        // Eight half-chunks (gen_a / gen_b of four pairs) over the 3 CT MFMAs of a half:
-        //   CT = 2:  a0 | b0 a1 | b1 | a2 | b2 a3 | b3          CT = 1:  a0 b0 a1 | b1 a2 b2 | a3 b3
-#pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
-          const f16x8 bhv = __builtin_bit_cast(f16x8, bh[mf]);
-          const f16x8 blv = __builtin_bit_cast(f16x8, bl[mf]);
-          f32x2 kv[4];
-          if constexpr (LEAN) {
-            load_ev(bufn, jbn, mf, ev[mf]);
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              const int o = (ct * 32 + l31) * LDH + jb + 16 * mf + 8 * h;
-              ah[mf][ct] = *reinterpret_cast<const f16x8*>(&Vhs[o]);
-              al[mf][ct] = *reinterpret_cast<const f16x8*>(&Vls[o]);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 3 * CT; ++q) {
-            // the two small terms first, then the leading one; consecutive instructions alternate accumulators
-            const int ct = q % CT, term = q / CT;
-            acc[ni][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al[mf][ct] : ah[mf][ct], term == 1 ? blv : bhv, acc[ni][ct], 0, 0, 0);
-            // half-chunk u = 2 p + (0: gen_a, 1: gen_b); this MFMA's share: [u0, u1)
-            constexpr int U6[7] = {0, 1, 3, 4, 5, 7, 8}, U3[4] = {0, 3, 6, 8};
-            const int u0 = CT == 1 ? U3[q] : U6[q], u1 = CT == 1 ? U3[q + 1] : U6[q + 1];
-#pragma unroll
-            for (int u = u0; u < u1; ++u) {
-              if ((u & 1) == 0) gen_a(kkn, mf, u >> 1, ev[mf], nin, kv[u >> 1], bhn[mf]);
-              else gen_b(kv[u >> 1], u >> 1, bhn[mf][u >> 1], bln[mf]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        bh[0] = bhn[0]; bh[1] = bhn[1]; bl[0] = bln[0]; bl[1] = bln[1];
-      }
-#pragma unroll
-      for (int kh = 0; kh < KH; ++kh) aqc[kh] = aqn[kh];
-      if constexpr (PF) {
-#pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) { ah[mf][ct] = ahn[mf][ct]; al[mf][ct] = aln[mf][ct]; }
-      } else if constexpr (!LEAN) {
-        load_a((jb + 32) & (BN - 1), ah, al);
-      }
-    }
-  }
-
-  mfma_result_fence();   // the accumulators of the last contraction MFMAs are read next (common.hpp; once per workgroup)
-  float* Pout = a.P + (int64_t)s * a.pstride;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int i = ibase + ni * 32 + l31;
-    if (i < a.n) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (c < a.t) Pout[(int64_t)c * a.ldo + i] = acc[ni][ct][r] * ka.colmul[c];
-        }
-    }
-    if constexpr (EX) {
-      const float part = eacc2[ni][0] + eacc2[ni][1];
-      const float tot = part + __shfl_xor(part, 32, 64);
-      if (h == 0 && i < a.n) Pout[(int64_t)TC * a.ldo + i] = tot * ka.colmul[TC];
-    }
-  }
+  constexpr int ABL = 0, NW = 4, OCC = kgh_waves<D>();   // the product: no ablation, four waves per workgroup (tune/kv_gramh_ablate.hpp sets the others)
+#include "kv_gramh_body.inc"
 }
 
 }  // namespace gpamd

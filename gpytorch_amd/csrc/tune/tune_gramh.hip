@@ -12,7 +12,7 @@ using namespace gpamd;
 extern "C" int gpamd_tune_kv_gramh_rbf3(int abl, int ni, int ex, const float* X1p, int n, const float* X2p, int m, const float* Vt, int64_t ldv,
                                         const void* Vh, const void* Vl, int64_t ldh, const float* colmul, float* P, int64_t ldo, int S,
                                         int jchunk, void* stream) {
-  KvhArgs ka;
+  KvhArgs ka{};   // (no chunk centres, no tile lists)
   KvArgs& a = ka.a;
   a.X1 = X1p; a.X2 = X2p; a.Vt = Vt; a.P = P;
   a.ldv = ldv; a.ldo = ldo; a.pstride = (int64_t)(64 + ex) * ldo;
