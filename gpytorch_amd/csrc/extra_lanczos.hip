@@ -74,7 +74,7 @@ static long pc_slices(int n) {
   long nb = ((long)n + 127) / 128;
   return nb > 256 ? 256 : (nb < 1 ? 1 : nb);
 }
-constexpr long PC_SMALL_GRID = 384;   // fewer workgroups than this (1.5 per CU) in the 128-row-tile form: the 32-row-tile form (four times as many)
+constexpr long PC_SMALL_GRID = 1L << 30;   // (was 384 = 1.5 workgroups per CU in the 128-row-tile form) the 32-row-tile form for EVERY <= 16-column projection: 1.6 - 1.9x at n = 36 584 .. 500 000, ranks 15 / 100 (profiles/r06_s31_precond_apply_timing.json): 256 workgroups of 62 latency-bound rounds at n = 500 000 were no better filled than 143 of eight
 int64_t gpamd_precond_coef_workspace_doubles(int n, int t, int k) {
   if (n <= 0 || t <= 0 || k <= 0) return 0;
   return (int64_t)pc_slices(n) * t * k;

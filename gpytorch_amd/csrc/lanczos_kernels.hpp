@@ -216,15 +216,15 @@ __global__ __launch_bounds__(256) void pc_apply_kernel(const float* __restrict__
     for (int e = threadIdx.x; e < nc * kt; e += 256) Ws[(e / kt) * (16 * PC_MT) + (e % kt)] = W[(int64_t)(c0 + e / kt) * k + m0 + (e % kt)];
     __syncthreads();
     if (i < n) {
-      // eight basis rows per round: their loads are issued together (round 6 -- one load, then its 16 multiply-adds, row after row, was a chain of
+      // four basis rows per round (eight measured the same at small n and 5 % slower at n = 500 000, 65 columns): their loads are issued together (round 6 -- one load, then its 16 multiply-adds, row after row, was a chain of
       // k memory latencies per wave: 30 us at n = 36 584 where one wave per SIMD has nothing to hide them behind); the sums keep their order
       int m = 0;
-      for (; m + 8 <= kt; m += 8) {
-        double q[8];
+      for (; m + 4 <= kt; m += 4) {
+        double q[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) q[u] = Q[(int64_t)(m0 + m + u) * ldq + i];
+        for (int u = 0; u < 4; ++u) q[u] = Q[(int64_t)(m0 + m + u) * ldq + i];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int c = 0; c < PA_CT; ++c) acc[c] = fma(Ws[c * (16 * PC_MT) + m + u], q[u], acc[c]);
       }
