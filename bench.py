@@ -251,12 +251,19 @@ def api_level_extras(Xd, yd, ls, t, dev, n_test=10_000):
         m.train(); m.eval()   # drops the prediction strategy (caches)
         with torch.no_grad(), S.max_cholesky_size(0), S.fast_pred_var(), S.max_preconditioner_size(rank), S.eval_cg_tolerance(tol), \
                 S.max_root_decomposition_size(love), S.lanczos_block_size(blk), S.max_cg_iterations(4000):
-            sync()
-            t0 = time.perf_counter()
-            pred = lik(m(Xs))
-            mu, var = pred.mean, pred.variance
-            sync()
-            t1 = time.perf_counter()
+            # "cold" = the model's caches dropped, not the operating system's: the first evaluation of a configuration can also page in solver-library
+            # code objects from disk (one run on a fresh box read 4.35 s for the third case where five others read 1.0 - 1.2 s) -- two cold
+            # evaluations, the faster one reported, both kept
+            cold_all = []
+            for _ in range(2):
+                m.train(); m.eval()
+                sync()
+                t0 = time.perf_counter()
+                pred = lik(m(Xs))
+                mu, var = pred.mean, pred.variance
+                sync()
+                t1 = time.perf_counter()
+                cold_all.append((t1 - t0) * 1e3)
             its = LCG.LAST_INFO.iterations if LCG.LAST_INFO is not None else None
             pred = lik(m(Xs))  # caches warm
             mu, var = pred.mean, pred.variance
@@ -264,7 +271,7 @@ def api_level_extras(Xd, yd, ls, t, dev, n_test=10_000):
             t2 = time.perf_counter()
             rank_res = S.max_preconditioner_size.resolve(n)
         post.append({"settings": tag, "max_preconditioner_size": rank, "resolved_rank": rank_res, "eval_cg_tolerance": tol, "love_rank": love,
-                     "lanczos_block_size": blk, "cold_ms": (t1 - t0) * 1e3, "warm_ms": (t2 - t1) * 1e3, "mean_cache_cg_iterations": its,
+                     "lanczos_block_size": blk, "cold_ms": min(cold_all), "cold_ms_all": cold_all, "warm_ms": (t2 - t1) * 1e3, "mean_cache_cg_iterations": its,
                      "mean_max_err_over_max_abs_mean": float((mu.double() - mean_ref).abs().max() / mean_ref.abs().max()),
                      "var_max_err_over_noise": float((var.double()[:nv] - var_ref).abs().max() / s2)})
     res["posterior"] = post
