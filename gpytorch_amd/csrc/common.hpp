@@ -68,6 +68,49 @@ __device__ __forceinline__ f32x2 cov_pair_from_sq(f32x2 s, float p = 0.f, float 
   }
 }
 
+// N pairs at once, STAGE BY STAGE (all square roots, then all exponent multiplies, then all exponentials, ...): written pair by pair the compiler keeps
+// the source order -- sqrt, its dependent multiply, exp, its dependent multiply, every instruction waiting on the one before it with an s_nop
+// between (133 s_nop per 64 elements in kv_gramv<Matern-5/2, T = 1>, round 6) -- although the N pairs are independent.  Same arithmetic per element as
+// cov_pair_from_sq: bitwise the same values.
+template <int KIND, int N>
+__device__ __forceinline__ void cov_pairs_from_sq(const f32x2 (&s)[N], float p, f32x2 (&k)[N]) {
+  if constexpr (KIND == KIND_RBF) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) k[i] = (f32x2){__builtin_amdgcn_exp2f(-s[i][0]), __builtin_amdgcn_exp2f(-s[i][1])};
+  } else if constexpr (KIND == KIND_RQ) {
+    f32x2 l2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const f32x2 u = s[i] + 1.0f;
+      l2[i] = (f32x2){__builtin_amdgcn_logf(u[0]), __builtin_amdgcn_logf(u[1])};
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) l2[i] = __builtin_elementwise_fma(l2[i], (f32x2)(-p), (f32x2)(0.f));
+#pragma unroll
+    for (int i = 0; i < N; ++i) k[i] = (f32x2){__builtin_amdgcn_exp2f(l2[i][0]), __builtin_amdgcn_exp2f(l2[i][1])};
+  } else {
+    f32x2 r[N], t[N], e[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = (f32x2){__builtin_amdgcn_sqrtf(__builtin_fabsf(s[i][0])), __builtin_amdgcn_sqrtf(__builtin_fabsf(s[i][1]))};
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = __builtin_elementwise_fma(r[i], (f32x2)(-LOG2E), (f32x2)(0.f));
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = (f32x2){__builtin_amdgcn_exp2f(t[i][0]), __builtin_amdgcn_exp2f(t[i][1])};
+    if constexpr (KIND == KIND_MATERN12) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) k[i] = e[i];
+    } else if constexpr (KIND == KIND_MATERN32) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) k[i] = (r[i] + 1.0f) * e[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) r[i] = __builtin_elementwise_fma(s[i], (f32x2)(1.0f / 3.0f), r[i] + 1.0f);
+#pragma unroll
+      for (int i = 0; i < N; ++i) k[i] = r[i] * e[i];
+    }
+  }
+}
+
 // d k / d s (derivative wrt the squared scaled distance), used by the gradient kernels:
 //   RBF: k = exp2(-s) = exp(-s ln2)      -> dk/ds = -ln2 * k
 //   Matern: with r = sqrt(s): dk/ds = k'(r) / (2 r)

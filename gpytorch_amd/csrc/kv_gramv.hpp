@@ -103,12 +103,14 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
             const f32x2 vv = {v4[e], v4[e + 1]};
+            // (pair form: packed-f32 arithmetic around the transcendentals, |S| as a source modifier of v_sqrt_f32 -- common.hpp; the NI row tiles'
+            // pairs stage by stage: cov_pairs_from_sq)
+            f32x2 sq[NI], kv[NI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              // (pair form: packed-f32 arithmetic around the transcendentals, |S| as a source modifier of v_sqrt_f32 -- common.hpp)
-              const f32x2 kv = cov_pair_from_sq<KIND>((f32x2){kk[ni][4 * g + e], kk[ni][4 * g + e + 1]}, a.kparam);
-              acc2[ni][0] = __builtin_elementwise_fma(kv, vv, acc2[ni][0]);
-            }
+            for (int ni = 0; ni < NI; ++ni) sq[ni] = (f32x2){kk[ni][4 * g + e], kk[ni][4 * g + e + 1]};
+            cov_pairs_from_sq<KIND, NI>(sq, a.kparam, kv);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc2[ni][0] = __builtin_elementwise_fma(kv[ni], vv, acc2[ni][0]);
           }
         } else if constexpr (T == 2 && KIND != KIND_RBF) {
           // TWO columns (four and more keep the scalar form: with two more operand pairs live the allocator gave up a resident wave at d = 10), families with more than one transcendental per pair (Matern: v_sqrt + v_exp + a polynomial; RQ: v_log + v_exp): two
@@ -122,13 +124,16 @@ __global__ __launch_bounds__(256) void kv_gramv_kernel(KvArgs a) {
               vp0[c] = *reinterpret_cast<const f32x2*>(&Vs[(jl + e) * T + 2 * c]);
               vp1[c] = *reinterpret_cast<const f32x2*>(&Vs[(jl + e + 1) * T + 2 * c]);
             }
+            f32x2 sq[NI], kv[NI];   // the NI row tiles' pairs stage by stage (common.hpp cov_pairs_from_sq)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) sq[ni] = (f32x2){kk[ni][4 * g + e], kk[ni][4 * g + e + 1]};
+            cov_pairs_from_sq<KIND, NI>(sq, a.kparam, kv);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              const f32x2 kv = cov_pair_from_sq<KIND>((f32x2){kk[ni][4 * g + e], kk[ni][4 * g + e + 1]}, a.kparam);
 #pragma unroll
               for (int c = 0; c < TP; ++c) {
-                acc2[ni][c] = __builtin_elementwise_fma((f32x2)(kv[0]), vp0[c], acc2[ni][c]);
-                acc2[ni][c] = __builtin_elementwise_fma((f32x2)(kv[1]), vp1[c], acc2[ni][c]);
+                acc2[ni][c] = __builtin_elementwise_fma((f32x2)(kv[ni][0]), vp0[c], acc2[ni][c]);
+                acc2[ni][c] = __builtin_elementwise_fma((f32x2)(kv[ni][1]), vp1[c], acc2[ni][c]);
               }
             }
           }
