@@ -110,7 +110,9 @@ class FixedNoiseGaussianLikelihood(_GaussianLikelihoodBase):
         super().__init__(FixedGaussianNoise(noise))
         self.second_noise_covar = None
         if learn_additional_noise:
-            self.second_noise_covar = HomoskedasticNoise(noise_prior=kwargs.get("noise_prior"), noise_constraint=kwargs.get("noise_constraint"))
+            # (gaussian_likelihood.py:291-296: the learned noise carries the likelihood's batch_shape -- one value per member of a batch of GPs)
+            self.second_noise_covar = HomoskedasticNoise(noise_prior=kwargs.get("noise_prior"), noise_constraint=kwargs.get("noise_constraint"),
+                                                         batch_shape=batch_shape)
 
     @property
     def noise(self):
