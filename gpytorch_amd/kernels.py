@@ -41,6 +41,79 @@ class Kernel(Module):
         return self._batch_shape
 
     @property
+    def dtype(self):
+        """kernel.py:276-285."""
+        if self.has_lengthscale:
+            return self.lengthscale.dtype
+        dtypes = {p.dtype for p in self.parameters()}
+        if len(dtypes) > 1:
+            raise RuntimeError(f"The kernel's parameters have multiple dtypes: {dtypes}.")
+        return dtypes.pop() if dtypes else torch.get_default_dtype()
+
+    @property
+    def device(self):
+        devices = {p.device for p in self.parameters()}
+        if len(devices) > 1:
+            raise RuntimeError(f"The kernel's parameters are on multiple devices: {devices}.")
+        return devices.pop() if devices else torch.device("cpu")
+
+    def named_sub_kernels(self):
+        """Directly held member kernels (``kernel.py:405-414``; the list-holding compositions override ``__getitem__`` / ``expand_batch`` themselves)."""
+        for name, module in self.named_children():
+            if isinstance(module, Kernel):
+                yield name, module
+
+    def _batch_parameters(self):
+        """Own parameters and those buffers that carry the batch shape (``active_dims`` is a buffer WITHOUT it)."""
+        yield from self.named_parameters(recurse=False)
+        nb = len(self._batch_shape)
+        for name, buf in self.named_buffers(recurse=False):
+            if buf is not None and name != "active_dims" and buf.dim() > nb and buf.shape[:nb] == self._batch_shape:
+                yield name, buf
+
+    def __getitem__(self, index):
+        """``kernel.py:556-590``: the kernel of the indexed batch members -- every batch-shaped parameter indexed, the batch shape shortened by the
+        dimensions the index removed, member kernels indexed the same way."""
+        if len(self._batch_shape) == 0:
+            return self
+        import copy
+
+        new = copy.deepcopy(self)
+        index = index if isinstance(index, tuple) else (index,)
+        for name, old in self._batch_parameters():
+            t = getattr(new, name)
+            t.data = t.data[index]
+            new._batch_shape = t.shape[: len(self._batch_shape) - (old.dim() - t.dim())]
+        for name, sub in self.named_sub_kernels():
+            setattr(new, name, sub[index])
+        return new
+
+    def expand_batch(self, *sizes):
+        """``kernel.py:354-403``: the same kernel with its parameters expanded to a larger batch shape."""
+        if len(sizes) == 1 and hasattr(sizes[0], "__iter__"):
+            new_shape = torch.Size(sizes[0])
+        elif all(isinstance(v, int) for v in sizes):
+            new_shape = torch.Size(sizes)
+        else:
+            raise RuntimeError(f"Invalid arguments {sizes} to expand_batch.")
+        if new_shape == self._batch_shape:
+            return self
+        try:
+            torch.broadcast_shapes(new_shape, self._batch_shape)
+        except RuntimeError:
+            raise RuntimeError(f"Cannot expand a kernel with batch shape {self._batch_shape} to new shape {new_shape}")
+        import copy
+
+        new = copy.deepcopy(self)
+        nb = len(self._batch_shape)
+        for name, old in self._batch_parameters():
+            getattr(new, name).data = old.data.expand(*new_shape, *old.shape[nb:]).clone()
+        new._batch_shape = new_shape
+        for name, sub in self.named_sub_kernels():
+            setattr(new, name, sub.expand_batch(new_shape))
+        return new
+
+    @property
     def lengthscale(self):
         return self._get_transformed("raw_lengthscale") if self.has_lengthscale else None
 
@@ -64,7 +137,8 @@ class Kernel(Module):
         """``kernel.py:454-534``: select active dims, promote 1-D inputs to [n, 1], default x2 = x1; leading dimensions of
         the inputs (and the kernel's ``batch_shape``) are batch dimensions (``kernel.py:163-208``)."""
         x1_, x2_ = x1, (None if x2 is x1 else x2)
-        if last_dim_is_batch:  # kernel.py:506-510: every input dimension becomes its own batch member, [..., d, n, 1]
+        in_forward = last_dim_is_batch and getattr(self, "dims_as_batch_in_forward", False)
+        if last_dim_is_batch and not in_forward:  # kernel.py:336-338: every input dimension becomes its own batch member, [..., d, n, 1]
             x1_ = x1_.transpose(-1, -2).unsqueeze(-1)
             x2_ = None if x2_ is None else x2_.transpose(-1, -2).unsqueeze(-1)
         if x1_.dim() == 1:
@@ -81,6 +155,8 @@ class Kernel(Module):
             raise RuntimeError("x1_ and x2_ must have the same number of dimensions!")
         if self.ard_num_dims is not None and self.ard_num_dims != x1_.shape[-1]:
             raise RuntimeError(f"Expected the input to have {self.ard_num_dims} dimensionality (based on ard_num_dims). Got {x1_.shape[-1]}.")
+        if in_forward:      # (the stationary families scale by their per-dimension lengthscales first, as the reference's forward does)
+            params["last_dim_is_batch"] = True
         return self.forward(x1_, x2_, diag=diag, **params)
 
     @property
@@ -125,15 +201,25 @@ class _StationaryFused(Kernel):
         """Non-tensor description of the operator for batch member ``b`` (families with a shape parameter add it here)."""
         return KernelSpec(self.kind, self._shift(x1))
 
-    def forward(self, x1, x2, diag=False, **params):
+    dims_as_batch_in_forward = True
+
+    def forward(self, x1, x2, diag=False, last_dim_is_batch=False, **params):
         # float32 with d <= 16: fused MFMA / VALU kernels; float64 or d > 16: generic path (backend.kv_chunked)
         ls = self.lengthscale
+        same = x2 is x1
+        nd = None
+        if last_dim_is_batch:
+            # rbf_kernel.py:78-81 + kernel.py:336-338 (deprecated in the reference, kept): the inputs are divided by the lengthscale of THEIR
+            # dimension, then every dimension becomes a batch member [..., d, n, 1] -- so the lengthscales move to the batch with them
+            nd = x1.shape[-1]
+            x1 = x1.transpose(-1, -2).unsqueeze(-1)
+            x2 = x1 if same else x2.transpose(-1, -2).unsqueeze(-1)
+            ls = ls.expand(*ls.shape[:-1], nd).transpose(-1, -2).unsqueeze(-1)
         batch = torch.broadcast_shapes(x1.shape[:-2], x2.shape[:-2], ls.shape[:-2])
         if not batch:
             op = FusedKernelLinearOperator(x1, x2, self._make_spec(x1), ls)
             return op.diagonal() if diag else op
         # batch mode: one fused operator per batch member (inputs and lengthscales broadcast against each other)
-        same = x2 is x1
         x1b = x1.expand(*batch, *x1.shape[-2:]).reshape(-1, *x1.shape[-2:])
         x2b = x1b if same else x2.expand(*batch, *x2.shape[-2:]).reshape(-1, *x2.shape[-2:])
         lsb = ls.expand(*batch, *ls.shape[-2:]).reshape(-1, *ls.shape[-2:])
@@ -141,7 +227,11 @@ class _StationaryFused(Kernel):
         for b in range(x1b.shape[0]):
             xa = x1b[b]
             xb = xa if same else x2b[b]
-            ops.append(FusedKernelLinearOperator(xa, xb, self._make_spec(xa, b, batch), lsb[b]))
+            if nd is None:
+                spec = self._make_spec(xa, b, batch)
+            else:               # (shape parameters belong to the kernel's own batch: the dimension index is the last batch dimension)
+                spec = self._make_spec(xa, b // nd, batch[:-1]) if len(batch) > 1 else self._make_spec(xa)
+            ops.append(FusedKernelLinearOperator(xa, xb, spec, lsb[b]))
         op = BatchLinearOperator(ops, batch)
         return op.diagonal() if diag else op
 
@@ -169,6 +259,18 @@ def _feature_operator(f1, f2, same):
     f2b = f1b if same else f2.expand(*batch, *f2.shape[-2:]).reshape(-1, *f2.shape[-2:])
     ops = [_feature_operator(f1b[b], f1b[b] if same else f2b[b], same) for b in range(f1b.shape[0])]
     return BatchLinearOperator(ops, batch)
+
+
+def _feature_diag(f1, f2):
+    """k(x1_i, x2_i) = exp(-1/2 |phi(x1_i) - phi(x2_i)|^2): the ``diag=True`` value for two DIFFERENT equally long inputs (kernels/kernel.py:318-330
+    evaluates the elementwise diagonal, not the all-ones diagonal of K(x, x))."""
+    return (f1 - f2).pow(2).sum(-1).mul(-0.5).exp()
+
+
+def _cat_features(fs):
+    """Feature maps of the members of a product side by side; members with and without a batch shape broadcast against each other."""
+    batch = torch.broadcast_shapes(*[f.shape[:-1] for f in fs])
+    return torch.cat([f.expand(*batch, f.shape[-1]) for f in fs], dim=-1)
 
 
 class PeriodicKernel(Kernel):
@@ -204,9 +306,11 @@ class PeriodicKernel(Kernel):
         return torch.cat([a.cos(), a.sin()], dim=-1) / torch.cat([self.lengthscale.sqrt().expand_as(a[..., :1, :])] * 2, dim=-1)
 
     def forward(self, x1, x2, diag=False, **params):
-        if diag:
-            return torch.ones(x1.shape[:-1], device=x1.device, dtype=x1.dtype)
         same = x2 is x1
+        if diag:
+            if same or (x1.shape == x2.shape and torch.equal(x1, x2)):
+                return torch.ones(x1.shape[:-1], device=x1.device, dtype=x1.dtype)
+            return _feature_diag(self.rbf_features(x1), self.rbf_features(x2))
         f1 = self.rbf_features(x1)
         return _feature_operator(f1, f1 if same else self.rbf_features(x2), same)
 
@@ -380,6 +484,16 @@ class MultiDeviceKernel(Kernel):
         return self.module.prediction_strategy
 
 
+def _index_members(kernel, index):
+    """``kernel.py:626-631`` / ``:684-688``: a sum / product of kernels indexes every member."""
+    import copy
+
+    new = copy.deepcopy(kernel)
+    for i, member in enumerate(kernel.kernels):
+        new.kernels[i] = member[index]
+    return new
+
+
 class AdditiveKernel(Kernel):
     """K = sum_i K_i (``kernels/kernel.py:592-632``): the members stay matrix-free; their sum is a
     :class:`~gpytorch_amd.operators.SumFusedLinearOperator` whose products, solves and log-determinants add the members'
@@ -392,6 +506,9 @@ class AdditiveKernel(Kernel):
     @property
     def is_stationary(self):
         return all(k.is_stationary for k in self.kernels)
+
+    def __getitem__(self, index):
+        return _index_members(self, index)
 
     def __call__(self, x1, x2=None, diag=False, **params):
         return self.forward(x1, x1 if x2 is None else x2, diag=diag, **params)
@@ -420,7 +537,7 @@ def _se_family(kernel):
         for _, sc in parts:
             if sc is not None:
                 scale = sc if scale is None else scale * sc
-        return (lambda x, parts=parts: torch.cat([f(x) for f, _ in parts], dim=-1)), scale
+        return (lambda x, parts=parts: _cat_features([f(x) for f, _ in parts])), scale
     if kernel.rbf_features.__func__ is not Kernel.rbf_features:
         return kernel.rbf_features, None
     return None
@@ -440,6 +557,9 @@ class ProductKernel(Kernel):
     def is_stationary(self):
         return all(k.is_stationary for k in self.kernels)
 
+    def __getitem__(self, index):
+        return _index_members(self, index)
+
     def __call__(self, x1, x2=None, diag=False, **params):
         return self.forward(x1, x1 if x2 is None else x2, diag=diag, **params)
 
@@ -447,10 +567,13 @@ class ProductKernel(Kernel):
         fam = _se_family(self)
         if fam is not None:
             feat, scale = fam
-            if diag:
-                one = torch.ones(x1.shape[:-1] if x1.dim() > 1 else x1.shape, device=x1.device, dtype=x1.dtype)
-                return one if scale is None else one * scale.unsqueeze(-1)
             same = x2 is x1
+            if diag:
+                if same or (x1.shape == x2.shape and torch.equal(x1, x2)):
+                    one = torch.ones(x1.shape[:-1] if x1.dim() > 1 else x1.shape, device=x1.device, dtype=x1.dtype)
+                else:     # two different inputs: the elementwise diagonal (test/kernels/test_additive_and_product_kernels.py:127-157)
+                    one = _feature_diag(feat(x1), feat(x2))
+                return one if scale is None else one * scale.unsqueeze(-1)
             f1 = feat(x1)
             if f1.shape[-1] <= B.MAX_INPUT_DIM or f1.dtype == torch.float64:
                 op = _feature_operator(f1, f1 if same else feat(x2), same)

@@ -155,6 +155,56 @@ class FixedNoiseGaussianLikelihood(_GaussianLikelihoodBase):
         return res
 
 
+class DirichletClassificationLikelihood(FixedNoiseGaussianLikelihood):
+    """Classification labels as heteroskedastic regression targets (``gaussian_likelihood.py:365-472``; Milios et al., 2018): class c of point i gets
+    the Dirichlet concentration alpha = alpha_epsilon (+ 1 for the observed class), matched by a log-normal with variance
+    sigma2 = log(1 / alpha + 1) and mean log(alpha) - sigma2 / 2.  The result is ONE exact GP per class -- ``batch_shape = (classes,)`` -- with the
+    fixed noise sigma2 [classes, n] and the targets ``transformed_targets`` [classes, n]: everything downstream is the fixed-noise hot path."""
+
+    @staticmethod
+    def _prepare_targets(targets, alpha_epsilon: float = 0.01, dtype=torch.float):
+        classes = int(targets.max()) + 1
+        alpha = torch.full((targets.shape[-1], classes), alpha_epsilon, device=targets.device, dtype=dtype)
+        alpha[torch.arange(targets.shape[-1], device=targets.device), targets] += 1.0
+        sigma2 = torch.log1p(alpha.reciprocal())
+        return sigma2.mT.contiguous(), alpha.log() - 0.5 * sigma2, classes
+
+    def __init__(self, targets, alpha_epsilon: float = 0.01, learn_additional_noise: bool = False, batch_shape=torch.Size(), dtype=torch.float, **kwargs):
+        sigma2, transformed, classes = self._prepare_targets(targets, alpha_epsilon=alpha_epsilon, dtype=dtype)
+        super().__init__(noise=sigma2, learn_additional_noise=learn_additional_noise, batch_shape=torch.Size((classes,)), **kwargs)
+        self.transformed_targets = transformed.mT.contiguous()
+        self.num_classes = classes
+        self.targets = targets
+        self.alpha_epsilon = alpha_epsilon
+
+    def _apply(self, fn, *args, **kwargs):
+        # (plain attributes in the reference too; moved with the module here so that ``likelihood.to(device)`` keeps the notebook's two lines working)
+        self.transformed_targets = fn(self.transformed_targets)
+        self.targets = fn(self.targets)
+        return super()._apply(fn, *args, **kwargs)
+
+    def get_fantasy_likelihood(self, **kwargs):
+        """gaussian_likelihood.py:438-458: the fantasy points bring class labels (under the ``noise`` keyword, as the reference has it)."""
+        if "noise" not in kwargs:
+            raise RuntimeError("FixedNoiseGaussianLikelihood.fantasize requires a `noise` kwarg")
+        import copy
+
+        new = copy.deepcopy(self)
+        labels = kwargs["noise"]
+        sigma2, _, _ = self._prepare_targets(labels, self.alpha_epsilon, dtype=self.transformed_targets.dtype)
+        old = self.noise_covar.noise
+        if old.dim() != sigma2.dim():
+            old = old.expand(*sigma2.shape[:-1], old.shape[-1])
+        new.targets = torch.cat([self.targets, labels], -1)
+        new.noise_covar = FixedGaussianNoise(torch.cat([old, sigma2.to(old)], -1))
+        return new
+
+    def __call__(self, input, *args, **kwargs):
+        if "targets" in kwargs:      # test-time labels -> test-time noise (gaussian_likelihood.py:466-472)
+            kwargs["noise"] = self._prepare_targets(kwargs.pop("targets"), dtype=self.transformed_targets.dtype)[0]
+        return super().__call__(input, *args, **kwargs)
+
+
 def _add_diags(a, b):
     """Sum of two diagonal operators as ONE diagonal operator (so the fused K + D path still applies)."""
     if isinstance(a, ConstantDiagLinearOperator) and isinstance(b, ConstantDiagLinearOperator):

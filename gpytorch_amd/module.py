@@ -137,7 +137,14 @@ class Module(nn.Module):
             param = getattr(self, name)
             val_t = torch.as_tensor(val, dtype=param.dtype, device=param.device)
             with torch.no_grad():
-                param.copy_(val_t.expand_as(param))
+                try:
+                    param.copy_(val_t.expand_as(param))
+                except RuntimeError:
+                    # module.py:170-178: a value that does not broadcast but has the parameter's element count is re-viewed (e.g. a [1, 1, 1]
+                    # lengthscale given to a kernel without a batch shape, test/kernels/test_periodic_kernel.py:56-62)
+                    if val_t.numel() != param.numel():
+                        raise
+                    param.copy_(val_t.reshape(param.shape))
         return self
 
     def _set_transformed(self, raw_name: str, value):

@@ -51,12 +51,16 @@ def hadamard_run(g, dev, k, data, steps=100):
 
 
 def classification_run(g, dev, steps=46):
-    """examples/01_Exact_GPs/GP_Regression_on_Classification_Labels.ipynb: a batch of three exact GPs on the Dirichlet-transformed labels -- fixed
-    per-point noise + one learned noise per member (``DirichletClassificationLikelihood`` IS a ``FixedNoiseGaussianLikelihood`` with
-    ``batch_shape = (classes,)``, gaussian_likelihood.py:415-432; its transformed targets and noise are in the fixture).  Returns rows of
+    """examples/01_Exact_GPs/GP_Regression_on_Classification_Labels.ipynb, cell for cell: ``DirichletClassificationLikelihood`` turns the labels into
+    regression targets + fixed per-point noise for a batch of three exact GPs (one per class) and learns one more noise per member.  Returns rows of
     (loss, mean lengthscale, mean learned noise) as the notebook prints them, one per step."""
-    X, targets, fixed = _t("cls_x", dev), _t("cls_targets", dev), _t("cls_fixed_noise", dev)
-    bs = torch.Size((targets.shape[0],))
+    train_x, train_y = _t("cls_x", dev), _t("cls_labels", dev)
+    likelihood = g.likelihoods.DirichletClassificationLikelihood(train_y, learn_additional_noise=True).to(dev)
+    # the class's own transform against the reference's (the fixture holds the output of the reference's ``_prepare_targets``, executed)
+    assert torch.allclose(likelihood.transformed_targets, _t("cls_targets", dev), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(likelihood.noise_covar.noise, _t("cls_fixed_noise", dev), rtol=1e-6, atol=1e-6)
+    X, targets = train_x, likelihood.transformed_targets
+    bs = torch.Size((likelihood.num_classes,))
 
     class DirichletGPModel(g.models.ExactGP):
         def __init__(self, train_x, train_y, likelihood):
@@ -67,7 +71,6 @@ def classification_run(g, dev, steps=46):
         def forward(self, x):
             return g.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
 
-    likelihood = g.likelihoods.FixedNoiseGaussianLikelihood(noise=fixed, learn_additional_noise=True, batch_shape=bs).to(dev)
     model = DirichletGPModel(X, targets, likelihood).to(dev)
     model.train()
     likelihood.train()

@@ -342,3 +342,32 @@ def test_rhs_refinement_on_the_additive_operator(dev):
             fvar = m(Xs.float().to(dev)).variance.double().cpu()
         verr[refine] = float((fvar - fvar_ref).abs().max() / 1e-3)      # in units of the noise
     assert verr[True] < 0.05 and verr[True] < verr[False], verr
+
+
+def test_sum_and_product_known_answers_of_the_reference(dev):
+    """test/kernels/test_additive_and_product_kernels.py:33-157 -- dense values, batch members, and ``diag=True`` on two DIFFERENT inputs (the
+    product of squared-exponential members used to answer with the all-ones diagonal of K(x, x) there)."""
+    import gpytorch_amd as g
+    from tests.known_answers import check_sum_product_known_answers
+
+    check_sum_product_known_answers(g, dev)
+
+
+def test_stationary_and_periodic_unit_tests_of_the_reference(dev):
+    """test/kernels/test_rbf_kernel.py:20-125, test/kernels/test_periodic_kernel.py:20-88 (closed forms; ``last_dim_is_batch`` with ARD lengthscales,
+    re-viewed hyper-parameter shapes)."""
+    import gpytorch_amd as g
+    from tests.known_answers import check_stationary_and_periodic_unit_tests
+
+    check_stationary_and_periodic_unit_tests(g, dev)
+
+
+@pytest.mark.parametrize("family", ["rbf", "matern32", "matern12", "matern52", "periodic", "rq", "scale_rbf"])
+def test_generic_kernel_battery_of_the_reference(family, dev):
+    """gpytorch/test/base_kernel_test_case.py:30-197: active dimensions, batch inputs under kernels with and without a batch shape, ARD, ``diag=True``,
+    kernel ``__getitem__`` / ``expand_batch``, pickling -- over every kernel family of the path."""
+    import gpytorch_amd as g
+    from tests.kernel_battery import families, run_battery
+
+    (_, make, make_ard), = [f for f in families(g) if f[0] == family]
+    run_battery(make, make_ard, dev)
