@@ -53,6 +53,10 @@ class _GaussianLikelihoodBase(Module):
         noise_covar = self._shaped_noise_covar(mean.shape, *params, **kwargs)
         return function_dist.__class__(mean, covar + noise_covar)
 
+    def get_fantasy_likelihood(self, **kwargs):
+        """gaussian_likelihood.py:60-61 / likelihood.py: a homoskedastic likelihood serves the fantasy model unchanged (hyper-parameters shared)."""
+        return self
+
     def __call__(self, input, *args, **kwargs):
         """likelihood.py:72-84: an MVN input means ``marginal``."""
         if isinstance(input, MultivariateNormal):

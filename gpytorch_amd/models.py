@@ -42,6 +42,7 @@ class DefaultPredictionStrategy:
         mvn = self.likelihood(train_prior_dist, train_inputs)
         self.lik_train_train_covar = mvn.lazy_covariance_matrix
         self._mean_cache = None
+        self._masked_cache = None
         self._covar_cache = None
         self._inv_root = inv_root
 
@@ -49,9 +50,30 @@ class DefaultPredictionStrategy:
     def num_train(self):
         return self._train_shape.numel()
 
+    def _masked_mean_cache(self, policy):
+        """exact_prediction_strategies.py:287-315: the training targets hold NaNs and the policy is "mask" or "fill".  Both solve the system of the
+        observed points only ("fill" zeroes the missing rows and columns of a dense matrix and keeps its diagonal -- the observed block of that
+        solve IS the masked solve) and mark the missing entries of the cache NaN; a point counts as observed if every batch member observes it."""
+        mvn = self.likelihood(self.train_prior_dist, self.train_inputs)
+        train_mean, op = mvn.loc, mvn.lazy_covariance_matrix.evaluate_kernel()
+        n = self.train_labels.shape[-1]
+        idx = (~torch.isnan(self.train_labels.reshape(-1, n)).any(dim=0)).nonzero().squeeze(-1)
+        sub = op.restrict(idx) if hasattr(op, "restrict") else op[idx][:, idx]
+        offset = (self.train_labels - train_mean)[..., idx].unsqueeze(-1)
+        mc = torch.full_like(self.train_labels, float("nan"))
+        mc[..., idx] = sub.solve(offset).squeeze(-1)
+        return mc.detach() if settings.detach_test_caches.on() else mc
+
     @property
     def mean_cache(self):
-        """exact_prediction_strategies.py:278-321 (nan policy 'ignore')."""
+        """exact_prediction_strategies.py:275-321: one cache per observation-NaN policy."""
+        policy = settings.observation_nan_policy.value()
+        if policy != "ignore" and bool(torch.isnan(self.train_labels).any()):
+            if policy == "fill":
+                warnings.warn("Observation NaN policy 'fill' makes the kernel matrix dense during exact prediction.", RuntimeWarning)
+            if self._masked_cache is None:
+                self._masked_cache = self._masked_mean_cache(policy)
+            return self._masked_cache
         if self._mean_cache is None:
             mvn = self.likelihood(self.train_prior_dist, self.train_inputs)
             train_mean, train_train_covar = mvn.loc, mvn.lazy_covariance_matrix
@@ -94,7 +116,10 @@ class DefaultPredictionStrategy:
 
     def exact_predictive_mean(self, test_mean, test_train_covar):
         """:371-412."""
-        res = (test_train_covar @ self.mean_cache.unsqueeze(-1)).squeeze(-1)
+        mc = self.mean_cache
+        if settings.observation_nan_policy.value() != "ignore":
+            mc = torch.nan_to_num(mc, nan=0.0)      # (:397-410: the columns of the missing observations drop out of the product)
+        res = (test_train_covar @ mc.unsqueeze(-1)).squeeze(-1)
         return res + test_mean
 
     def exact_predictive_covar(self, test_test_covar, test_train_covar):
@@ -255,12 +280,13 @@ class ExactGP(GP):
         n, m = ps.num_train, targets.shape[-1]
         full_inputs = [torch.cat([ti, inp], dim=-2) for ti, inp in zip(train_inputs, inputs)]
         full_targets = torch.cat([self.train_targets, targets], dim=-1)
+        fantasy_kwargs = {"noise": kwargs.pop("noise")} if "noise" in kwargs else {}      # exact_gp.py:229-232: the fantasy points' own noise
         with torch.no_grad():
             full_output = Module.__call__(self, *full_inputs, **kwargs)
             prior_covar = full_output.lazy_covariance_matrix
             k = to_dense(prior_covar[:n, n:].evaluate_kernel())                               # [n, m] prior cross-covariance
             new_prior = full_output.__class__(full_output.loc[..., n:], to_dense(prior_covar[n:, n:].evaluate_kernel()))
-            khat_new = to_dense(self.likelihood(new_prior, inputs).lazy_covariance_matrix)   # [m, m] incl. noise
+            khat_new = to_dense(self.likelihood(new_prior, inputs, **fantasy_kwargs).lazy_covariance_matrix)   # [m, m] incl. noise
             with settings.cg_tolerance(settings.eval_cg_tolerance.value()):
                 alpha = ps.mean_cache                                                         # [n]
                 Bm = ps.lik_train_train_covar.solve(k)                                        # [n, m]
@@ -280,9 +306,11 @@ class ExactGP(GP):
                 bot = torch.cat([torch.zeros(m, R.shape[-1], device=R.device, dtype=R.dtype), lsinv_t], dim=-1)
                 new_covar_cache = torch.cat([top, bot], dim=-2)
         new_model = copy.copy(self)                 # shares parameters / modules (exact_gp.py:244-263 deep-copies only the caches)
+        new_model._modules = dict(self._modules)    # (its own module table: the fantasy likelihood below must not replace this model's)
+        new_model.likelihood = self.likelihood.get_fantasy_likelihood(**fantasy_kwargs)     # exact_gp.py:251
         new_model.train_inputs = tuple(full_inputs)
         new_model.train_targets = full_targets
-        new_model.prediction_strategy = prediction_strategy(full_inputs, full_output, full_targets, self.likelihood)
+        new_model.prediction_strategy = prediction_strategy(full_inputs, full_output, full_targets, new_model.likelihood)
         new_model.prediction_strategy._mean_cache = new_cache.detach()
         if new_covar_cache is not None:
             new_model.prediction_strategy._covar_cache = new_covar_cache.detach()

@@ -1191,6 +1191,11 @@ class BatchLinearOperator(LinearOperator):
     def batch_shape(self):
         return self._batch_shape
 
+    def restrict(self, idx: torch.Tensor):
+        """Every member restricted to the same subset of its points (``observation_nan_policy("mask")``: a point counts as observed only if every
+        batch member observes it, settings.py:428-440)."""
+        return BatchLinearOperator([op.restrict(idx) if hasattr(op, "restrict") else op[idx][:, idx] for op in self.ops], self._batch_shape)
+
     def _size(self):
         return torch.Size([*self._batch_shape, *self.ops[0].shape[-2:]])
 

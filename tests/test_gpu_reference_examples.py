@@ -178,3 +178,34 @@ def test_cg_solve_vs_dense_inverse_with_gradients(ard, dev):
     want = ls64.grad * chain
     assert torch.allclose(got, want, rtol=2e-3, atol=1e-6 * float(want.abs().max())), (got, want)
     assert torch.allclose(rhs.grad.double().cpu(), rhs64.grad, rtol=0.03, atol=2e-4 * float(rhs64.grad.abs().max()))
+
+
+def _simple_cases():
+    from tests import simple_gp_cases as C
+
+    return C.CASES
+
+
+@pytest.mark.parametrize("case", _simple_cases(), ids=[c.__name__ for c in _simple_cases()])
+@pytest.mark.filterwarnings("ignore")
+def test_simple_gp_regression_cases_of_the_reference(case, dev):
+    """test/examples/test_simple_gp_regression.py:47-330, case by case (tests/simple_gp_cases.py), on the device."""
+    import gpytorch_amd as g
+
+    torch.manual_seed(1)
+    case(g, dev)
+
+
+@pytest.mark.parametrize("name", ["case_posterior_with_optimization", "case_skip_variances", "case_train_on_single_set_test_on_batch",
+                                  "case_train_on_batch_shared_hypers_over_batch", "case_missing_data_single", "case_fantasy_updates"])
+@pytest.mark.filterwarnings("ignore")
+def test_simple_gp_regression_cases_through_the_bbmm_branch(name, dev):
+    """The same reference cases with the dense branch switched off (``max_cholesky_size(0)``): every MLL, gradient, mean cache and LOVE cache of these
+    11-to-41-point problems comes from mBCG / SLQ / Lanczos on the fused kernels (the reference does the same in its CG-forcing example tests,
+    e.g. test/examples/test_white_noise_regression.py:56-102)."""
+    import gpytorch_amd as g
+    from tests import simple_gp_cases as C
+
+    torch.manual_seed(1)
+    with g.settings.max_cholesky_size(0), g.settings.num_trace_samples(100), g.settings.cg_tolerance(0.01), g.settings.max_preconditioner_size(0):
+        getattr(C, name)(g, dev)
