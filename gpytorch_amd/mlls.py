@@ -24,14 +24,32 @@ class MarginalLogLikelihood(Module):
         self.model = model
 
 
+MASK_DENSE_LIMIT = 8192    # structured operators without a point-restricted form are masked densely up to this many rows
+
+
 def _observed_only(marginal: MultivariateNormal, target: torch.Tensor):
-    """observation_nan_policy "mask" (reference :68-77): condition on the observed entries only.  The fused operators
-    restrict themselves to a subset of the points (no dense masking operator is needed)."""
-    keep = ~torch.isnan(target.reshape(-1, *marginal.event_shape)).any(dim=0)
+    """observation_nan_policy "mask" (reference :68-77): condition on the observed entries only -- an entry of the EVENT (a point, or a (point, task)
+    pair of a multitask distribution, flattened in the interleaved order of its covariance) counts as observed if every batch member observes it.
+    The fused operators restrict themselves to a subset of the points (no masking operator is needed); an operator whose structure an arbitrary subset
+    breaks (Kronecker multitask with some tasks of a point missing) is masked on its dense form, as the reference's ``MaskedLinearOperator``
+    ends up doing inside a Cholesky-sized solve."""
+    event = marginal.event_shape
+    keep = ~torch.isnan(target.reshape(-1, *event)).any(dim=0)
     idx = keep.reshape(-1).nonzero().squeeze(-1)
+    batch = target.shape[: target.dim() - len(event)]
+    mean = marginal.mean.reshape(*marginal.mean.shape[: marginal.mean.dim() - len(event)], -1)[..., idx]
+    target = target.reshape(*batch, -1)[..., idx]
     covar = marginal.lazy_covariance_matrix
-    sub = covar.restrict(idx) if hasattr(covar, "restrict") else covar[idx][:, idx]
-    return MultivariateNormal(marginal.mean[..., idx], sub), target[..., idx]
+    if hasattr(covar, "restrict") and len(event) == 1:
+        sub = covar.restrict(idx)
+    else:
+        if covar.shape[-1] > MASK_DENSE_LIMIT:
+            raise NotImplementedError(f"observation_nan_policy('mask') on a {type(covar).__name__} of {covar.shape[-1]} rows: no point-restricted form")
+        from .operators import DenseLinearOperator, to_dense
+
+        dense = to_dense(covar)
+        sub = DenseLinearOperator(dense[..., idx, :][..., :, idx])
+    return MultivariateNormal(mean, sub), target
 
 
 class ExactMarginalLogLikelihood(MarginalLogLikelihood):

@@ -372,3 +372,75 @@ def case_train_on_batch_shared_hypers_over_batch(g, dev):                       
 
 
 CASES += [case_train_on_single_set_test_on_batch, case_train_on_batch_shared_hypers_over_batch]
+
+
+def _multitask_model(g, num_tasks, rank, scale=False):
+    class MultitaskGPModel(g.models.ExactGP):
+        def __init__(self, x, y, likelihood):
+            super().__init__(x, y, likelihood)
+            self.mean_module = g.means.MultitaskMean(g.means.ConstantMean(), num_tasks=num_tasks)
+            base = g.kernels.ScaleKernel(g.kernels.RBFKernel()) if scale else g.kernels.RBFKernel()
+            self.covar_module = g.kernels.MultitaskKernel(base, num_tasks=num_tasks, rank=rank)
+
+        def forward(self, x):
+            return g.distributions.MultitaskMultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    return MultitaskGPModel
+
+
+def case_kronecker_multitask_mean_abs_error(g, dev):                                # test/examples/test_kronecker_multitask_gp_regression.py:20-91
+    train_x = torch.linspace(0, 1, 100, device=dev)
+    train_y = torch.stack([torch.sin(train_x * (2 * pi)) + torch.randn(100, device=dev) * 0.1,
+                           torch.cos(train_x * (2 * pi)) + torch.randn(100, device=dev) * 0.1], -1)
+    likelihood = g.likelihoods.MultitaskGaussianLikelihood(num_tasks=2).to(dev)
+    model = _multitask_model(g, 2, 2)(train_x, train_y, likelihood).to(dev)
+    model.train()
+    likelihood.train()
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.1)
+    mll = g.mlls.ExactMarginalLogLikelihood(likelihood, model)
+    for _ in range(50):
+        optimizer.zero_grad()
+        loss = -mll(model(train_x), train_y)
+        loss.backward()
+        optimizer.step()
+    model.eval()
+    likelihood.eval()
+    test_x = torch.linspace(0, 1, 51, device=dev)
+    with torch.no_grad():
+        preds = likelihood(model(test_x)).mean
+    assert torch.mean(torch.abs(torch.sin(test_x * (2 * pi)) - preds[:, 0])).item() < 0.05
+    assert torch.mean(torch.abs(torch.cos(test_x * (2 * pi)) - preds[:, 1])).item() < 0.05
+
+
+def case_missing_data_multitask(g, dev):                                            # test/examples/test_missing_data.py:177-195 ("mask" policy)
+    num_tasks = 10
+    train_x, test_x = torch.linspace(0, 1, 41, device=dev), torch.linspace(0, 1, 51, device=dev)
+    coefficients = torch.rand(1, num_tasks, device=dev)
+    train_y = torch.sin(2 * torch.pi * train_x)[:, None] * coefficients
+    train_y = train_y + torch.normal(0, 0.01, train_y.shape).to(dev)
+    test_y = torch.sin(2 * torch.pi * test_x)[:, None] * coefficients
+    train_y[::3, : num_tasks // 2] = torch.nan
+    train_y[::4, num_tasks // 2:] = torch.nan
+    likelihood = g.likelihoods.MultitaskGaussianLikelihood(num_tasks).to(dev)
+    model = _multitask_model(g, num_tasks, 1, scale=True)(train_x, train_y, likelihood).to(dev)
+    mll = g.mlls.ExactMarginalLogLikelihood(likelihood, model)
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.15)
+    with g.settings.observation_nan_policy("mask"):
+        model.train()
+        likelihood.train()
+        for _ in range(30):
+            optimizer.zero_grad()
+            output = model(train_x)
+            loss = -mll(output, train_y).sum()
+            assert not torch.isnan(output.mean).any() and not torch.isnan(loss)
+            loss.backward()
+            optimizer.step()
+        model.eval()
+        likelihood.eval()
+        with torch.no_grad():
+            prediction = model(test_x)
+            assert not torch.isnan(prediction.mean).any()
+            torch.testing.assert_close(prediction.mean, test_y, rtol=1e-4, atol=0.2)
+
+
+MULTITASK_CASES = [case_kronecker_multitask_mean_abs_error, case_missing_data_multitask]

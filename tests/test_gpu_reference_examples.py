@@ -183,7 +183,7 @@ def test_cg_solve_vs_dense_inverse_with_gradients(ard, dev):
 def _simple_cases():
     from tests import simple_gp_cases as C
 
-    return C.CASES
+    return C.CASES + C.MULTITASK_CASES
 
 
 @pytest.mark.parametrize("case", _simple_cases(), ids=[c.__name__ for c in _simple_cases()])
