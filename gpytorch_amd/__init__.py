@@ -16,7 +16,7 @@ kernel-matrix MVM, modified batched CG, Lanczos / SLQ, pivoted-Cholesky precondi
 The compute path is hand-written HIP for gfx950 (``csrc/``, C ABI in ``include/gpamd.h``);
 there is no CPU fallback.  The functional aliases below mirror ``gpytorch/__init__.py:34-278``.
 """
-from . import distributed, distributions, kernels, likelihoods, means, mlls, models, operators, priors, settings  # noqa: F401
+from . import constraints, distributed, distributions, kernels, likelihoods, means, mlls, models, operators, priors, settings  # noqa: F401
 from ._lib import LIB_PATH, GpamdError  # noqa: F401
 from .mlls import ExactMarginalLogLikelihood  # noqa: F401
 from .module import Module  # noqa: F401

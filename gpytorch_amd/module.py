@@ -17,55 +17,121 @@ def inv_softplus(x: torch.Tensor) -> torch.Tensor:
     return x + torch.log(-torch.expm1(-x))
 
 
-class Interval(nn.Module):
-    """``gpytorch/constraints/constraints.py``: sigmoid-transformed box constraint."""
+def _sigmoid(x):
+    return torch.sigmoid(x)
 
-    def __init__(self, lower_bound, upper_bound, initial_value=None):
+
+def _inv_sigmoid(x):
+    return torch.log(x) - torch.log1p(-x)
+
+
+def _softplus(x):
+    return torch.nn.functional.softplus(x)
+
+
+_KNOWN_INVERSES = {torch.exp: torch.log, torch.sigmoid: _inv_sigmoid, _sigmoid: _inv_sigmoid, _softplus: None, torch.nn.functional.softplus: None}
+
+
+class Interval(nn.Module):
+    """``gpytorch/constraints/constraints.py:17-150``: a parameter kept inside (lower, upper) by ``transform`` of its raw value -- a map onto (0, 1)
+    when both bounds are finite (sigmoid by default), onto (0, inf) when one is (softplus by default); ``transform=None`` registers the bounds
+    without enforcing them; ``initial_value`` (a constrained value) is stored as the RAW value the parameter starts at."""
+
+    def __init__(self, lower_bound, upper_bound, transform=_sigmoid, inv_transform=_inv_sigmoid, initial_value=None):
+        dtype = torch.get_default_dtype()
+        lower_bound = torch.as_tensor(lower_bound).to(dtype)
+        upper_bound = torch.as_tensor(upper_bound).to(dtype)
+        if torch.any(torch.ge(lower_bound, upper_bound)):
+            raise ValueError("Got parameter bounds with empty intervals.")
+        if type(self) is Interval and (torch.max(upper_bound) == math.inf or torch.min(lower_bound) == -math.inf):
+            raise ValueError("Cannot make an Interval directly with non-finite bounds. Use a derived class like GreaterThan or LessThan instead.")
         super().__init__()
-        self.register_buffer("lower_bound", torch.as_tensor(float(lower_bound)))
-        self.register_buffer("upper_bound", torch.as_tensor(float(upper_bound)))
-        self._initial_value = initial_value
+        self.register_buffer("lower_bound", lower_bound)
+        self.register_buffer("upper_bound", upper_bound)
+        self._transform = transform
+        self._inv_transform = inv_transform
+        if transform is not None and inv_transform is None:
+            known = _KNOWN_INVERSES.get(transform)
+            if known is None and transform in (_softplus, torch.nn.functional.softplus):
+                known = inv_softplus
+            if known is None:
+                raise RuntimeError("Must specify inv_transform for custom transforms")
+            self._inv_transform = known
+        self._initial_value = None if initial_value is None else self.inverse_transform(torch.as_tensor(initial_value))
 
     @property
-    def enforced(self):
-        return True
+    def enforced(self) -> bool:
+        return self._transform is not None
+
+    def check(self, tensor) -> bool:
+        return bool(torch.all(tensor <= self.upper_bound) and torch.all(tensor >= self.lower_bound))
+
+    def check_raw(self, tensor) -> bool:
+        return self.check(self.transform(tensor))
+
+    def intersect(self, other):
+        """The intersection of two constraints with the same transform (``constraints.py:87-101``)."""
+        if self._transform != other._transform:
+            raise RuntimeError("Cant intersect Interval constraints with conflicting transforms!")
+        return Interval(torch.max(self.lower_bound, other.lower_bound), torch.min(self.upper_bound, other.upper_bound))
 
     def transform(self, tensor):
-        return torch.sigmoid(tensor) * (self.upper_bound - self.lower_bound) + self.lower_bound
+        if not self.enforced:
+            return tensor
+        return self._transform(tensor) * (self.upper_bound - self.lower_bound) + self.lower_bound
 
     def inverse_transform(self, tensor):
-        p = (tensor - self.lower_bound) / (self.upper_bound - self.lower_bound)
-        return torch.log(p) - torch.log1p(-p)
+        if not self.enforced:
+            return tensor
+        return self._inv_transform((tensor - self.lower_bound) / (self.upper_bound - self.lower_bound))
 
     @property
     def initial_value(self):
+        """The RAW value the parameter starts at (None if no initial value was given)."""
         return self._initial_value
+
+    def __iter__(self):
+        yield self.lower_bound
+        yield self.upper_bound
 
 
 class GreaterThan(Interval):
-    """``constraints.py:160-178``: softplus(raw) + lower_bound."""
+    """``constraints.py:153-178``: transform(raw) + lower_bound, softplus by default."""
 
-    def __init__(self, lower_bound, initial_value=None):
-        super().__init__(lower_bound, math.inf, initial_value)
+    def __init__(self, lower_bound, transform=_softplus, inv_transform=inv_softplus, initial_value=None):
+        super().__init__(lower_bound, math.inf, transform=transform, inv_transform=inv_transform, initial_value=initial_value)
 
     def transform(self, tensor):
-        return torch.nn.functional.softplus(tensor) + self.lower_bound
+        return self._transform(tensor) + self.lower_bound if self.enforced else tensor
 
     def inverse_transform(self, tensor):
-        return inv_softplus(tensor - self.lower_bound)
+        return self._inv_transform(tensor - self.lower_bound) if self.enforced else tensor
 
 
 class Positive(GreaterThan):
     """``constraints.py:181-194``."""
 
-    def __init__(self, initial_value=None):
-        super().__init__(0.0, initial_value)
+    def __init__(self, transform=_softplus, inv_transform=inv_softplus, initial_value=None):
+        super().__init__(0.0, transform=transform, inv_transform=inv_transform, initial_value=initial_value)
 
     def transform(self, tensor):
-        return torch.nn.functional.softplus(tensor)
+        return self._transform(tensor) if self.enforced else tensor
 
     def inverse_transform(self, tensor):
-        return inv_softplus(tensor)
+        return self._inv_transform(tensor) if self.enforced else tensor
+
+
+class LessThan(Interval):
+    """``constraints.py:197-222``: upper_bound - transform(-raw)."""
+
+    def __init__(self, upper_bound, transform=_softplus, inv_transform=inv_softplus, initial_value=None):
+        super().__init__(-math.inf, upper_bound, transform=transform, inv_transform=inv_transform, initial_value=initial_value)
+
+    def transform(self, tensor):
+        return -self._transform(-tensor) + self.upper_bound if self.enforced else tensor
+
+    def inverse_transform(self, tensor):
+        return -self._inv_transform(-(tensor - self.upper_bound)) if self.enforced else tensor
 
 
 class Module(nn.Module):
@@ -86,11 +152,32 @@ class Module(nn.Module):
     def register_constraint(self, param_name: str, constraint: Interval):
         self.add_module(param_name + "_constraint", constraint)
         self._constraints_map[param_name] = constraint
-        if constraint.initial_value is not None:
-            self.initialize(**{param_name: constraint.inverse_transform(torch.as_tensor(constraint.initial_value))})
+        if constraint.initial_value is not None:       # (already a raw value: module.py:348-349)
+            self.initialize(**{param_name: constraint.initial_value})
 
     def constraint_for(self, param_name: str):
         return self._constraints_map.get(param_name)
+
+    def constraint_for_parameter_name(self, param_name: str):
+        """module.py:206-227: the constraint of a (possibly dotted, nested) parameter name, or None."""
+        base, _, name = param_name.rpartition(".")
+        mod = self
+        for part in (base.split(".") if base else []):
+            mod = getattr(mod, part, None)
+            if mod is None:
+                return None
+        return mod.constraint_for(name) if isinstance(mod, Module) else None
+
+    def named_parameters_and_constraints(self):
+        """module.py:229-231."""
+        for name, param in self.named_parameters():
+            yield name, param, self.constraint_for_parameter_name(name)
+
+    def named_constraints(self):
+        for name, mod in self.named_modules():
+            if isinstance(mod, Module):
+                for pname, c in mod._constraints_map.items():
+                    yield (f"{name}.{pname}_constraint" if name else f"{pname}_constraint"), c
 
     def register_prior(self, name, prior, param_or_closure, setting_closure=None):
         if isinstance(param_or_closure, str):

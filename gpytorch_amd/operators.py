@@ -226,7 +226,7 @@ class LinearOperator:
             iq = (sol * r.to(torch.float64)).sum(-2).to(r.dtype)
             if reduce_inv_quad:
                 iq = iq.sum(-1)
-        ld = (2.0 * Lc.diagonal().log().sum()).to(self.dtype) if logdet else None
+        ld = (2.0 * Lc.diagonal(dim1=-2, dim2=-1).log().sum(-1)).to(self.dtype) if logdet else None      # (one value per batch member)
         return iq, ld
 
     def inv_quad(self, inv_quad_rhs, reduce_inv_quad=True):
@@ -452,7 +452,7 @@ class DiagLinearOperator(LinearOperator):
             iq = (r.pow(2) / self._diag.unsqueeze(-1)).sum(-2)
             if reduce_inv_quad:
                 iq = iq.sum(-1)
-        return iq, (self._diag.log().sum() if logdet else None)
+        return iq, (self._diag.log().sum(-1) if logdet else None)
 
 
 class ConstantDiagLinearOperator(DiagLinearOperator):
@@ -507,6 +507,11 @@ class RootLinearOperator(LinearOperator):
     def _size(self):
         n = self.root.shape[-2]
         return torch.Size([n, n])
+
+    def root_decomposition(self, method=None):
+        """An operator given AS its root is its own root decomposition, whatever the root's column count (the reference's
+        ``RootLinearOperator.root_decomposition``; ``test/distributions/test_multivariate_normal.py:307-325`` samples through a 5 x 10 root)."""
+        return self
 
     def _matmul(self, rhs):
         return self.root @ (self.root.mT @ rhs)
