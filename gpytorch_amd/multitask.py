@@ -470,32 +470,125 @@ class MultitaskMean(Mean):
 
 
 class MultitaskMultivariateNormal(MultivariateNormal):
-    """n x T event, interleaved flattening row = i*T + tau (multitask_multivariate_normal.py:34-71)."""
+    """An [n, T] event (leading batch dimensions allowed) over an nT x nT covariance (``multitask_multivariate_normal.py:14-297``).  ``interleaved``
+    (the default, and the layout of every operator this package builds): row = i T + tau, data-major; otherwise row = tau n + i, task-major."""
 
     def __init__(self, mean: torch.Tensor, covariance_matrix, validate_args=False, interleaved=True):
-        if not interleaved:
-            raise NotImplementedError("only the interleaved (data-major, task-minor) layout is implemented")
+        if mean.dim() < 2:
+            raise RuntimeError("mean should be a matrix or a batch matrix (batch mode)")
         self._output_shape = mean.shape
-        super().__init__(mean.reshape(-1), covariance_matrix)
+        self._interleaved = interleaved
+        flat = mean if interleaved else mean.mT
+        super().__init__(flat.reshape(*mean.shape[:-2], -1), covariance_matrix)
 
     @property
     def event_shape(self):
         return self._output_shape[-2:]
 
     @property
+    def batch_shape(self):
+        return self._output_shape[:-2]
+
+    @property
     def num_tasks(self):
         return self._output_shape[-1]
 
+    def _to_event(self, flat):
+        """[..., n T] in this distribution's flattening -> [..., n, T]."""
+        n, T = self._output_shape[-2:]
+        return flat.reshape(*flat.shape[:-1], n, T) if self._interleaved else flat.reshape(*flat.shape[:-1], T, n).mT
+
+    def _to_flat(self, value):
+        return (value if self._interleaved else value.mT).reshape(*value.shape[:-2], -1)
+
     @property
     def mean(self):
-        return self.loc.view(self._output_shape)
+        return self._to_event(self.loc)
 
     @property
     def variance(self):
-        return super().variance.view(self._output_shape)
+        return self._to_event(super().variance)
 
     def log_prob(self, value):
-        return super().log_prob(value.reshape(-1))
+        return super().log_prob(self._to_flat(value))
+
+    def rsample(self, sample_shape=torch.Size(), base_samples=None):
+        if base_samples is not None:
+            base_samples = self._to_flat(base_samples)
+        return self._to_event(super().rsample(sample_shape, base_samples))
+
+    sample = rsample
+
+    def __add__(self, other):
+        if isinstance(other, MultivariateNormal):
+            return self.__class__(self.mean + other.mean, self.lazy_covariance_matrix + other.lazy_covariance_matrix, interleaved=self._interleaved)
+        return self.__class__(self.mean + other, self._covar, interleaved=self._interleaved)
+
+    def __mul__(self, other):
+        if not isinstance(other, (int, float)):
+            raise RuntimeError("Can only multiply by scalars")
+        if other == 1:
+            return self
+        covar = self._covar.mul(other ** 2) if self.islazy else self._covar * (other ** 2)
+        return self.__class__(self.mean * other, covar, interleaved=self._interleaved)
+
+    def expand(self, batch_size):
+        batch = torch.Size(batch_size)
+        N = self.loc.shape[-1]
+        return self.__class__(self.mean.expand(*batch, *self._output_shape[-2:]), self._rewrap(self.covariance_matrix.expand(*batch, N, N)), interleaved=self._interleaved)
+
+    def __getitem__(self, idx):
+        raise NotImplementedError("indexing a MultitaskMultivariateNormal: index its mean / covariance_matrix")
+
+    # ---- constructors from single-output distributions (``:86-190``).  The tasks are INDEPENDENT here: the covariance is block diagonal.  It is
+    # assembled densely (the reference, too, evaluates the member covariances for ``from_independent_mvns``); a batch of GPs that should stay on
+    # the fused path is trained and queried as a batch model -- these constructors serve the layers that want an [n, T]-shaped result.
+    @classmethod
+    def from_batch_mvn(cls, batch_mvn, task_dim=-1):
+        nb = len(batch_mvn.batch_shape)
+        td = task_dim if task_dim >= 0 else nb + task_dim
+        if td < 0 or td >= max(nb, 1) or nb == 0:
+            raise ValueError(f"task_dim of {task_dim} is incompatible with MVN batch shape of {batch_mvn.batch_shape}")
+        mean = batch_mvn.mean.movedim(td, -1)                                   # [*rest, n, T]
+        blocks = batch_mvn.covariance_matrix.movedim(td, -3)                    # [*rest, T, n, n]
+        T, n = blocks.shape[-3], blocks.shape[-1]
+        full = torch.zeros(*blocks.shape[:-3], n, T, n, T, dtype=blocks.dtype, device=blocks.device)
+        tau = torch.arange(T, device=blocks.device)
+        full[..., :, tau, :, tau] = blocks.movedim(-3, 0)                       # entry (i, tau; j, tau) = K_tau[i, j]: interleaved block diagonal
+        return cls(mean, full.reshape(*blocks.shape[:-3], n * T, n * T))
+
+    @classmethod
+    def from_independent_mvns(cls, mvns):
+        if len(mvns) < 2:
+            raise ValueError("Must provide at least 2 MVNs to form a MultitaskMultivariateNormal")
+        if any(isinstance(m, MultitaskMultivariateNormal) for m in mvns):
+            raise ValueError("Cannot accept MultitaskMultivariateNormals")
+        if not all(m.batch_shape == mvns[0].batch_shape for m in mvns[1:]):
+            batch = torch.broadcast_shapes(*(m.batch_shape for m in mvns))
+            mvns = [m.expand(batch) for m in mvns]
+        if not all(m.event_shape == mvns[0].event_shape for m in mvns[1:]):
+            raise ValueError("All MultivariateNormals must have the same event shape")
+        mean = torch.stack([m.mean for m in mvns], -1)
+        covar = torch.stack([torch.block_diag(*bs) for bs in zip(*[m.covariance_matrix.reshape(-1, *m.covariance_matrix.shape[-2:]) for m in mvns])])
+        N = covar.shape[-1]
+        return cls(mean, covar.reshape(*mean.shape[:-2], N, N), interleaved=False)          # task-major, as the reference returns it
+
+    @classmethod
+    def from_repeated_mvn(cls, mvn, num_tasks):
+        return cls.from_batch_mvn(mvn.expand(torch.Size([num_tasks]) + mvn.batch_shape), task_dim=0)
+
+    def to_data_independent_dist(self, jitter_val=1e-4):
+        """``:255-276``: one T x T distribution per data point (the task covariance at each point, cross-point covariances dropped)."""
+        n, T = self._output_shape[-2:]
+        full = self.covariance_matrix
+        if self._interleaved:
+            data = torch.arange(0, n * T, T, device=full.device).view(-1, 1, 1)
+            task = torch.arange(T, device=full.device)
+        else:
+            data = torch.arange(n, device=full.device).view(-1, 1, 1)
+            task = torch.arange(0, n * T, n, device=full.device)
+        task_covars = full[..., data + task.unsqueeze(-2), data + task.unsqueeze(-1)]
+        return MultivariateNormal(self.mean, task_covars + jitter_val * torch.eye(T, dtype=full.dtype, device=full.device))
 
 
 class MultitaskGaussianLikelihood(_GaussianLikelihoodBase):
