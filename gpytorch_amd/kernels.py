@@ -14,6 +14,7 @@ import torch
 from . import backend as B
 from .functions import KernelSpec
 from .module import Interval, Module, Positive
+from .module import AttrGetter, AttrSetter
 from .operators import BatchLinearOperator, FusedKernelLinearOperator, LinearOperator
 
 
@@ -34,7 +35,7 @@ class Kernel(Module):
             self.register_parameter("raw_lengthscale", torch.nn.Parameter(torch.zeros(*self._batch_shape, 1, n_ls)))
             self.register_constraint("raw_lengthscale", Positive() if lengthscale_constraint is None else lengthscale_constraint)
             if lengthscale_prior is not None:
-                self.register_prior("lengthscale_prior", lengthscale_prior, lambda m: m.lengthscale, lambda m, v: m._set_lengthscale(v))
+                self.register_prior("lengthscale_prior", lengthscale_prior, AttrGetter("lengthscale"), AttrSetter("_set_lengthscale"))
 
     @property
     def batch_shape(self):
@@ -287,7 +288,7 @@ class PeriodicKernel(Kernel):
         self.register_parameter("raw_period_length", torch.nn.Parameter(torch.zeros(*self._batch_shape, 1, n_p)))
         self.register_constraint("raw_period_length", Positive() if period_length_constraint is None else period_length_constraint)
         if period_length_prior is not None:
-            self.register_prior("period_length_prior", period_length_prior, lambda m: m.period_length, lambda m, v: m._set_period_length(v))
+            self.register_prior("period_length_prior", period_length_prior, AttrGetter("period_length"), AttrSetter("_set_period_length"))
 
     @property
     def period_length(self):
@@ -376,7 +377,7 @@ class ScaleKernel(Kernel):
         self.register_parameter("raw_outputscale", torch.nn.Parameter(torch.zeros(self._batch_shape)))
         self.register_constraint("raw_outputscale", Positive() if outputscale_constraint is None else outputscale_constraint)
         if outputscale_prior is not None:
-            self.register_prior("outputscale_prior", outputscale_prior, lambda m: m.outputscale, lambda m, v: m._set_outputscale(v))
+            self.register_prior("outputscale_prior", outputscale_prior, AttrGetter("outputscale"), AttrSetter("_set_outputscale"))
 
     @property
     def is_stationary(self):

@@ -10,7 +10,7 @@ import torch
 from . import settings
 from .distributions import MultivariateNormal
 from .linear_cg import NumericalWarning
-from .module import GreaterThan, Module
+from .module import AttrGetter, AttrSetter, GreaterThan, Module
 from .operators import ConstantDiagLinearOperator, DiagLinearOperator, FixedPlusConstantDiagLinearOperator, ZeroLinearOperator
 
 
@@ -24,7 +24,7 @@ class HomoskedasticNoise(Module):
         self.register_parameter("raw_noise", torch.nn.Parameter(torch.zeros(*batch_shape, 1)))
         self.register_constraint("raw_noise", GreaterThan(1e-4) if noise_constraint is None else noise_constraint)
         if noise_prior is not None:
-            self.register_prior("noise_prior", noise_prior, lambda m: m.noise, lambda m, v: m._set_transformed("raw_noise", v))
+            self.register_prior("noise_prior", noise_prior, AttrGetter("noise"), AttrSetter("_set_transformed", "raw_noise"))
 
     @property
     def noise(self):

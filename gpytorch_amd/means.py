@@ -27,7 +27,15 @@ class ConstantMean(Mean):
         if constant_constraint is not None:
             self.register_constraint("raw_constant", constant_constraint)
         if constant_prior is not None:
-            self.register_prior("mean_prior", constant_prior, lambda m: m.constant, lambda m, v: m._set_transformed("raw_constant", v))
+            self.register_prior("mean_prior", constant_prior, self._constant_param, self._constant_closure)
+
+    @staticmethod
+    def _constant_param(m):        # constant_mean.py:99-101
+        return m.constant
+
+    @staticmethod
+    def _constant_closure(m, value):
+        m._set_transformed("raw_constant", value)
 
     @property
     def constant(self):

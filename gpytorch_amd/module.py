@@ -134,6 +134,27 @@ class LessThan(Interval):
         return -self._inv_transform(-(tensor - self.upper_bound)) if self.enforced else tensor
 
 
+class AttrGetter:
+    """``closure(module) -> module.<name>``: what a prior is evaluated on.  A class, not a lambda, so that modules with priors pickle
+    (``test/kernels/test_scale_kernel.py:137-141``, ``test/likelihoods/test_gaussian_likelihood.py:23-27``: pickle round trips with a prior)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __call__(self, module):
+        return getattr(module, self.name)
+
+
+class AttrSetter:
+    """``setting_closure(module, value) -> module.<method>(*args, value)``: how a value sampled from a prior is written back."""
+
+    def __init__(self, method, *args):
+        self.method, self.args = method, args
+
+    def __call__(self, module, value):
+        return getattr(module, self.method)(*self.args, value)
+
+
 class Module(nn.Module):
     """Parameter / constraint / prior registry (``gpytorch/module.py``)."""
 
@@ -180,13 +201,11 @@ class Module(nn.Module):
                     yield (f"{name}.{pname}_constraint" if name else f"{pname}_constraint"), c
 
     def register_prior(self, name, prior, param_or_closure, setting_closure=None):
-        if isinstance(param_or_closure, str):
-            pname = param_or_closure
+        from .priors import Prior
 
-            def closure(m, pname=pname):
-                return getattr(m, pname)
-        else:
-            closure = param_or_closure
+        if not isinstance(prior, Prior):     # (kernels/scale_kernel.py:91-92, periodic_kernel.py:107-108, index_kernel.py:74-75: the reference's type check)
+            raise TypeError("Expected gpytorch.priors.Prior but got " + type(prior).__name__)
+        closure = AttrGetter(param_or_closure) if isinstance(param_or_closure, str) else param_or_closure
         self.add_module(name, prior) if isinstance(prior, nn.Module) else None
         self._priors_reg[name] = (prior, closure, setting_closure)
 

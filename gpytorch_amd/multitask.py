@@ -403,6 +403,13 @@ class IndexKernel(Kernel):
         self.register_parameter("covar_factor", torch.nn.Parameter(torch.randn(num_tasks, rank)))
         self.register_parameter("raw_var", torch.nn.Parameter(torch.randn(num_tasks)))
         self.register_constraint("raw_var", Positive() if var_constraint is None else var_constraint)
+        if prior is not None:       # index_kernel.py:73-76: a prior on the task covariance matrix B B^T + diag(v) itself
+            from .module import AttrGetter
+
+            self.register_prior("IndexKernelPrior", prior, AttrGetter("covar_matrix"))
+
+    def _eval_covar_matrix(self):
+        return self.covar_matrix
 
     @property
     def var(self):
