@@ -639,8 +639,21 @@ class MultitaskGaussianLikelihood(_GaussianLikelihoodBase):
             out = out + self.noise
         return out
 
+    @property
+    def task_noise_covar(self):
+        raise AttributeError("This likelihood holds diagonal task noises (rank 0): there is no low-rank task noise covariance")
+
+    @task_noise_covar.setter
+    def task_noise_covar(self, value):
+        # multitask_gaussian_likelihood.py:262-270: a full task-noise matrix can only be set on a rank > 0 likelihood
+        raise AttributeError("Cannot set non-diagonal task noises when covariance is diagonal.")
+
     def marginal(self, function_dist, *params, **kwargs):
         mean, covar = function_dist.mean, function_dist.lazy_covariance_matrix
         n = covar.shape[-1] // self.num_tasks
-        covar = covar + TaskNoiseDiagLinearOperator(self._task_noise_vector(), n)
-        return function_dist.__class__(mean, covar)
+        if getattr(function_dist, "_interleaved", True):
+            return function_dist.__class__(mean, covar + TaskNoiseDiagLinearOperator(self._task_noise_vector(), n))
+        # task-major flattening (multitask_gaussian_likelihood.py:118-141 orders the Kronecker factors of the noise the same way)
+        from .operators import DiagLinearOperator
+
+        return function_dist.__class__(mean, covar + DiagLinearOperator(self._task_noise_vector().repeat_interleave(n)), interleaved=False)

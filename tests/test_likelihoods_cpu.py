@@ -80,3 +80,33 @@ def test_dirichlet_transform_equals_the_references_own_output():
     plain = FixedNoiseGaussianLikelihood(noise=torch.rand(3, 5) + 0.1, learn_additional_noise=True, batch_shape=torch.Size([3]))
     assert plain.second_noise_covar.raw_noise.shape == (3, 1)
     assert FixedNoiseGaussianLikelihood(noise=torch.rand(5) + 0.1, learn_additional_noise=True).second_noise_covar.raw_noise.shape == (1,)
+
+
+@pytest.mark.parametrize("interleaved,lazy", [(True, True), (True, False), (False, True)])
+def test_multitask_likelihood_marginal_variance(interleaved, lazy):
+    """test/likelihoods/test_multitask_gaussian_likelihood.py:31-37 (rank 0; both flattenings of the multitask covariance, :76-82)."""
+    from gpytorch_amd.operators import DenseLinearOperator
+
+    lik = g.likelihoods.MultitaskGaussianLikelihood(num_tasks=4, rank=0, has_global_noise=False)
+    lik.task_noises = torch.tensor([0.1, 0.2, 0.3, 0.4])
+    c = torch.tensor([1, 0.6, 0.4, 0.2, 0.1])
+    i = torch.arange(5)
+    data = c[(i[:, None] - i[None, :]).abs()]                       # the Toeplitz data covariance of the reference's test
+    t = torch.tensor([[1.0], [2.0], [3.0], [4.0]])
+    cov = torch.kron(data, t @ t.t()) if interleaved else torch.kron(t @ t.t(), data)
+    dist = g.distributions.MultitaskMultivariateNormal(torch.randn(5, 4), DenseLinearOperator(cov) if lazy else cov, interleaved=interleaved)
+    torch.testing.assert_close(lik(dist).variance, torch.tensor([1.1, 4.2, 9.3, 16.4]).repeat(5, 1))
+
+
+def test_multitask_likelihood_setters():
+    """test/likelihoods/test_multitask_gaussian_likelihood.py:47-62 (rank 0: diagonal task noises; a full task-noise matrix cannot be set)."""
+    lik = g.likelihoods.MultitaskGaussianLikelihood(num_tasks=3, rank=0)
+    lik.noise = 0.5
+    assert abs(lik.noise.item() - 0.5) < 1e-6
+    lik.task_noises = torch.tensor([0.04, 0.04, 0.04])
+    assert all(abs(lik.task_noises[k].item() - 0.04) < 1e-6 for k in range(3))
+    a = torch.randn(3, 2)
+    with pytest.raises(AttributeError, match="task noises"):
+        lik.task_noise_covar = a @ a.t()
+    with pytest.raises(NotImplementedError):                          # (rank > 0 -- inter-task noise correlations -- is outside the built path, said loudly)
+        g.likelihoods.MultitaskGaussianLikelihood(num_tasks=3, rank=2)
