@@ -16,8 +16,6 @@ LN2 = math.log(2.0)
 
 
 def prep_points(kind, x, lengthscale, shift=None, param=None):
-    if kind == "rq":
-        raise NotImplementedError("cpu double: rbf / matern only")
     n, d = x.shape[-2], x.shape[-1]
     dp = B.padded_dim(d)
     wd = B.work_dtype(x)
@@ -28,6 +26,10 @@ def prep_points(kind, x, lengthscale, shift=None, param=None):
     if ls.numel() not in (1, d):
         raise ValueError(f"lengthscale must have 1 or {d} elements, got {ls.numel()}")
     z = torch.zeros(n, dp, dtype=torch.float64)
+    if kind == "rq":                      # z = (x - shift) / (l sqrt(2 alpha)), k = (1 + |dz|^2)^-alpha  (backend.prep_coef_of; VALUES only: no derivative double)
+        param = float(param)
+        z[:, :d] = xs / ls / (2.0 * param) ** 0.5
+        return B.PreparedPoints(z.to(wd), n, d, dp, kind, param)
     z[:, :d] = B.prep_coef(kind) * xs / ls
     return B.PreparedPoints(z.to(wd), n, d, dp, kind, None)
 
@@ -38,7 +40,10 @@ def _k_and_dk(x1, x2):
     sq = (z1[:, None, :] - z2[None, :, :]).pow(2)
     s = sq.sum(-1)
     kind = x1.kind
-    if kind == "rbf":
+    if kind == "rq":
+        k = (1.0 + s).pow(-x1.param)
+        dk = -x1.param * (1.0 + s).pow(-x1.param - 1.0)
+    elif kind == "rbf":
         k = torch.exp2(-s)
         dk = -LN2 * k
     else:
