@@ -401,6 +401,8 @@ class ScaleKernel(Kernel):
     def forward(self, x1, x2, diag=False, **params):
         orig = self.base_kernel(x1, x2, diag=diag, **params)
         os_ = self.outputscale
+        if params.get("last_dim_is_batch", False):      # scale_kernel.py:110-112: the input dimensions became the LAST batch dimension
+            os_ = os_.unsqueeze(-1)
         if diag:
             return orig * os_.unsqueeze(-1)
         if isinstance(orig, LinearOperator):  # scale_kernel.py:117-118: outputscale.view(*batch, 1, 1)

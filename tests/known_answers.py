@@ -109,3 +109,51 @@ def check_stationary_and_periodic_unit_tests(g, dev):
         k.eval()
         actual = torch.stack([((a[i].unsqueeze(1) - b[i].unsqueeze(0)) * math.pi / period[i].unsqueeze(-1)).sin().pow(2).sum(-1).div(ls[i]).mul(-2.0).exp() for i in range(2)])
         assert dn(k(a, b).to_dense() - actual) < 1e-5
+
+
+def check_scale_kernel_unit_tests(g, dev):
+    """``test/kernels/test_scale_kernel.py:24-127``: an outputscale over an ARD kernel (dense, diagonal, ``last_dim_is_batch``), a per-member outputscale
+    over a batch kernel (the outputscale follows the kernel's batch dimensions, NOT the dimension-batch ``last_dim_is_batch`` appends), ``initialize``,
+    stationarity, inherited active dimensions."""
+    K = g.kernels
+    T = lambda *a: torch.tensor(*a, dtype=torch.float, device=dev)  # noqa: E731
+    dn = lambda x: float(x.norm())  # noqa: E731
+    with torch.no_grad():
+        a, b, ls = T([[1, 2], [2, 4]]), T([[1, 3], [0, 4]]), T([1, 2]).view(1, 2)
+        base = K.RBFKernel(ard_num_dims=2).to(dev)
+        base.initialize(lengthscale=ls)
+        k = K.ScaleKernel(base).to(dev)
+        k.initialize(outputscale=T([3]))
+        k.eval()
+        sa, sb = a / ls, b / ls
+        actual = (sa.unsqueeze(-2) - sb.unsqueeze(-3)).pow(2).sum(-1).mul(-0.5).exp() * 3
+        assert dn(k(a, b).to_dense() - actual) < 1e-5 and dn(k(a, b).diagonal(dim1=-1, dim2=-2) - actual.diagonal()) < 1e-5
+        per_dim = (sa.mT.unsqueeze(-1) - sb.mT.unsqueeze(-2)).pow(2).mul(-0.5).exp() * 3
+        res = k(a, b, last_dim_is_batch=True)
+        assert dn(res.to_dense() - per_dim) < 1e-5 and dn(res.diagonal(dim1=-1, dim2=-2) - per_dim.diagonal(dim1=-1, dim2=-2)) < 1e-5
+        a = T([[[1, 2, 3], [2, 4, 0]], [[-1, 1, 2], [2, 1, 4]]])
+        b = T([[[1, 3, 1]], [[2, -1, 0]]]).repeat(1, 2, 1)
+        ls = T([[[1, 2, 1]]])
+        base = K.RBFKernel(batch_shape=torch.Size([2]), ard_num_dims=3).to(dev)
+        base.initialize(lengthscale=ls)
+        k = K.ScaleKernel(base, batch_shape=torch.Size([2])).to(dev)
+        k.initialize(outputscale=T([1, 2]))
+        k.eval()
+        sa, sb = a / ls, b / ls
+        actual = (sa.unsqueeze(-2) - sb.unsqueeze(-3)).pow(2).sum(-1).mul(-0.5).exp()
+        actual[1] *= 2
+        assert dn(k(a, b).to_dense() - actual) < 1e-5 and dn(k(a, b).diagonal(dim1=-1, dim2=-2) - actual.diagonal(dim1=-1, dim2=-2)) < 1e-5
+        per_dim = (sa.mT.unsqueeze(-1) - sb.mT.unsqueeze(-2)).pow(2).mul(-0.5).exp()
+        per_dim[1] *= 2
+        res = k(a, b, last_dim_is_batch=True)
+        assert dn(res.to_dense() - per_dim) < 1e-5 and dn(res.diagonal(dim1=-1, dim2=-2) - per_dim.diagonal(dim1=-2, dim2=-1)) < 1e-5
+    k = K.ScaleKernel(K.RBFKernel())
+    k.initialize(outputscale=3.14)
+    assert dn(k.outputscale - torch.tensor(3.14).view_as(k.outputscale)) < 1e-5
+    k = K.ScaleKernel(K.RBFKernel(), batch_shape=torch.Size([2]))
+    v = torch.tensor([3.14, 4.13])
+    k.initialize(outputscale=v)
+    assert dn(k.outputscale - v.view_as(k.outputscale)) < 1e-5
+    assert K.ScaleKernel(K.RBFKernel()).is_stationary
+    base = K.RBFKernel(active_dims=(1, 2), ard_num_dims=2)
+    assert torch.all(K.ScaleKernel(base).active_dims == base.active_dims)

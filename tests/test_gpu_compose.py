@@ -371,3 +371,11 @@ def test_generic_kernel_battery_of_the_reference(family, dev):
 
     (_, make, make_ard), = [f for f in families(g) if f[0] == family]
     run_battery(make, make_ard, dev)
+
+
+def test_scale_kernel_unit_tests_of_the_reference(dev):
+    """test/kernels/test_scale_kernel.py:24-127 (tests/known_answers.py)."""
+    import gpytorch_amd as g
+    from tests.known_answers import check_scale_kernel_unit_tests
+
+    check_scale_kernel_unit_tests(g, dev)

@@ -40,6 +40,16 @@ def test_generic_kernel_battery_on_the_cpu_double(family, monkeypatch):
     assert "getitem" in done and "pickle_dtype" in done and ("ard" in done or make_ard is None)
 
 
+def test_scale_kernel_unit_tests_on_the_cpu_double(monkeypatch):
+    from tests.shim import cpu_backend
+
+    cpu_backend.install(monkeypatch)
+    import gpytorch_amd as g
+    from tests.known_answers import check_scale_kernel_unit_tests
+
+    check_scale_kernel_unit_tests(g, torch.device("cpu"))
+
+
 def test_oracle_reproduces_the_same_literals():
     """test/kernels/test_additive_and_product_kernels.py:92-157: the four-digit literals against the oracle's RBF."""
     a = torch.tensor([4.0, 2.0, 8.0], dtype=torch.float64).view(3, 1)
